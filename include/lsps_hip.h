@@ -1,0 +1,138 @@
+/*
+ * lsps_hip.h — C-ABI of liblsps_hip.so: the MI355X (gfx950) kernels behind the LSPS depth path.
+ *
+ * The reference (masabdi/LSPS) has no FFI seam: its depth encoder/decoder path is Python that
+ * calls torch.nn built-ins.  Each entry point below replaces ONE torch built-in call site of
+ * the reference (cited per function as src/trainers/<file>:<line>); lsps_amd/trainers binds
+ * them through ctypes from torch.autograd.Function.forward/backward.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every tensor is float32, contiguous, NCHW (row-major),
+ *     resident in device (HBM) memory; `stream` is a hipStream_t passed as void*;
+ *   - every call is asynchronous on `stream`, never allocates and never synchronises: scratch
+ *     memory is handed in by the caller (`ws`, sized by the matching *_workspace_bytes);
+ *   - return value 0 = launched, negative = rejected (LSPS_E_*); lsps_last_error() explains.
+ *   - Conv2d weight is (K, C, R, S); ConvTranspose2d weight is (C_in, C_out, R, S) as in torch.
+ */
+#ifndef LSPS_HIP_H
+#define LSPS_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSPS_ABI_VERSION 1
+
+#define LSPS_E_ARG   (-1)   /* bad argument (null pointer, unsupported size)            */
+#define LSPS_E_WS    (-2)   /* workspace too small                                      */
+#define LSPS_E_HIP   (-3)   /* a HIP runtime call failed                                */
+
+/* epilogue activations fused into the conv kernels */
+#define LSPS_ACT_NONE  0
+#define LSPS_ACT_LRELU 1    /* nn.LeakyReLU(slope), common_net.py:252,264               */
+#define LSPS_ACT_TANH  2    /* nn.Tanh, lsps_nets.py:228-229                            */
+
+int         lsps_version(void);
+const char *lsps_last_error(void);
+/* number of compute units of the current device (used by callers to size split counts) */
+int         lsps_device_cus(void);
+
+/* ---- Conv2d: replaces nn.Conv2d forward + autograd's convolution_backward -----------------
+ * call sites: common_net.py:250 (LeakyReLUConv2d), :162-163 (LeakyINSResBlock.conv3x3),
+ *             lsps_nets.py:123-124 (Post / D heads).
+ * x[N,C,H,W] * w[K,C,R,S] -> y[N,K,P,Q], P = (H+2*pad-R)/stride+1.                           */
+size_t lsps_conv2d_workspace_bytes(int N, int C, int H, int W, int K, int R, int S, int stride, int pad);
+int lsps_conv2d_fwd(const float *x, const float *w, const float *bias /*nullable*/, float *y,
+                    int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
+                    int act, float slope, void *ws, size_t ws_bytes, void *stream);
+int lsps_conv2d_dgrad(const float *dy, const float *w, float *dx,
+                      int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
+                      void *ws, size_t ws_bytes, void *stream);
+/* dw[K,C,R,S] and (optional) db[K] are OVERWRITTEN */
+int lsps_conv2d_wgrad(const float *x, const float *dy, float *dw, float *db /*nullable*/,
+                      int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
+                      void *ws, size_t ws_bytes, void *stream);
+
+/* ---- ConvTranspose2d: replaces nn.ConvTranspose2d forward/backward -------------------------
+ * call sites: common_net.py:262 (LeakyReLUConvTranspose2d), lsps_nets.py:226-227 (1x1 output),
+ *             lsps_nets.py:17-23 (Mapping).
+ * x[N,Ci,H,W] * w[Ci,Co,R,S] -> y[N,Co,Ho,Wo], Ho = (H-1)*stride-2*pad+R+outpad.             */
+size_t lsps_convT2d_workspace_bytes(int N, int Ci, int H, int W, int Co, int R, int S, int stride, int pad, int outpad);
+int lsps_convT2d_fwd(const float *x, const float *w, const float *bias, float *y,
+                     int N, int Ci, int H, int W, int Co, int R, int S, int stride, int pad, int outpad,
+                     int act, float slope, void *ws, size_t ws_bytes, void *stream);
+int lsps_convT2d_dgrad(const float *dy, const float *w, float *dx,
+                       int N, int Ci, int H, int W, int Co, int R, int S, int stride, int pad, int outpad,
+                       void *ws, size_t ws_bytes, void *stream);
+int lsps_convT2d_wgrad(const float *x, const float *dy, float *dw, float *db,
+                       int N, int Ci, int H, int W, int Co, int R, int S, int stride, int pad, int outpad,
+                       void *ws, size_t ws_bytes, void *stream);
+
+/* ---- InstanceNorm2d(affine=False) [+ LeakyReLU] [+ residual add], fused --------------------
+ * call sites: common_net.py:168-171 (norm + in-place LeakyReLU), :177-181 (norm, out += residual).
+ * planes = N*C, hw = H*W.  out = act(IN(y)) (+ residual).  slope < 0 => no activation.
+ * `out` may alias `y`.  rstd[planes] is saved for the backward.
+ * The backward works from the OUTPUT (x_hat is recovered from out / out-residual).            */
+int lsps_inorm_fwd(const float *y, const float *residual /*nullable*/, float *out, float *rstd,
+                   int planes, int hw, float eps, float slope, void *stream);
+int lsps_inorm_bwd(const float *dout, const float *out, const float *residual /*nullable*/,
+                   const float *rstd, float *dy, int planes, int hw, float slope, void *stream);
+
+/* ---- activation backward from the saved OUTPUT (in-place LeakyReLU / Tanh) ------------------
+ * dx = dy * act'(.) ; kind = LSPS_ACT_LRELU (uses sign of out) or LSPS_ACT_TANH (1-out^2).
+ * dx may alias dy.  (autograd of common_net.py:252,264; lsps_nets.py:228)                     */
+int lsps_act_bwd(const float *dy, const float *out, float *dx, long n, int kind, float slope, void *stream);
+
+/* ---- losses (lsps_trainer.py:42-60, :107-112, :172-192; helpers.py:20-32) -------------------
+ * Forward kernels write ONE float (already divided by `denom`) to out[0].
+ *   L1  : sum|a-b| / denom          (nn.L1Loss; b == NULL means zeros: the feature-matching form)
+ *   L2  : sum (a-b)^2 / denom       (_compute_l2_loss)
+ *   SQ  : sum a^2 / denom           (_compute_kl(mu))
+ *   KLSD: sum (mu^2+sd^2-log sd^2)/denom   (a = mu, b = sd; _compute_kl(mu, sd))
+ * Backward kernels write da (and db = -da when db != NULL), scaled by gout[0] (device scalar). */
+#define LSPS_LOSS_L1   0
+#define LSPS_LOSS_L2   1
+#define LSPS_LOSS_SQ   2
+#define LSPS_LOSS_KLSD 3
+size_t lsps_loss_workspace_bytes(long n);
+int lsps_loss_fwd(int kind, const float *a, const float *b, long n, float denom, float *out,
+                  void *ws, size_t ws_bytes, void *stream);
+int lsps_loss_bwd(int kind, const float *a, const float *b, long n, float denom, const float *gout,
+                  float *da, float *db, void *stream);
+/* sigmoid + binary_cross_entropy against a constant target (1.0 or 0.0), mean over n logits,
+ * with torch's clamp of log() at -100.  out[0] = loss, out[1] = #(p >= 0.5), out[2] = #(p <= 0.5).
+ * (lsps_trainer.py:107-112,179-192 ; counters feed helpers.py:20-32)                           */
+int lsps_bce_sigmoid_fwd(const float *logits, long n, float target, float *out3,
+                         void *ws, size_t ws_bytes, void *stream);
+int lsps_bce_sigmoid_bwd(const float *logits, long n, float target, const float *gout, float *dlogits, void *stream);
+
+/* ---- pose-MLP head: nn.Linear (+ LeakyReLU / Softplus), lsps_nets.py:44-50,73-83 ------------
+ * y[n,out] = act(x[n,in] @ W[out,in]^T + b[out]); act: 0 none, 1 LeakyReLU(slope), 3 Softplus.  */
+#define LSPS_ACT_SOFTPLUS 3
+int lsps_linear_fwd(const float *x, const float *w, const float *b, float *y, int n, int in, int out,
+                    int act, float slope, void *stream);
+/* dz = dy * act'(y) is formed internally from the saved output y; dx (nullable), dw, db overwritten */
+int lsps_linear_bwd(const float *x, const float *w, const float *y, const float *dy,
+                    float *dx, float *dw, float *db, int n, int in, int out, int act, float slope,
+                    float *ws_dz /* n*out floats */, void *stream);
+
+/* ---- Adam with coupled L2 weight decay over a flat parameter arena --------------------------
+ * replaces torch.optim.Adam.step (lsps_trainer.py:26-29,72,131,213,258).
+ * seg_* describe `nseg` parameter tensors laid out back-to-back in p/g/m/v (device arrays):
+ *   seg_off[i] (element offset, 64-bit), seg_len[i], seg_bc1[i] = 1-b1^step_i,
+ *   seg_bc2s[i] = sqrt(1-b2^step_i); seg_len[i] == 0 marks a tensor without a gradient this
+ *   step (skipped entirely, as torch does for grad=None).  gscale multiplies g first (1/world). */
+int lsps_adam_step(float *p, const float *g, float *m, float *v,
+                   const long *seg_off, const int *seg_len, const float *seg_bc1, const float *seg_bc2s,
+                   int nseg, float lr, float beta1, float beta2, float eps, float weight_decay, float gscale,
+                   void *stream);
+
+/* elementwise helpers used by the trainer glue (GaussianNoiseLayer common_net.py:39-40 etc.) */
+int lsps_axpy(const float *x, const float *y, float alpha, float *out, long n, void *stream);  /* out = x + alpha*y */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSPS_HIP_H */

@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, 'tests', 'golden')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: full-width (ch=64) CPU oracle cases")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    def load(config):
+        return dict(np.load(os.path.join(REPO, 'tests', 'golden', 'golden_%s.npz' % config)))
+    return load

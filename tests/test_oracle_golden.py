@@ -1,0 +1,48 @@
+"""The CPU oracle (oracle/lsps_ref.py) against golden vectors captured from the REAL reference
+(tests/golden/make_golden.py).  This is what pins the oracle: every public method of the nets
+and every update step, tiny (ch=8/4) and full (ch=64) width.  Tolerance: 1e-4 relative to the
+tensor's abs-max (same torch CPU kernels, different op composition => ~1e-6 expected)."""
+import pytest
+import torch
+
+import cases
+from oracle import lsps_ref
+
+RTOL = 1e-4
+
+
+@pytest.mark.parametrize("config", ["tiny", "full"])
+def test_oracle_modules_match_reference(config, golden):
+    torch.set_num_threads(8)
+    A = cases.NativeAdapter(lsps_ref, 'cpu')
+    R = cases.run_module_cases(A, config, lsps_ref)
+    g = {k: v for k, v in golden(config).items() if k.split('/')[0] in R}
+    assert g, "no golden entries"
+    bad, worst = cases.compare(R, g, RTOL)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:5])
+
+
+@pytest.mark.parametrize("config", ["tiny", "full"])
+def test_oracle_steps_match_reference(config, golden):
+    torch.set_num_threads(8)
+    A = cases.NativeAdapter(lsps_ref, 'cpu')
+    R = cases.run_step_cases(A, config, lsps_ref)
+    g = {k: v for k, v in golden(config).items() if k.split('/')[0] in R}
+    assert g, "no golden entries"
+    # Adam divides by sqrt(v)+eps: where a gradient is ~0 the update direction is noise-dominated,
+    # so post-step weights are compared at 1e-3 of the tensor's abs-max (weights ~0.02, lr 1e-4).
+    bad, worst = cases.compare(R, g, 1e-3, grad_rtol=2e-2)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:5])
+
+
+def test_shape_tables_match_reference_keys(golden):
+    """State-dict key sets / shapes equal the reference's (80/20/10/8 tensors)."""
+    hp = cases.hp_for('full')
+    assert len(lsps_ref.gen_shapes(hp['gen'])) == 80
+    assert len(lsps_ref.dis_shapes(hp['dis'])) == 20
+    assert len(lsps_ref.vae_shapes(hp['vae'])) == 10
+    assert len(lsps_ref.map_shapes(hp['map'])) == 8
+    g = golden('full')
+    for net, shapes in (('gen', lsps_ref.gen_shapes(hp['gen'])), ('dis', lsps_ref.dis_shapes(hp['dis']))):
+        for k, s in shapes.items():
+            assert tuple(g['pretrain.it0.%s.params/%s/shape' % (net, k)]) == tuple(s)
