@@ -123,11 +123,12 @@ int lsps_linear_bwd(const float *x, const float *w, const float *y, const float 
  * seg_* describe `nseg` parameter tensors laid out back-to-back in p/g/m/v (device arrays):
  *   seg_off[i] (element offset, 64-bit), seg_len[i], seg_bc1[i] = 1-b1^step_i,
  *   seg_bc2s[i] = sqrt(1-b2^step_i); seg_len[i] == 0 marks a tensor without a gradient this
- *   step (skipped entirely, as torch does for grad=None).  gscale multiplies g first (1/world). */
+ *   step (skipped entirely, as torch does for grad=None).  max_seg_len = max_i seg_len[i] (host
+ *   copy, sizes the grid).  gscale multiplies g first (1/world_size under data parallelism). */
 int lsps_adam_step(float *p, const float *g, float *m, float *v,
                    const long *seg_off, const int *seg_len, const float *seg_bc1, const float *seg_bc2s,
-                   int nseg, float lr, float beta1, float beta2, float eps, float weight_decay, float gscale,
-                   void *stream);
+                   int nseg, int max_seg_len, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float gscale, void *stream);
 
 /* elementwise helpers used by the trainer glue (GaussianNoiseLayer common_net.py:39-40 etc.) */
 int lsps_axpy(const float *x, const float *y, float alpha, float *out, long n, void *stream);  /* out = x + alpha*y */

@@ -1,0 +1,110 @@
+"""ctypes binding of liblsps_hip.so (the C-ABI declared in include/lsps_hip.h).
+
+There is NO fallback: if the shared library is missing or a tensor is not a contiguous float32
+HIP tensor, the call raises.  The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C lsps_amd/csrc``.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblsps_hip.so')
+
+ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2, 3
+LOSS_L1, LOSS_L2, LOSS_SQ, LOSS_KLSD = 0, 1, 2, 3
+
+_P = c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    'lsps_version': (c_int, []),
+    'lsps_last_error': (c_char_p, []),
+    'lsps_device_cus': (c_int, []),
+    'lsps_conv2d_workspace_bytes': (c_size_t, [c_int] * 9),
+    'lsps_conv2d_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [c_int, c_float, _P, c_size_t, _P]),
+    'lsps_conv2d_dgrad': (c_int, [_P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
+    'lsps_conv2d_wgrad': (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
+    'lsps_convT2d_workspace_bytes': (c_size_t, [c_int] * 10),
+    'lsps_convT2d_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 10 + [c_int, c_float, _P, c_size_t, _P]),
+    'lsps_convT2d_dgrad': (c_int, [_P, _P, _P] + [c_int] * 10 + [_P, c_size_t, _P]),
+    'lsps_convT2d_wgrad': (c_int, [_P, _P, _P, _P] + [c_int] * 10 + [_P, c_size_t, _P]),
+    'lsps_inorm_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    'lsps_inorm_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    'lsps_act_bwd': (c_int, [_P, _P, _P, c_long, c_int, c_float, _P]),
+    'lsps_loss_workspace_bytes': (c_size_t, [c_long]),
+    'lsps_loss_fwd': (c_int, [c_int, _P, _P, c_long, c_float, _P, _P, c_size_t, _P]),
+    'lsps_loss_bwd': (c_int, [c_int, _P, _P, c_long, c_float, _P, _P, _P, _P]),
+    'lsps_bce_sigmoid_fwd': (c_int, [_P, c_long, c_float, _P, _P, c_size_t, _P]),
+    'lsps_bce_sigmoid_bwd': (c_int, [_P, c_long, c_float, _P, _P, _P]),
+    'lsps_linear_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    'lsps_linear_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P]),
+    'lsps_adam_step': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int] + [c_float] * 6 + [_P]),
+    'lsps_axpy': (c_int, [_P, _P, c_float, _P, c_long, _P]),
+}
+EXPORTS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+
+
+class LspsHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads (once) and returns the ctypes handle; raises if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LspsHipError("liblsps_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`"
+                               % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(h, name)           # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().lsps_last_error()
+        raise LspsHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ''))
+
+
+# ------------------------------------------------------------------------------------------
+# tensor plumbing (torch is used for device memory + streams only)
+# ------------------------------------------------------------------------------------------
+def ptr(t):
+    """Device pointer of a contiguous float32 HIP tensor (or None -> NULL)."""
+    if t is None:
+        return None
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise LspsHipError("lsps_amd ops need HIP device tensors (got %s); there is no CPU fallback"
+                           % (t.device if hasattr(t, 'device') else type(t)))
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise LspsHipError("lsps_amd ops need contiguous float32 tensors (dtype=%s contiguous=%s)"
+                           % (t.dtype, t.is_contiguous()))
+    return t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device):
+    """One scratch buffer per device, grown on demand; ops on one stream run in order, so it is shared."""
+    import torch
+    key = (device.type, device.index)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            torch.cuda.current_stream().synchronize()   # outstanding users of the old buffer
+        nbytes = max(int(nbytes * 1.25), 1 << 20)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf.data_ptr(), buf.numel()

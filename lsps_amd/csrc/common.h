@@ -1,0 +1,50 @@
+// Shared helpers for the liblsps_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/lsps_hip.h"
+
+namespace lsps {
+
+void set_error(const char *fmt, ...);
+
+#define LSPS_CHECK_ARG(cond, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      lsps::set_error(__VA_ARGS__);          \
+      return LSPS_E_ARG;                     \
+    }                                        \
+  } while (0)
+
+#define LSPS_CHECK_LAUNCH(name)                                            \
+  do {                                                                     \
+    hipError_t e_ = hipGetLastError();                                     \
+    if (e_ != hipSuccess) {                                                \
+      lsps::set_error("%s: %s", name, hipGetErrorString(e_));              \
+      return LSPS_E_HIP;                                                   \
+    }                                                                      \
+  } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// 64-lane wavefront sum (all lanes receive the total)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves). `red` is >= 4 floats of LDS.
+// Every thread receives the total.  Safe to call repeatedly with the same `red`.
+__device__ __forceinline__ float block_sum_256(float v, float *red) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+}  // namespace lsps

@@ -1,0 +1,741 @@
+// Implicit-GEMM Conv2d / ConvTranspose2d for gfx950 on the f32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact f32, 157 TFLOP/s dense peak).
+//
+// One gather-GEMM covers every conv-shaped op of the depth path (NCHW, no im2col buffer):
+//
+//   F kernel  D[m][pix] = sum_{(c,t)} Wp[(c,t)][m] * X[n][c][ph*ist+dh[t]][pw*ist+dw[t]]
+//       - Conv2d forward / ConvTranspose2d dgrad:  "forward direction" (big -> small image),
+//         all R*S taps, ist = stride, dh = r - pad.
+//       - Conv2d dgrad / ConvTranspose2d forward:  "transposed direction" (small -> big image),
+//         decomposed by output parity class (a,b) in [0,stride)^2: a class only sees the taps with
+//         (a + pad - r) % stride == 0, so no multiply-by-zero work is issued (9 taps total for a
+//         3x3 stride-2 layer instead of 36); ist = 1, dh = (a + pad - r)/stride.
+//   W kernel  D[m][(c,t)] = sum_{pix} Small[n][m][pix] * Big[n][c][ph*ist+dh[t]][pw*ist+dw[t]]
+//       - Conv2d / ConvTranspose2d weight gradient, split over the pixel reduction, partial
+//         tiles reduced deterministically by a second kernel.
+//
+// MFMA roles: A = weights / small-side rows (i = output row m), B = pixels or (c,t) columns.
+// The C/D layout then puts 32 consecutive pixels of one output channel in lanes 0..31 of one
+// accumulator register => 128-byte coalesced NCHW stores without any LDS transpose.
+// Tiles are staged through LDS (register prefetch of the next chunk overlaps the MFMA chain).
+//
+// Reference call sites replaced: every nn.Conv2d / nn.ConvTranspose2d on the path
+// (src/trainers/common_net.py:162-163,250,262; src/trainers/lsps_nets.py:17-23,123-124,226-227)
+// and their autograd backward (total_loss.backward(), src/trainers/lsps_trainer.py:71,130,212,257).
+#include "common.h"
+#include <stdarg.h>
+#include <string.h>
+
+namespace lsps {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LSPS_MAXT 49
+#define BK_F 32   // reduction chunk of the F kernel
+#define BK_W 64   // reduction (pixel) chunk of the W kernel
+#define LDW (BK_W + 1)
+
+struct Taps {
+  int T;
+  int toff[LSPS_MAXT];          // dh*Wx + dw
+  signed char dh[LSPS_MAXT], dw[LSPS_MAXT];
+};
+
+struct FParams {
+  const float *X, *Wp, *bias;
+  float *Y;
+  int Cx, Hx, Wx, HxWx;          // gather source [N][Cx][Hx][Wx]
+  int PH, PW, P, NPIX;           // output pixel lattice per sample, P = PH*PW, NPIX = N*P
+  int ist;                       // input step per lattice step
+  int RED, REDp, Mp;             // RED = Cx*T ; packed weights are [REDp][Mp], zero padded
+  unsigned magicT;               // floor(2^32/T)+1 (T>1)
+  int M, HyWy, Wy, h0, hs, w0, ws;   // D[m][pix] -> Y[n][m][h0+hs*ph][w0+ws*pw]
+  int act;
+  float slope;
+  Taps taps;
+};
+
+struct WParams {
+  const float *Small, *Big;
+  float *part;                   // [splits][M][J]
+  int Cx, Hx, Wx, HxWx;          // Big = [N][Cx][Hx][Wx]
+  int PH, PW, P, NPIX;           // Small = [N][M][PH][PW]
+  int ist;
+  int M, J;                      // J = Cx*T
+  unsigned magicT;
+  int nchunks, chunks_per_split;
+  Taps taps;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  if (act == LSPS_ACT_LRELU) return v > 0.f ? v : v * slope;
+  if (act == LSPS_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+// -------------------------------------------------------------------------------------------
+// weight packing: Wp[red=(c,t)][m] = W[m*sm + c*sc + tapidx[t]], zero padded to [REDp][Mp]
+// -------------------------------------------------------------------------------------------
+struct PackParams {
+  const float *W;
+  float *Wp;
+  int M, Mp, RED, REDp, T;
+  unsigned magicT;
+  long sm, sc;
+  int tapidx[LSPS_MAXT];
+};
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackParams p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)p.REDp * p.Mp;
+  if (idx >= total) return;
+  const int red = (int)(idx / p.Mp), m = (int)(idx - (long)red * p.Mp);
+  float v = 0.f;
+  if (red < p.RED && m < p.M) {
+    const int c = (p.T == 1) ? red : (int)__umulhi((unsigned)red, p.magicT);
+    const int t = red - c * p.T;
+    v = p.W[(long)m * p.sm + (long)c * p.sc + p.tapidx[t]];
+  }
+  p.Wp[idx] = v;
+}
+
+// -------------------------------------------------------------------------------------------
+// F kernel
+// -------------------------------------------------------------------------------------------
+template <int WM, int WN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void igemm_f_kernel(FParams p) {
+  constexpr int BM = WM * 32 * WAVES_M, BN = WN * 32 * WAVES_N, BK = BK_F;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(BN == 128 || BN == 256, "pixel tile");
+  constexpr int PIXW = BN / 64;        // waves side by side along the pixel tile
+  constexpr int RSTEP = 4 / PIXW;      // reduction rows covered per pass of the 4 waves
+  constexpr int NB = BK / RSTEP;       // B gathers per thread per chunk
+  constexpr int A4 = BK * BM / 4 / 256;
+  static_assert(A4 >= 1, "A tile");
+
+  __shared__ __attribute__((aligned(16))) float lds[BK * BM + BK * BN];
+  float *As = lds, *Bs = lds + BK * BM;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.y * BM;
+
+  // ---- this thread's gather pixel (one column of the B tile)
+  const int pcol = (wave % PIXW) * 64 + lane;
+  const int rbase = wave / PIXW;
+  const long Jg = (long)blockIdx.x * BN + pcol;
+  const bool pv = Jg < p.NPIX;
+  int gn = 0, gph = 0, gpw = 0;
+  if (pv) {
+    gn = (int)(Jg / p.P);
+    const int rem = (int)(Jg - (long)gn * p.P);
+    gph = rem / p.PW;
+    gpw = rem - gph * p.PW;
+  }
+  const int ih0 = gph * p.ist, iw0 = gpw * p.ist;
+  const float *xb = p.X + ((long)gn * p.Cx * p.Hx + ih0) * p.Wx + iw0;
+  unsigned long long mask = 0ull;
+  for (int t = 0; t < p.taps.T; ++t) {
+    const int ih = ih0 + p.taps.dh[t], iw = iw0 + p.taps.dw[t];
+    if (pv && ih >= 0 && ih < p.Hx && iw >= 0 && iw < p.Wx) mask |= (1ull << t);
+  }
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float breg[NB];
+  float4 areg[A4];
+  const int T = p.taps.T;
+
+  auto prefetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A4; ++i) {
+      const int u = tid + 256 * i;
+      const int row = u / (BM / 4), c4 = u % (BM / 4);
+      areg[i] = *reinterpret_cast<const float4 *>(p.Wp + (long)(k0 + row) * p.Mp + m0 + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int red = __builtin_amdgcn_readfirstlane(k0 + rbase + RSTEP * i);
+      const int c = (T == 1) ? red : (int)__umulhi((unsigned)red, p.magicT);
+      const int t = red - c * T;
+      const bool ok = (c < p.Cx) && ((mask >> t) & 1ull);
+      const int off = c * p.HxWx + p.taps.toff[t];
+      breg[i] = ok ? xb[off] : 0.f;
+    }
+  };
+
+  const int nchunks = p.REDp / BK;
+  if (nchunks > 0) prefetch(0);
+
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < A4; ++i) {
+      const int u = tid + 256 * i;
+      const int row = u / (BM / 4), c4 = u % (BM / 4);
+      *reinterpret_cast<float4 *>(As + row * BM + c4 * 4) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) Bs[(rbase + RSTEP * i) * BN + pcol] = breg[i];
+    __syncthreads();
+    if (ch + 1 < nchunks) prefetch((ch + 1) * BK);
+
+#pragma unroll 4
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[WM], b[WN];
+      const int row = 2 * kk + half;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = As[row * BM + (wm * WM + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = Bs[row * BN + (wn * WN + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds pixel column l31 of each 32x32 tile, rows (r&3)+8*(r>>2)+4*half
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const long Jo = (long)blockIdx.x * BN + (wn * WN + j) * 32 + l31;
+    if (Jo >= p.NPIX) continue;
+    const int n = (int)(Jo / p.P);
+    const int rem = (int)(Jo - (long)n * p.P);
+    const int ph = rem / p.PW, pw = rem - ph * p.PW;
+    float *yb = p.Y + (long)n * p.M * p.HyWy + (long)(p.h0 + p.hs * ph) * p.Wy + (p.w0 + p.ws * pw);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < p.M) {
+          float v = acc[i][j][r];
+          if (p.bias) v += p.bias[m];
+          yb[(long)m * p.HyWy] = apply_act(v, p.act, p.slope);
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// W kernel (weight gradient): tile 128 (m) x 128 (c,t) x 64 pixels, split over pixel chunks
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
+  constexpr int BM = 128, BN = 128, BK = BK_W;
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDW];
+  float *As = lds, *Bs = lds + BM * LDW;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+  const int split = blockIdx.z;
+  const int ch_begin = split * p.chunks_per_split;
+  int ch_end = ch_begin + p.chunks_per_split;
+  if (ch_end > p.nchunks) ch_end = p.nchunks;
+  const int T = p.taps.T;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float areg[32], breg[32];
+
+  auto prefetch = [&](int ch) {
+    const long q = (long)ch * BK + lane;          // this lane's pixel of the chunk
+    const bool pv = q < p.NPIX;
+    int n = 0, ph = 0, pw = 0, pp = 0;
+    if (pv) {
+      n = (int)(q / p.P);
+      pp = (int)(q - (long)n * p.P);
+      ph = pp / p.PW;
+      pw = pp - ph * p.PW;
+    }
+    const int ih0 = ph * p.ist, iw0 = pw * p.ist;
+    unsigned long long mask = 0ull;
+    for (int t = 0; t < T; ++t) {
+      const int ih = ih0 + p.taps.dh[t], iw = iw0 + p.taps.dw[t];
+      if (pv && ih >= 0 && ih < p.Hx && iw >= 0 && iw < p.Wx) mask |= (1ull << t);
+    }
+    const float *sb = p.Small + (long)n * p.M * p.P + pp;
+    const float *xb = p.Big + ((long)n * p.Cx * p.Hx + ih0) * p.Wx + iw0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int m = m0 + wave + 4 * i;            // wave-uniform row
+      areg[i] = (pv && m < p.M) ? sb[(long)m * p.P] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int j = __builtin_amdgcn_readfirstlane(j0 + wave + 4 * i);
+      const int c = (T == 1) ? j : (int)__umulhi((unsigned)j, p.magicT);
+      const int t = j - c * T;
+      const bool ok = (j < p.J) && ((mask >> t) & 1ull);
+      const int off = c * p.HxWx + p.taps.toff[t];
+      breg[i] = ok ? xb[off] : 0.f;
+    }
+  };
+
+  if (ch_begin < ch_end) prefetch(ch_begin);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      As[(wave + 4 * i) * LDW + lane] = areg[i];
+      Bs[(wave + 4 * i) * LDW + lane] = breg[i];
+    }
+    __syncthreads();
+    if (ch + 1 < ch_end) prefetch(ch + 1);
+#pragma unroll 4
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[2], b[2];
+      const int col = 2 * kk + half;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[((wm * 2 + i) * 32 + l31) * LDW + col];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[((wn * 2 + j) * 32 + l31) * LDW + col];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  float *out = p.part + (long)split * p.M * p.J;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int jj = j0 + (wn * 2 + j) * 32 + l31;
+    if (jj >= p.J) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < p.M) out[(long)m * p.J + jj] = acc[i][j][r];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *part, float *out, long n, int splits) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += part[(long)k * n + i];
+  out[i] = s;
+}
+
+// db[c] = sum_{n,p} t[n][c][p] ; one workgroup per channel
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float *t, float *db, int N, int C, int HW) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float *base = t + ((long)n * C + c) * HW;
+    for (int i = threadIdx.x; i < HW; i += 256) s += base[i];
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) db[c] = s;
+}
+
+// -------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------
+static unsigned magic_for(int T) { return T <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)T + 1ull); }
+
+static int choose_cfg(int M) { return M >= 128 ? 0 : (M >= 64 ? 1 : 2); }
+static int cfg_bm(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
+static int cfg_bn(int cfg) { return cfg == 0 ? 128 : 256; }
+
+struct TapList {
+  int T;
+  int dh[LSPS_MAXT], dw[LSPS_MAXT], idx[LSPS_MAXT];
+};
+
+static void fill_taps(Taps &t, const TapList &l, int Wx) {
+  t.T = l.T;
+  for (int i = 0; i < LSPS_MAXT; ++i) {
+    t.toff[i] = 0;
+    t.dh[i] = 0;
+    t.dw[i] = 0;
+  }
+  for (int i = 0; i < l.T; ++i) {
+    t.dh[i] = (signed char)l.dh[i];
+    t.dw[i] = (signed char)l.dw[i];
+    t.toff[i] = l.dh[i] * Wx + l.dw[i];
+  }
+}
+
+static int launch_pack(const float *W, float *Wp, int M, int Mp, int RED, int REDp, const TapList &l, long sm, long sc,
+                       hipStream_t st) {
+  if (REDp == 0) return 0;
+  PackParams pp;
+  pp.W = W;
+  pp.Wp = Wp;
+  pp.M = M;
+  pp.Mp = Mp;
+  pp.RED = RED;
+  pp.REDp = REDp;
+  pp.T = l.T;
+  pp.magicT = magic_for(l.T);
+  pp.sm = sm;
+  pp.sc = sc;
+  for (int i = 0; i < LSPS_MAXT; ++i) pp.tapidx[i] = i < l.T ? l.idx[i] : 0;
+  const long total = (long)REDp * Mp;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, pp);
+  LSPS_CHECK_LAUNCH("pack_weights");
+  return 0;
+}
+
+static int launch_f(const FParams &p, int cfg, hipStream_t st) {
+  const int BM = cfg_bm(cfg), BN = cfg_bn(cfg);
+  dim3 grid(ceil_div(p.NPIX, BN), ceil_div(p.M, BM));
+  if (grid.x == 0 || grid.y == 0) return 0;
+  if (cfg == 0)
+    hipLaunchKernelGGL((igemm_f_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+  else if (cfg == 1)
+    hipLaunchKernelGGL((igemm_f_kernel<2, 2, 1, 4>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((igemm_f_kernel<1, 2, 1, 4>), grid, dim3(256), 0, st, p);
+  LSPS_CHECK_LAUNCH("igemm_f");
+  return 0;
+}
+
+static size_t packed_floats(int Cin, int taps_total, int classes, int M) {
+  const size_t Mp = align_up((size_t)M, 128);
+  return ((size_t)Cin * taps_total + (size_t)32 * classes) * Mp;
+}
+
+// "forward direction": in = big image [N][Cb][Hb][Wb], out = small image [N][Cs][Hs][Ws]
+//   out[n][m][p][q] = sum_{c,r,s} W(m,c,r,s) * in[n][c][p*st-pad+r][q*st-pad+s]
+//   weight element address: W[m*sm + c*sc + r*S + s]
+static int run_forward_dir(const float *in, const float *W, const float *bias, float *out, int N, int Cb, int Hb, int Wb,
+                           int Cs, int Hs, int Ws, int R, int S, int st_, int pad, long sm, long sc, int act,
+                           float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+  TapList l;
+  l.T = R * S;
+  for (int r = 0; r < R; ++r)
+    for (int s = 0; s < S; ++s) {
+      l.dh[r * S + s] = r - pad;
+      l.dw[r * S + s] = s - pad;
+      l.idx[r * S + s] = r * S + s;
+    }
+  const int M = Cs, RED = Cb * l.T;
+  const int Mp = (int)align_up(M, 128), REDp = (int)align_up(RED, BK_F);
+  const size_t need = (size_t)REDp * Mp * sizeof(float);
+  if (need > ws_bytes) {
+    set_error("conv workspace too small: need %zu, have %zu", need, ws_bytes);
+    return LSPS_E_WS;
+  }
+  float *Wp = (float *)ws;
+  int rc = launch_pack(W, Wp, M, Mp, RED, REDp, l, sm, sc, st);
+  if (rc) return rc;
+  FParams p;
+  memset(&p, 0, sizeof(p));
+  p.X = in;
+  p.Wp = Wp;
+  p.bias = bias;
+  p.Y = out;
+  p.Cx = Cb;
+  p.Hx = Hb;
+  p.Wx = Wb;
+  p.HxWx = Hb * Wb;
+  p.PH = Hs;
+  p.PW = Ws;
+  p.P = Hs * Ws;
+  p.NPIX = N * Hs * Ws;
+  p.ist = st_;
+  p.RED = RED;
+  p.REDp = REDp;
+  p.Mp = Mp;
+  p.magicT = magic_for(l.T);
+  p.M = M;
+  p.HyWy = Hs * Ws;
+  p.Wy = Ws;
+  p.h0 = 0;
+  p.hs = 1;
+  p.w0 = 0;
+  p.ws = 1;
+  p.act = act;
+  p.slope = slope;
+  fill_taps(p.taps, l, Wb);
+  return launch_f(p, choose_cfg(M), st);
+}
+
+// "transposed direction": in = small image [N][Cs][Hs][Ws], out = big image [N][Cb][Hb][Wb]
+//   out[n][m][h][w] = sum_{c,r,s} W(m,c,r,s) * in[n][c][(h+pad-r)/st][(w+pad-s)/st]   (divisible, in range)
+static int run_transposed_dir(const float *in, const float *W, const float *bias, float *out, int N, int Cb, int Hb,
+                              int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad, long sm, long sc, int act,
+                              float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+  const int M = Cb;
+  const int Mp = (int)align_up(M, 128);
+  size_t used = 0;
+  for (int a = 0; a < st_; ++a)
+    for (int b = 0; b < st_; ++b) {
+      const int PH = (Hb - a + st_ - 1) / st_, PW = (Wb - b + st_ - 1) / st_;
+      if (PH <= 0 || PW <= 0) continue;
+      TapList l;
+      l.T = 0;
+      for (int r = 0; r < R; ++r) {
+        const int vr = a + pad - r;
+        if (((vr % st_) + st_) % st_ != 0) continue;
+        for (int s = 0; s < S; ++s) {
+          const int vs = b + pad - s;
+          if (((vs % st_) + st_) % st_ != 0) continue;
+          l.dh[l.T] = vr / st_;
+          l.dw[l.T] = vs / st_;
+          l.idx[l.T] = r * S + s;
+          ++l.T;
+        }
+      }
+      const int RED = Cs * l.T;
+      const int REDp = (int)align_up(RED, BK_F);
+      const size_t need = (size_t)REDp * Mp * sizeof(float);
+      if (used + need > ws_bytes) {
+        set_error("conv workspace too small: need >= %zu, have %zu", used + need, ws_bytes);
+        return LSPS_E_WS;
+      }
+      float *Wp = (float *)((char *)ws + used);
+      used += need;
+      int rc = launch_pack(W, Wp, M, Mp, RED, REDp, l, sm, sc, st);
+      if (rc) return rc;
+      FParams p;
+      memset(&p, 0, sizeof(p));
+      p.X = in;
+      p.Wp = Wp;
+      p.bias = bias;
+      p.Y = out;
+      p.Cx = Cs;
+      p.Hx = Hs;
+      p.Wx = Ws;
+      p.HxWx = Hs * Ws;
+      p.PH = PH;
+      p.PW = PW;
+      p.P = PH * PW;
+      p.NPIX = N * PH * PW;
+      p.ist = 1;
+      p.RED = RED;
+      p.REDp = REDp;
+      p.Mp = Mp;
+      p.magicT = magic_for(l.T);
+      p.M = M;
+      p.HyWy = Hb * Wb;
+      p.Wy = Wb;
+      p.h0 = a;
+      p.hs = st_;
+      p.w0 = b;
+      p.ws = st_;
+      p.act = act;
+      p.slope = slope;
+      fill_taps(p.taps, l, Ws);
+      rc = launch_f(p, choose_cfg(M), st);
+      if (rc) return rc;
+    }
+  return 0;
+}
+
+static int wgrad_splits(int M, int J, int nchunks) {
+  const long tiles = (long)ceil_div(M, 128) * ceil_div(J, 128);
+  long s = (1024 + tiles - 1) / tiles;
+  if (s > 64) s = 64;
+  if (s > nchunks) s = nchunks;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+// dW[m][(c,t)] = sum_{n,p,q} small[n][m][p][q] * big[n][c][p*st-pad+r][q*st-pad+s]
+static int run_wgrad(const float *small, const float *big, float *dW, int N, int Cb, int Hb, int Wb, int Cs, int Hs,
+                     int Ws, int R, int S, int st_, int pad, void *ws, size_t ws_bytes, hipStream_t st) {
+  WParams p;
+  memset(&p, 0, sizeof(p));
+  TapList l;
+  l.T = R * S;
+  for (int r = 0; r < R; ++r)
+    for (int s = 0; s < S; ++s) {
+      l.dh[r * S + s] = r - pad;
+      l.dw[r * S + s] = s - pad;
+      l.idx[r * S + s] = r * S + s;
+    }
+  p.Small = small;
+  p.Big = big;
+  p.Cx = Cb;
+  p.Hx = Hb;
+  p.Wx = Wb;
+  p.HxWx = Hb * Wb;
+  p.PH = Hs;
+  p.PW = Ws;
+  p.P = Hs * Ws;
+  p.NPIX = N * Hs * Ws;
+  p.ist = st_;
+  p.M = Cs;
+  p.J = Cb * l.T;
+  p.magicT = magic_for(l.T);
+  p.nchunks = ceil_div(p.NPIX, BK_W);
+  const int splits = wgrad_splits(p.M, p.J, p.nchunks);
+  p.chunks_per_split = ceil_div(p.nchunks, splits);
+  fill_taps(p.taps, l, Wb);
+  const long nW = (long)p.M * p.J;
+  if (splits > 1) {
+    const size_t need = (size_t)splits * nW * sizeof(float);
+    if (need > ws_bytes) {
+      set_error("wgrad workspace too small: need %zu, have %zu", need, ws_bytes);
+      return LSPS_E_WS;
+    }
+    p.part = (float *)ws;
+  } else {
+    p.part = dW;
+  }
+  dim3 grid(ceil_div(p.J, 128), ceil_div(p.M, 128), splits);
+  hipLaunchKernelGGL(igemm_w_kernel, grid, dim3(256), 0, st, p);
+  LSPS_CHECK_LAUNCH("igemm_w");
+  if (splits > 1) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(nW, 256)), dim3(256), 0, st, (const float *)p.part, dW, nW,
+                       splits);
+    LSPS_CHECK_LAUNCH("reduce_partials");
+  }
+  return 0;
+}
+
+static int run_bias_grad(const float *t, float *db, int N, int C, int HW, hipStream_t st) {
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, st, t, db, N, C, HW);
+  LSPS_CHECK_LAUNCH("bias_grad");
+  return 0;
+}
+
+static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_) {
+  const size_t fwd = packed_floats(Cb, R * S, 1, Cs);
+  const size_t tr = packed_floats(Cs, R * S, st_ * st_, Cb);
+  const int J = Cb * R * S;
+  const int nchunks = ceil_div((long)N * Hs * Ws, BK_W);
+  const int splits = wgrad_splits(Cs, J, nchunks);
+  const size_t wg = splits > 1 ? (size_t)splits * Cs * J : 0;
+  size_t m = fwd > tr ? fwd : tr;
+  if (wg > m) m = wg;
+  return m * sizeof(float) + 256;
+}
+
+static bool conv_args_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
+  return N > 0 && C > 0 && H > 0 && W > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0 &&
+         R * S <= LSPS_MAXT && stride <= 4;
+}
+
+}  // namespace lsps
+
+using namespace lsps;
+
+extern "C" {
+
+int lsps_version(void) { return LSPS_ABI_VERSION; }
+const char *lsps_last_error(void) { return lsps::g_err; }
+
+int lsps_device_cus(void) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+  return cus;
+}
+
+size_t lsps_conv2d_workspace_bytes(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
+  if (!conv_args_ok(N, C, H, W, K, R, S, stride, pad)) return 0;
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  return conv_ws_bytes(N, C, H, W, K, P, Q, R, S, stride);
+}
+
+int lsps_conv2d_fwd(const float *x, const float *w, const float *bias, float *y, int N, int C, int H, int W, int K,
+                    int R, int S, int stride, int pad, int act, float slope, void *ws, size_t ws_bytes, void *stream) {
+  LSPS_CHECK_ARG(x && w && y && ws, "conv2d_fwd: null pointer");
+  LSPS_CHECK_ARG(conv_args_ok(N, C, H, W, K, R, S, stride, pad), "conv2d_fwd: unsupported geometry");
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  LSPS_CHECK_ARG(P > 0 && Q > 0, "conv2d_fwd: empty output");
+  return run_forward_dir(x, w, bias, y, N, C, H, W, K, P, Q, R, S, stride, pad, (long)C * R * S, (long)R * S, act,
+                         slope, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_conv2d_dgrad(const float *dy, const float *w, float *dx, int N, int C, int H, int W, int K, int R, int S,
+                      int stride, int pad, void *ws, size_t ws_bytes, void *stream) {
+  LSPS_CHECK_ARG(dy && w && dx && ws, "conv2d_dgrad: null pointer");
+  LSPS_CHECK_ARG(conv_args_ok(N, C, H, W, K, R, S, stride, pad), "conv2d_dgrad: unsupported geometry");
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  // out channel m = c: W[k][c][r][s] -> sm = R*S ; reduction channel k -> sc = C*R*S
+  return run_transposed_dir(dy, w, nullptr, dx, N, C, H, W, K, P, Q, R, S, stride, pad, (long)R * S, (long)C * R * S,
+                            LSPS_ACT_NONE, 1.f, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_conv2d_wgrad(const float *x, const float *dy, float *dw, float *db, int N, int C, int H, int W, int K, int R,
+                      int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream) {
+  LSPS_CHECK_ARG(x && dy && dw && ws, "conv2d_wgrad: null pointer");
+  LSPS_CHECK_ARG(conv_args_ok(N, C, H, W, K, R, S, stride, pad), "conv2d_wgrad: unsupported geometry");
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  int rc = run_wgrad(dy, x, dw, N, C, H, W, K, P, Q, R, S, stride, pad, ws, ws_bytes, (hipStream_t)stream);
+  if (rc) return rc;
+  if (db) return run_bias_grad(dy, db, N, K, P * Q, (hipStream_t)stream);
+  return 0;
+}
+
+size_t lsps_convT2d_workspace_bytes(int N, int Ci, int H, int W, int Co, int R, int S, int stride, int pad,
+                                    int outpad) {
+  if (!conv_args_ok(N, Ci, H, W, Co, R, S, stride, pad)) return 0;
+  const int Ho = (H - 1) * stride - 2 * pad + R + outpad, Wo = (W - 1) * stride - 2 * pad + S + outpad;
+  return conv_ws_bytes(N, Co, Ho, Wo, Ci, H, W, R, S, stride);
+}
+
+int lsps_convT2d_fwd(const float *x, const float *w, const float *bias, float *y, int N, int Ci, int H, int W, int Co,
+                     int R, int S, int stride, int pad, int outpad, int act, float slope, void *ws, size_t ws_bytes,
+                     void *stream) {
+  LSPS_CHECK_ARG(x && w && y && ws, "convT2d_fwd: null pointer");
+  LSPS_CHECK_ARG(conv_args_ok(N, Ci, H, W, Co, R, S, stride, pad) && outpad >= 0 && (outpad == 0 || outpad < stride),
+                 "convT2d_fwd: unsupported geometry");
+  const int Ho = (H - 1) * stride - 2 * pad + R + outpad, Wo = (W - 1) * stride - 2 * pad + S + outpad;
+  LSPS_CHECK_ARG(Ho > 0 && Wo > 0, "convT2d_fwd: empty output");
+  // out channel m = co: W[ci][co][r][s] -> sm = R*S ; reduction channel ci -> sc = Co*R*S
+  return run_transposed_dir(x, w, bias, y, N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad, (long)R * S, (long)Co * R * S,
+                            act, slope, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_convT2d_dgrad(const float *dy, const float *w, float *dx, int N, int Ci, int H, int W, int Co, int R, int S,
+                       int stride, int pad, int outpad, void *ws, size_t ws_bytes, void *stream) {
+  LSPS_CHECK_ARG(dy && w && dx && ws, "convT2d_dgrad: null pointer");
+  LSPS_CHECK_ARG(conv_args_ok(N, Ci, H, W, Co, R, S, stride, pad), "convT2d_dgrad: unsupported geometry");
+  const int Ho = (H - 1) * stride - 2 * pad + R + outpad, Wo = (W - 1) * stride - 2 * pad + S + outpad;
+  // dx[n][ci][h][w] = sum_{co,r,s} W[ci][co][r][s] dy[n][co][h*st-pad+r][w*st-pad+s]
+  return run_forward_dir(dy, w, nullptr, dx, N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad, (long)Co * R * S, (long)R * S,
+                         LSPS_ACT_NONE, 1.f, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_convT2d_wgrad(const float *x, const float *dy, float *dw, float *db, int N, int Ci, int H, int W, int Co,
+                       int R, int S, int stride, int pad, int outpad, void *ws, size_t ws_bytes, void *stream) {
+  LSPS_CHECK_ARG(x && dy && dw && ws, "convT2d_wgrad: null pointer");
+  LSPS_CHECK_ARG(conv_args_ok(N, Ci, H, W, Co, R, S, stride, pad), "convT2d_wgrad: unsupported geometry");
+  const int Ho = (H - 1) * stride - 2 * pad + R + outpad, Wo = (W - 1) * stride - 2 * pad + S + outpad;
+  int rc = run_wgrad(x, dy, dw, N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad, ws, ws_bytes, (hipStream_t)stream);
+  if (rc) return rc;
+  if (db) return run_bias_grad(dy, db, N, Co, Ho * Wo, (hipStream_t)stream);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+// InstanceNorm2d(affine=False) fused with LeakyReLU / residual add, activation backward, axpy.
+// All HBM-bound: one pass over the data, float4 accesses, wavefront-shuffle reductions.
+//
+// Reference call sites: src/trainers/common_net.py:168-171 (InstanceNorm2d + in-place LeakyReLU),
+// :177-181 (InstanceNorm2d then `out += residual`), :32-40 (GaussianNoiseLayer add),
+// :252,264 and src/trainers/lsps_nets.py:228 (activation backward inside autograd).
+#include "common.h"
+
+namespace lsps {
+
+// One workgroup (256 threads) per (n,c) plane.  VPT float4 per thread held in registers when the
+// plane has exactly 256*4*VPT elements (the 32x32 latent: VPT=1); generic strided path otherwise.
+template <int VPT>
+__global__ __launch_bounds__(256) void inorm_fwd_kernel(const float *__restrict__ y, const float *__restrict__ res,
+                                                        float *__restrict__ out, float *__restrict__ rstd_out, int hw,
+                                                        float eps, float slope) {
+  __shared__ float red[4];
+  const long base = (long)blockIdx.x * hw;
+  const float inv = 1.f / (float)hw;
+  if (VPT > 0) {
+    float4 v[VPT > 0 ? VPT : 1];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      v[i] = *reinterpret_cast<const float4 *>(y + base + (threadIdx.x + 256 * i) * 4);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = block_sum_256(s, red) * inv;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float var = block_sum_256(q, red) * inv;
+    const float rstd = 1.f / sqrtf(var + eps);
+    if (threadIdx.x == 0) rstd_out[blockIdx.x] = rstd;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const long o = base + (threadIdx.x + 256 * i) * 4;
+      float4 r;
+      r.x = (v[i].x - mean) * rstd;
+      r.y = (v[i].y - mean) * rstd;
+      r.z = (v[i].z - mean) * rstd;
+      r.w = (v[i].w - mean) * rstd;
+      if (slope >= 0.f) {
+        r.x = r.x > 0.f ? r.x : r.x * slope;
+        r.y = r.y > 0.f ? r.y : r.y * slope;
+        r.z = r.z > 0.f ? r.z : r.z * slope;
+        r.w = r.w > 0.f ? r.w : r.w * slope;
+      }
+      if (res) {
+        const float4 x = *reinterpret_cast<const float4 *>(res + o);
+        r.x += x.x;
+        r.y += x.y;
+        r.z += x.z;
+        r.w += x.w;
+      }
+      *reinterpret_cast<float4 *>(out + o) = r;
+    }
+  } else {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) s += y[base + i];
+    const float mean = block_sum_256(s, red) * inv;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+      const float d = y[base + i] - mean;
+      q += d * d;
+    }
+    const float var = block_sum_256(q, red) * inv;
+    const float rstd = 1.f / sqrtf(var + eps);
+    __syncthreads();   // all reads of y done before (possibly aliased) writes
+    if (threadIdx.x == 0) rstd_out[blockIdx.x] = rstd;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+      float r = (y[base + i] - mean) * rstd;
+      if (slope >= 0.f) r = r > 0.f ? r : r * slope;
+      if (res) r += res[base + i];
+      out[base + i] = r;
+    }
+  }
+}
+
+// Backward from the OUTPUT.  act variant (slope>=0): g = dout*lrelu'(out), xhat = out>0 ? out : out/slope.
+// residual variant (res != null, slope<0): g = dout, xhat = out - res.  plain (no res, slope<0): xhat = out.
+// dy = rstd * (g - mean(g) - xhat*mean(g*xhat))
+template <int VPT>
+__global__ __launch_bounds__(256) void inorm_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ out,
+                                                        const float *__restrict__ res, const float *__restrict__ rstd_in,
+                                                        float *__restrict__ dy, int hw, float slope) {
+  __shared__ float red[4];
+  const long base = (long)blockIdx.x * hw;
+  const float inv = 1.f / (float)hw;
+  const float rstd = rstd_in[blockIdx.x];
+  const float inv_slope = slope > 0.f ? 1.f / slope : 0.f;
+  auto xhat_g = [&](float o, float r, float d, float &xh, float &g) {
+    if (slope >= 0.f) {
+      const bool pos = o > 0.f;
+      xh = pos ? o : o * inv_slope;
+      g = pos ? d : d * slope;
+    } else {
+      xh = o - r;
+      g = d;
+    }
+  };
+  if (VPT > 0) {
+    float xh[VPT > 0 ? VPT * 4 : 1], g[VPT > 0 ? VPT * 4 : 1];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const long o = base + (threadIdx.x + 256 * i) * 4;
+      const float4 ov = *reinterpret_cast<const float4 *>(out + o);
+      const float4 dv = *reinterpret_cast<const float4 *>(dout + o);
+      float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (res) rv = *reinterpret_cast<const float4 *>(res + o);
+      xhat_g(ov.x, rv.x, dv.x, xh[4 * i + 0], g[4 * i + 0]);
+      xhat_g(ov.y, rv.y, dv.y, xh[4 * i + 1], g[4 * i + 1]);
+      xhat_g(ov.z, rv.z, dv.z, xh[4 * i + 2], g[4 * i + 2]);
+      xhat_g(ov.w, rv.w, dv.w, xh[4 * i + 3], g[4 * i + 3]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s1 += g[4 * i + k];
+        s2 += g[4 * i + k] * xh[4 * i + k];
+      }
+    }
+    const float m1 = block_sum_256(s1, red) * inv;
+    const float m2 = block_sum_256(s2, red) * inv;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const long o = base + (threadIdx.x + 256 * i) * 4;
+      float4 r;
+      r.x = rstd * (g[4 * i + 0] - m1 - xh[4 * i + 0] * m2);
+      r.y = rstd * (g[4 * i + 1] - m1 - xh[4 * i + 1] * m2);
+      r.z = rstd * (g[4 * i + 2] - m1 - xh[4 * i + 2] * m2);
+      r.w = rstd * (g[4 * i + 3] - m1 - xh[4 * i + 3] * m2);
+      *reinterpret_cast<float4 *>(dy + o) = r;
+    }
+  } else {
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+      float xh, g;
+      xhat_g(out[base + i], res ? res[base + i] : 0.f, dout[base + i], xh, g);
+      s1 += g;
+      s2 += g * xh;
+    }
+    const float m1 = block_sum_256(s1, red) * inv;
+    const float m2 = block_sum_256(s2, red) * inv;
+    __syncthreads();
+    for (int i = threadIdx.x; i < hw; i += 256) {
+      float xh, g;
+      xhat_g(out[base + i], res ? res[base + i] : 0.f, dout[base + i], xh, g);
+      dy[base + i] = rstd * (g - m1 - xh * m2);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ out,
+                                                      float *__restrict__ dx, long n, int kind, float slope) {
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 d = *reinterpret_cast<const float4 *>(dy + i);
+      const float4 o = *reinterpret_cast<const float4 *>(out + i);
+      float4 r;
+      if (kind == LSPS_ACT_LRELU) {
+        r.x = o.x > 0.f ? d.x : d.x * slope;
+        r.y = o.y > 0.f ? d.y : d.y * slope;
+        r.z = o.z > 0.f ? d.z : d.z * slope;
+        r.w = o.w > 0.f ? d.w : d.w * slope;
+      } else {
+        r.x = d.x * (1.f - o.x * o.x);
+        r.y = d.y * (1.f - o.y * o.y);
+        r.z = d.z * (1.f - o.z * o.z);
+        r.w = d.w * (1.f - o.w * o.w);
+      }
+      *reinterpret_cast<float4 *>(dx + i) = r;
+    } else {
+      for (long k = i; k < n; ++k) {
+        const float o = out[k], d = dy[k];
+        dx[k] = kind == LSPS_ACT_LRELU ? (o > 0.f ? d : d * slope) : d * (1.f - o * o);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float *__restrict__ x, const float *__restrict__ y, float alpha,
+                                                   float *__restrict__ out, long n) {
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 a = *reinterpret_cast<const float4 *>(x + i);
+      const float4 b = *reinterpret_cast<const float4 *>(y + i);
+      float4 r;
+      r.x = a.x + alpha * b.x;
+      r.y = a.y + alpha * b.y;
+      r.z = a.z + alpha * b.z;
+      r.w = a.w + alpha * b.w;
+      *reinterpret_cast<float4 *>(out + i) = r;
+    } else {
+      for (long k = i; k < n; ++k) out[k] = x[k] + alpha * y[k];
+    }
+  }
+}
+
+static int ew_grid(long n) {
+  long b = (n / 4 + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace lsps
+
+using namespace lsps;
+
+extern "C" {
+
+int lsps_inorm_fwd(const float *y, const float *residual, float *out, float *rstd, int planes, int hw, float eps,
+                   float slope, void *stream) {
+  LSPS_CHECK_ARG(y && out && rstd && planes > 0 && hw > 0, "inorm_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const bool al = (((uintptr_t)y | (uintptr_t)out | (uintptr_t)residual) & 15) == 0;
+  if (hw == 1024 && al)
+    hipLaunchKernelGGL(inorm_fwd_kernel<1>, dim3(planes), dim3(256), 0, st, y, residual, out, rstd, hw, eps, slope);
+  else if (hw == 4096 && al)
+    hipLaunchKernelGGL(inorm_fwd_kernel<4>, dim3(planes), dim3(256), 0, st, y, residual, out, rstd, hw, eps, slope);
+  else
+    hipLaunchKernelGGL(inorm_fwd_kernel<0>, dim3(planes), dim3(256), 0, st, y, residual, out, rstd, hw, eps, slope);
+  LSPS_CHECK_LAUNCH("inorm_fwd");
+  return 0;
+}
+
+int lsps_inorm_bwd(const float *dout, const float *out, const float *residual, const float *rstd, float *dy, int planes,
+                   int hw, float slope, void *stream) {
+  LSPS_CHECK_ARG(dout && out && rstd && dy && planes > 0 && hw > 0, "inorm_bwd: bad argument");
+  LSPS_CHECK_ARG(!(slope == 0.f), "inorm_bwd: slope 0 (ReLU) cannot be inverted from the output");
+  hipStream_t st = (hipStream_t)stream;
+  const bool al = (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)dy) & 15) == 0;
+  if (hw == 1024 && al)
+    hipLaunchKernelGGL(inorm_bwd_kernel<1>, dim3(planes), dim3(256), 0, st, dout, out, residual, rstd, dy, hw, slope);
+  else if (hw == 4096 && al)
+    hipLaunchKernelGGL(inorm_bwd_kernel<4>, dim3(planes), dim3(256), 0, st, dout, out, residual, rstd, dy, hw, slope);
+  else
+    hipLaunchKernelGGL(inorm_bwd_kernel<0>, dim3(planes), dim3(256), 0, st, dout, out, residual, rstd, dy, hw, slope);
+  LSPS_CHECK_LAUNCH("inorm_bwd");
+  return 0;
+}
+
+int lsps_act_bwd(const float *dy, const float *out, float *dx, long n, int kind, float slope, void *stream) {
+  LSPS_CHECK_ARG(dy && out && dx && n >= 0, "act_bwd: bad argument");
+  LSPS_CHECK_ARG(kind == LSPS_ACT_LRELU || kind == LSPS_ACT_TANH, "act_bwd: unknown activation");
+  LSPS_CHECK_ARG((((uintptr_t)dy | (uintptr_t)out | (uintptr_t)dx) & 15) == 0, "act_bwd: pointers must be 16-byte aligned");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, out, dx, n, kind, slope);
+  LSPS_CHECK_LAUNCH("act_bwd");
+  return 0;
+}
+
+int lsps_axpy(const float *x, const float *y, float alpha, float *out, long n, void *stream) {
+  LSPS_CHECK_ARG(x && y && out && n >= 0, "axpy: bad argument");
+  LSPS_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)out) & 15) == 0, "axpy: pointers must be 16-byte aligned");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, alpha, out, n);
+  LSPS_CHECK_LAUNCH("axpy");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,320 @@
+"""torch.autograd.Function wrappers over the C-ABI kernels (include/lsps_hip.h).
+
+PyTorch is used here for device memory, streams and the autograd tape only; every arithmetic
+op below runs in liblsps_hip.so.  Each Function names the torch built-in of the reference it
+replaces.  Inputs must be HIP float32 tensors — there is no CPU fallback (``_lib.ptr`` raises).
+"""
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_SOFTPLUS, ACT_TANH, LOSS_KLSD, LOSS_L1, LOSS_L2, LOSS_SQ  # noqa: F401
+
+LRELU_SLOPE = 0.01     # nn.LeakyReLU() default (src/trainers/common_net.py:169,252,264)
+IN_EPS = 1e-5          # nn.InstanceNorm2d default
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def conv_out_size(h, r, stride, pad):
+    return (h + 2 * pad - r) // stride + 1
+
+
+def convT_out_size(h, r, stride, pad, outpad):
+    return (h - 1) * stride - 2 * pad + r + outpad
+
+
+# ------------------------------------------------------------------------------------------
+# Conv2d (+ fused bias and LeakyReLU/Tanh epilogue)
+# ------------------------------------------------------------------------------------------
+class _Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d [+ nn.LeakyReLU(inplace)] — common_net.py:250-252, 162-163; lsps_nets.py:123-124."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act, slope):
+        L = _lib.lib()
+        x, w = _c(x), _c(w)
+        N, C, H, W = x.shape
+        K, C2, R, S = w.shape
+        assert C == C2, "channel mismatch"
+        P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
+        y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
+        ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, R, S, stride, pad), x.device)
+        _lib.check(L.lsps_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, C, H, W, K, R, S,
+                                     stride, pad, act, slope, ws, wsb, _lib.stream()), 'conv2d_fwd')
+        ctx.geom = (N, C, H, W, K, R, S, stride, pad, act, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w, y = ctx.saved_tensors
+        N, C, H, W, K, R, S, stride, pad, act, slope = ctx.geom
+        dy = _c(dy)
+        st = _lib.stream()
+        if act != ACT_NONE:
+            dpre = torch.empty_like(dy)
+            _lib.check(L.lsps_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dpre), dy.numel(), act, slope, st), 'act_bwd')
+            dy = dpre
+        ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, R, S, stride, pad), x.device)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(L.lsps_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, C, H, W, K, R, S, stride, pad,
+                                           ws, wsb, st), 'conv2d_dgrad')
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = torch.empty(K, dtype=torch.float32, device=x.device)
+            _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), N, C, H, W, K, R, S,
+                                           stride, pad, ws, wsb, st), 'conv2d_wgrad')
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, slope=LRELU_SLOPE):
+    return _Conv2dFn.apply(x, w, b, int(stride), int(pad), int(act), float(slope))
+
+
+# ------------------------------------------------------------------------------------------
+# ConvTranspose2d
+# ------------------------------------------------------------------------------------------
+class _ConvT2dFn(torch.autograd.Function):
+    """nn.ConvTranspose2d [+ LeakyReLU / Tanh] — common_net.py:262-264; lsps_nets.py:17-23, 226-229."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, outpad, act, slope):
+        L = _lib.lib()
+        x, w = _c(x), _c(w)
+        N, Ci, H, W = x.shape
+        Ci2, Co, R, S = w.shape
+        assert Ci == Ci2, "channel mismatch"
+        Ho, Wo = convT_out_size(H, R, stride, pad, outpad), convT_out_size(W, S, stride, pad, outpad)
+        y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+        ws, wsb = _lib.workspace(L.lsps_convT2d_workspace_bytes(N, Ci, H, W, Co, R, S, stride, pad, outpad), x.device)
+        _lib.check(L.lsps_convT2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, Ci, H, W, Co, R, S,
+                                      stride, pad, outpad, act, slope, ws, wsb, _lib.stream()), 'convT2d_fwd')
+        ctx.geom = (N, Ci, H, W, Co, R, S, stride, pad, outpad, act, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w, y = ctx.saved_tensors
+        N, Ci, H, W, Co, R, S, stride, pad, outpad, act, slope = ctx.geom
+        dy = _c(dy)
+        st = _lib.stream()
+        if act != ACT_NONE:
+            dpre = torch.empty_like(dy)
+            _lib.check(L.lsps_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dpre), dy.numel(), act, slope, st), 'act_bwd')
+            dy = dpre
+        ws, wsb = _lib.workspace(L.lsps_convT2d_workspace_bytes(N, Ci, H, W, Co, R, S, stride, pad, outpad), x.device)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(L.lsps_convT2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, Ci, H, W, Co, R, S, stride,
+                                            pad, outpad, ws, wsb, st), 'convT2d_dgrad')
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = torch.empty(Co, dtype=torch.float32, device=x.device)
+            _lib.check(L.lsps_convT2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), N, Ci, H, W, Co, R,
+                                            S, stride, pad, outpad, ws, wsb, st), 'convT2d_wgrad')
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv_transpose2d(x, w, b=None, stride=1, pad=0, outpad=0, act=ACT_NONE, slope=LRELU_SLOPE):
+    return _ConvT2dFn.apply(x, w, b, int(stride), int(pad), int(outpad), int(act), float(slope))
+
+
+# ------------------------------------------------------------------------------------------
+# InstanceNorm2d(affine=False) [+ LeakyReLU] [+ residual], in place on the conv output
+# ------------------------------------------------------------------------------------------
+class _InormFn(torch.autograd.Function):
+    """nn.InstanceNorm2d (+ nn.LeakyReLU(inplace) | `out += residual`) — common_net.py:168-171, 177-181.
+    Works in place on ``y`` (a fresh conv output nobody else saved); the backward is computed from the
+    saved OUTPUT, so the pre-norm tensor is never kept."""
+
+    @staticmethod
+    def forward(ctx, y, residual, slope):
+        L = _lib.lib()
+        assert y.is_contiguous()
+        N, C, H, W = y.shape
+        if residual is not None:
+            residual = _c(residual)
+        rstd = torch.empty(N * C, dtype=torch.float32, device=y.device)
+        _lib.check(L.lsps_inorm_fwd(_lib.ptr(y), _lib.ptr(residual), _lib.ptr(y), _lib.ptr(rstd), N * C, H * W,
+                                    IN_EPS, slope, _lib.stream()), 'inorm_fwd')
+        ctx.mark_dirty(y)
+        ctx.slope = slope
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(y, residual, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        out, residual, rstd = ctx.saved_tensors
+        dout = _c(dout)
+        N, C, H, W = out.shape
+        dy = torch.empty_like(out)
+        _lib.check(L.lsps_inorm_bwd(_lib.ptr(dout), _lib.ptr(out), _lib.ptr(residual), _lib.ptr(rstd), _lib.ptr(dy),
+                                    N * C, H * W, ctx.slope, _lib.stream()), 'inorm_bwd')
+        return dy, (dout if ctx.has_res and ctx.needs_input_grad[1] else None), None
+
+
+def instance_norm_(y, residual=None, slope=-1.0):
+    """In-place fused InstanceNorm: y <- act(IN(y)) (+ residual).  slope < 0: no activation."""
+    return _InormFn.apply(y, residual, float(slope))
+
+
+# ------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kind, denom, a, b):
+        L = _lib.lib()
+        a = _c(a)
+        b = _c(b) if b is not None else None
+        if b is not None:
+            assert a.shape == b.shape, "loss operands must have equal shapes"
+        out = torch.empty(1, dtype=torch.float32, device=a.device)
+        n = a.numel()
+        ws, wsb = _lib.workspace(L.lsps_loss_workspace_bytes(n), a.device)
+        _lib.check(L.lsps_loss_fwd(kind, _lib.ptr(a), _lib.ptr(b), n, denom, _lib.ptr(out), ws, wsb, _lib.stream()),
+                   'loss_fwd')
+        ctx.kind, ctx.denom = kind, denom
+        ctx.save_for_backward(a, b)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        a, b = ctx.saved_tensors
+        g = _c(g.reshape(1))
+        da = torch.empty_like(a)
+        need_b = b is not None and ctx.needs_input_grad[3]
+        db = torch.empty_like(b) if need_b else None
+        _lib.check(L.lsps_loss_bwd(ctx.kind, _lib.ptr(a), _lib.ptr(b), a.numel(), ctx.denom, _lib.ptr(g),
+                                   _lib.ptr(da), _lib.ptr(db), _lib.stream()), 'loss_bwd')
+        return None, None, da, db
+
+
+def l1_loss(a, b=None):
+    """nn.L1Loss()(a, b) (mean); b=None is the feature-matching form against zeros (lsps_trainer.py:44-49,172-177)."""
+    return _LossFn.apply(LOSS_L1, float(a.numel()), a, b)
+
+
+def l2_loss(a, b):
+    """torch.pow(a-b, 2).mean() (lsps_trainer.py:51-52)."""
+    return _LossFn.apply(LOSS_L2, float(a.numel()), a, b)
+
+
+def kl_loss(mu, sd=None):
+    """_compute_kl (lsps_trainer.py:55-60): mean(mu^2), or sum(mu^2+sd^2-log sd^2)/batch."""
+    if sd is None:
+        return _LossFn.apply(LOSS_SQ, float(mu.numel()), mu, None)
+    return _LossFn.apply(LOSS_KLSD, float(mu.size(0)), mu, sd)
+
+
+class _BceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        L = _lib.lib()
+        logits = _c(logits)
+        n = logits.numel()
+        out = torch.empty(3, dtype=torch.float32, device=logits.device)
+        ws, wsb = _lib.workspace(L.lsps_loss_workspace_bytes(n), logits.device)
+        _lib.check(L.lsps_bce_sigmoid_fwd(_lib.ptr(logits), n, target, _lib.ptr(out), ws, wsb, _lib.stream()), 'bce_fwd')
+        ctx.target = target
+        ctx.save_for_backward(logits)
+        counts = out[1:3]
+        ctx.mark_non_differentiable(counts)
+        return out[0], counts
+
+    @staticmethod
+    def backward(ctx, g, _gc):
+        L = _lib.lib()
+        (logits,) = ctx.saved_tensors
+        g = _c(g.reshape(1))
+        dx = torch.empty_like(logits)
+        _lib.check(L.lsps_bce_sigmoid_bwd(_lib.ptr(logits), logits.numel(), ctx.target, _lib.ptr(g), _lib.ptr(dx),
+                                          _lib.stream()), 'bce_bwd')
+        return dx, None
+
+
+def bce_sigmoid(logits, target):
+    """binary_cross_entropy(sigmoid(logits), const target) (lsps_trainer.py:107-112,179-192).
+    Returns (loss, counts) with counts = [#(p>=0.5), #(p<=0.5)] for helpers.py:20-32."""
+    return _BceFn.apply(logits, float(target))
+
+
+# ------------------------------------------------------------------------------------------
+# pose-MLP linear
+# ------------------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    """nn.Linear (+ LeakyReLU | Softplus) — lsps_nets.py:44-50, 73-83; common_net.py:221-231."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope):
+        L = _lib.lib()
+        x, w = _c(x), _c(w)
+        n, i = x.shape
+        o = w.shape[0]
+        y = torch.empty((n, o), dtype=torch.float32, device=x.device)
+        _lib.check(L.lsps_linear_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), n, i, o, act, slope,
+                                     _lib.stream()), 'linear_fwd')
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w, y = ctx.saved_tensors
+        dy = _c(dy)
+        n, i = x.shape
+        o = w.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty(o, dtype=torch.float32, device=x.device)
+        dz = torch.empty_like(y)
+        _lib.check(L.lsps_linear_bwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dw),
+                                     _lib.ptr(db), n, i, o, ctx.act, ctx.slope, _lib.ptr(dz), _lib.stream()), 'linear_bwd')
+        return dx, dw, db, None, None
+
+
+def linear(x, w, b, act=ACT_NONE, slope=LRELU_SLOPE):
+    return _LinearFn.apply(x, w, b, int(act), float(slope))
+
+
+# ------------------------------------------------------------------------------------------
+# elementwise glue
+# ------------------------------------------------------------------------------------------
+class _AxpyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, alpha):
+        L = _lib.lib()
+        x, y = _c(x), _c(y)
+        assert x.shape == y.shape
+        out = torch.empty_like(x)
+        _lib.check(L.lsps_axpy(_lib.ptr(x), _lib.ptr(y), alpha, _lib.ptr(out), x.numel(), _lib.stream()), 'axpy')
+        ctx.alpha = alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gy = None
+        if ctx.needs_input_grad[1]:
+            gy = g * ctx.alpha
+        return g, gy, None
+
+
+def axpy(x, y, alpha=1.0):
+    """x + alpha*y (GaussianNoiseLayer: common_net.py:39-40; reparameterisation: lsps_nets.py:78)."""
+    return _AxpyFn.apply(x, y, float(alpha))

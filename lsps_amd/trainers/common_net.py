@@ -1,0 +1,154 @@
+"""Building blocks of the depth path on the HIP kernels (reference: src/trainers/common_net.py).
+
+Class names, constructor signatures and state-dict keys follow the reference so that its
+checkpoints load unchanged (`<block>.model.0.weight`, `.model.3.weight` ...), but every forward
+runs fused liblsps_hip kernels: conv + bias + LeakyReLU in one launch, InstanceNorm + LeakyReLU
+(+ residual add) in one in-place pass.  Parameter-free placeholder modules keep the Sequential
+indices of the reference where an op has been fused into its neighbour.
+"""
+import math
+
+import numpy as np  # noqa: F401  (leaked by the reference's namespace; depth_train.py:220 uses `np`)
+import torch
+import torch.nn as nn
+from torch.autograd import Variable  # noqa: F401  (leaked too; depth_train.py:145 uses it)
+
+from .init import *  # noqa: F401,F403
+from .init import gaussian_weights_init
+from .. import ops
+from ..ops import ACT_LRELU, ACT_NONE, ACT_TANH, LRELU_SLOPE  # noqa: F401
+
+
+class _Fused(nn.Module):
+    """Index-keeping placeholder for an op executed inside the neighbouring fused kernel."""
+
+    def __init__(self, what):
+        super(_Fused, self).__init__()
+        self.what = what
+
+    def forward(self, x):
+        return x
+
+    def extra_repr(self):
+        return 'fused: %s' % self.what
+
+
+def _default_reset(weight, bias, fan_in):
+    nn.init.kaiming_uniform_(weight, a=math.sqrt(5))          # torch's default conv / linear init
+    if bias is not None:
+        bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+        nn.init.uniform_(bias, -bound, bound)
+
+
+class Conv2d(nn.Module):
+    """Parameter holder + launcher for lsps_conv2d_* (replaces nn.Conv2d; weight (K,C,R,S))."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride=1, padding=0, bias=True, act=ACT_NONE):
+        super(Conv2d, self).__init__()
+        self.stride, self.padding, self.act = stride, padding, act
+        self.weight = nn.Parameter(torch.empty(n_out, n_in, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(n_out)) if bias else None
+        _default_reset(self.weight, self.bias, n_in * kernel_size * kernel_size)
+
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.act, LRELU_SLOPE)
+
+
+class ConvTranspose2d(nn.Module):
+    """Parameter holder + launcher for lsps_convT2d_* (replaces nn.ConvTranspose2d; weight (Ci,Co,R,S))."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride=1, padding=0, output_padding=0, bias=True, act=ACT_NONE):
+        super(ConvTranspose2d, self).__init__()
+        self.stride, self.padding, self.output_padding, self.act = stride, padding, output_padding, act
+        self.weight = nn.Parameter(torch.empty(n_in, n_out, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(n_out)) if bias else None
+        _default_reset(self.weight, self.bias, n_out * kernel_size * kernel_size)
+
+    def forward(self, x):
+        return ops.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding,
+                                    self.act, LRELU_SLOPE)
+
+
+class Linear(nn.Module):
+    """Parameter holder + launcher for lsps_linear_* (replaces nn.Linear)."""
+
+    def __init__(self, n_in, n_out, act=ACT_NONE):
+        super(Linear, self).__init__()
+        self.act = act
+        self.weight = nn.Parameter(torch.empty(n_out, n_in))
+        self.bias = nn.Parameter(torch.empty(n_out))
+        _default_reset(self.weight, self.bias, n_in)
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias, self.act, LRELU_SLOPE)
+
+
+class GaussianNoiseLayer(nn.Module):
+    """x + N(0,1) in training, identity in eval (common_net.py:32-40).  `noise` injects the draw."""
+
+    def forward(self, x, noise=None):
+        if not self.training:
+            return x
+        if noise is None:
+            noise = torch.randn(x.size(), device=x.device, dtype=x.dtype)
+        return ops.axpy(x, noise, 1.0)
+
+
+class LeakyINSResBlock(nn.Module):
+    """x + IN(conv3x3(LReLU(IN(conv3x3(x))))) (common_net.py:160-181).
+    The conv biases are kept for state-dict parity but not applied: an affine-free InstanceNorm
+    subtracts the per-plane mean, so a per-channel constant cancels exactly (gradient exactly 0)."""
+
+    def __init__(self, inplanes, planes, stride=1, dropout=0.0):
+        super(LeakyINSResBlock, self).__init__()
+        if dropout > 0:
+            raise NotImplementedError("res_dropout_ratio > 0 is not used by the shipped configs")
+        self.model = nn.Sequential(
+            Conv2d(inplanes, planes, 3, stride, 1), _Fused('InstanceNorm2d'), _Fused('LeakyReLU'),
+            Conv2d(planes, planes, 3, 1, 1), _Fused('InstanceNorm2d + residual add'))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        c1, c2 = self.model[0], self.model[3]
+        h = ops.conv2d(x, c1.weight, None, c1.stride, 1)
+        h = ops.instance_norm_(h, None, LRELU_SLOPE)
+        h = ops.conv2d(h, c2.weight, None, 1, 1)
+        return ops.instance_norm_(h, x, -1.0)
+
+
+class LeakyReLUConv2d(nn.Module):
+    """LeakyReLU(conv(x)) in one launch (common_net.py:246-256)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0):
+        super(LeakyReLUConv2d, self).__init__()
+        self.model = nn.Sequential(Conv2d(n_in, n_out, kernel_size, stride, padding, act=ACT_LRELU),
+                                   _Fused('LeakyReLU'))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        return self.model[0](x)
+
+
+class LeakyReLUConvTranspose2d(nn.Module):
+    """LeakyReLU(conv_transpose(x)) in one launch per output parity class (common_net.py:258-268)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0, output_padding=0):
+        super(LeakyReLUConvTranspose2d, self).__init__()
+        self.model = nn.Sequential(
+            ConvTranspose2d(n_in, n_out, kernel_size, stride, padding, output_padding, act=ACT_LRELU),
+            _Fused('LeakyReLU'))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        return self.model[0](x)
+
+
+class LeakyReLULinear(nn.Module):
+    """LeakyReLU(linear(x)) (common_net.py:221-231)."""
+
+    def __init__(self, n_in, n_out):
+        super(LeakyReLULinear, self).__init__()
+        self.model = nn.Sequential(Linear(n_in, n_out, act=ACT_LRELU), _Fused('LeakyReLU'))
+
+    def forward(self, x):
+        return self.model[0](x)

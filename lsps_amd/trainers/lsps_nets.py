@@ -1,0 +1,225 @@
+"""The four networks of the depth path on the HIP kernels (reference: src/trainers/lsps_nets.py).
+
+Same class names, constructor dicts, method signatures and state-dict keys as the reference;
+additional keyword-only `noise=` arguments expose the two random draws (GaussianNoiseLayer,
+common_net.py:39; poseVAE.encode, lsps_nets.py:77) so parity tests can inject them.
+"""
+import torch
+import torch.nn as nn
+
+from .common_net import *  # noqa: F401,F403
+from .common_net import (ACT_LRELU, ACT_NONE, ACT_TANH, Conv2d, ConvTranspose2d, GaussianNoiseLayer,
+                         LeakyINSResBlock, LeakyReLUConv2d, LeakyReLUConvTranspose2d, LeakyReLULinear, Linear, _Fused)
+from .. import ops
+from ..ops import ACT_SOFTPLUS
+
+
+class _Net(nn.Module):
+    """Base: `zero_grad` keeps the flat gradient arena (lsps_amd/optim.py) instead of dropping .grad;
+    `.cuda(gpu)` moves the parameters like the reference's per-net overrides do."""
+
+    _arena = None
+
+    def zero_grad(self, set_to_none=True):
+        if self._arena is not None:
+            self._arena.zero_grad()
+        else:
+            super(_Net, self).zero_grad(set_to_none=set_to_none)
+
+    def frozen(self):
+        return _Frozen(self)
+
+
+class _Frozen(object):
+    """Context: parameters do not require grad (skips weight-gradient kernels nobody consumes)."""
+
+    def __init__(self, net):
+        self.params = [p for p in net.parameters() if p.requires_grad]
+
+    def __enter__(self):
+        for p in self.params:
+            p.requires_grad_(False)
+
+    def __exit__(self, *a):
+        for p in self.params:
+            p.requires_grad_(True)
+
+
+class Mapping(_Net):
+    """Pose code [n, input_dim] -> latent map [n, ch, dim, dim] by four 4x4 transposed convs (lsps_nets.py:8-31)."""
+
+    def __init__(self, params):
+        super(Mapping, self).__init__()
+        self.input_dim = params['input_dim']
+        dim, ch = params['output_dim'], params['output_ch']
+        self.output_dim = (ch, dim, dim)
+        self.model = nn.Sequential(
+            LeakyReLUConvTranspose2d(self.input_dim, 4 * ch, kernel_size=4, stride=1, padding=0),
+            LeakyReLUConvTranspose2d(4 * ch, 4 * ch, kernel_size=4, stride=2, padding=1),
+            LeakyReLUConvTranspose2d(4 * ch, 2 * ch, kernel_size=4, stride=2, padding=1),
+            ConvTranspose2d(2 * ch, ch, kernel_size=4, stride=2, padding=1))
+
+    def forward(self, x):
+        return self.model(x.unsqueeze(2).unsqueeze(3).contiguous())
+
+
+class poseVAE(_Net):
+    """Pose MLP: encode 108->50->(20,20) with reparameterisation, decode 20->50->108 (lsps_nets.py:34-83)."""
+
+    def __init__(self, params):
+        super(poseVAE, self).__init__()
+        self.input_dim, self.z_dim, self.h_dim = params['input_dim'], params['z_dim'], params['h_dim']
+        self.en_fc1 = Linear(self.input_dim, self.h_dim, act=ACT_LRELU)      # + self.lrelu, :74
+        self.en_mu = Linear(self.h_dim, self.z_dim)
+        self.en_sigma = Linear(self.h_dim, self.z_dim, act=ACT_SOFTPLUS)     # + self.softplus, :76
+        self.de_fc1 = LeakyReLULinear(self.z_dim, self.h_dim)
+        self.de_fc2 = Linear(self.h_dim, self.input_dim)
+        self.preset_parameters()
+
+    def preset_parameters(self):                                              # :55-59
+        for m in (self.en_mu, self.en_sigma):
+            m.weight.data.normal_(0, 0.002)
+            m.bias.data.normal_(0, 0.002)
+
+    def encode(self, y, noise=None):
+        h = self.en_fc1(y)
+        mu, sd = self.en_mu(h), self.en_sigma(h)
+        if noise is None:                                                     # N(0, 0.05) ALWAYS, also in eval (:77)
+            noise = torch.randn(mu.size(), device=mu.device, dtype=mu.dtype) * 0.05
+        return mu + sd * noise, mu, sd
+
+    def decode(self, z):
+        if z.dim() == 1:                                                      # regress_*().squeeze() at n == 1
+            return self.de_fc2(self.de_fc1(z.unsqueeze(0))).squeeze(0)
+        return self.de_fc2(self.de_fc1(z))
+
+    def forward(self, y, noise=None):
+        z, mu, sd = self.encode(y, noise)
+        return self.decode(z), z, mu, sd
+
+
+class SharedDis(_Net):
+    """Two per-domain strided-conv fronts, shared strided-conv trunk, D (1x1) and Post (2x2) heads
+    (lsps_nets.py:86-160)."""
+
+    def __init__(self, params):
+        super(SharedDis, self).__init__()
+        ch = params['ch']
+        n_front, n_shared = params['n_front_layer'], params['n_shared_layer']
+        n_expand = params['n_expand_layer'] if 'n_expand_layer' in params.keys() else 0
+        self.post_dim, self.reg_dim = params['post_dim'], params['reg_dim']
+        self.model_A, tch = self._make_front_net(ch, params['input_dim_a'], n_front)
+        self.model_B, tch = self._make_front_net(ch, params['input_dim_b'], n_front)
+        self.model_S, self.D, self.Post = self._make_shared_net(tch, n_shared, n_expand)
+        self.dropout = None
+
+    @staticmethod
+    def _make_front_net(ch, input_dim, n_layer):
+        layers = [LeakyReLUConv2d(input_dim, ch, kernel_size=7, stride=2, padding=3)]
+        tch = ch
+        for _ in range(1, n_layer):
+            layers.append(LeakyReLUConv2d(tch, tch * 2, kernel_size=3, stride=2, padding=1))
+            tch *= 2
+        return nn.Sequential(*layers), tch
+
+    def _make_shared_net(self, ch, n_layer, n_expand_layer):
+        layers, tch = [], ch
+        for _ in range(n_expand_layer):
+            layers.append(LeakyReLUConv2d(tch, tch * 2, kernel_size=3, stride=1, padding=1))
+            tch *= 2
+        for _ in range(n_layer):
+            layers.append(LeakyReLUConv2d(tch, tch * 2, kernel_size=3, stride=2, padding=1))
+            tch *= 2
+        post = Conv2d(tch, self.post_dim, kernel_size=2, stride=1, padding=0)
+        discrim = Conv2d(tch, 1, kernel_size=1, stride=1, padding=0)
+        return nn.Sequential(*layers), discrim, post
+
+    def _regress(self, front, x):
+        post = self.Post(self.model_S(front(x))).squeeze()
+        return post, post, post
+
+    def regress_a(self, x_A):
+        return self._regress(self.model_A, x_A)
+
+    def regress_b(self, x_B):
+        return self._regress(self.model_B, x_B)
+
+    def feats(self, x_aa, x_ba, x_ab, x_bb):
+        f = torch.cat((self.model_A(torch.cat((x_aa, x_ba), 0)), self.model_B(torch.cat((x_ab, x_bb), 0))), 0)
+        f = self.model_S(f)
+        return torch.split(f, f.size(0) // 4, dim=0)
+
+    def forward(self, x_A, x_B, second_feats=False):
+        f = self.model_S(torch.cat((self.model_A(x_A), self.model_B(x_B)), 0))
+        out_D = self.D(f)
+        feats_A, feats_B = torch.split(f, f.size(0) // 2, dim=0)
+        out_D_A, out_D_B = torch.split(out_D, out_D.size(0) // 2, dim=0)
+        return out_D_A.reshape(-1), out_D_B.reshape(-1), feats_A, feats_B
+
+
+class SharedResGen(_Net):
+    """Per-domain encoders (7x7 stem, strided 3x3 downsamples, residual blocks) -> shared residual
+    block + Gaussian noise -> shared latent -> shared residual block -> per-domain decoders
+    (residual blocks, 3x3 stride-2 transposed convs, 1x1 transposed conv + tanh) (lsps_nets.py:164-272)."""
+
+    def __init__(self, params):
+        super(SharedResGen, self).__init__()
+        ch = params['ch']
+        if params.get('res_dropout_ratio', 0):
+            raise NotImplementedError("res_dropout_ratio > 0 is not used by the shipped configs")
+
+        def encoder(input_dim):
+            layers = [LeakyReLUConv2d(input_dim, ch, kernel_size=7, stride=1, padding=3)]
+            tch = ch
+            for _ in range(1, params['n_enc_front_blk']):
+                layers.append(LeakyReLUConv2d(tch, tch * 2, kernel_size=3, stride=2, padding=1))
+                tch *= 2
+            layers += [LeakyINSResBlock(tch, tch) for _ in range(params['n_enc_res_blk'])]
+            return nn.Sequential(*layers), tch
+
+        def decoder(tch, output_dim):
+            layers = [LeakyINSResBlock(tch, tch) for _ in range(params['n_gen_res_blk'])]
+            for _ in range(1, params['n_gen_front_blk']):
+                layers.append(LeakyReLUConvTranspose2d(tch, tch // 2, kernel_size=3, stride=2, padding=1,
+                                                       output_padding=1))
+                tch //= 2
+            layers += [ConvTranspose2d(tch, output_dim, kernel_size=1, stride=1, padding=0, act=ACT_TANH),
+                       _Fused('Tanh')]
+            return nn.Sequential(*layers)
+
+        self.encode_A, tch = encoder(params['input_dim_a'])
+        self.encode_B, tch = encoder(params['input_dim_b'])
+        self.enc_shared = nn.Sequential(*([LeakyINSResBlock(tch, tch) for _ in range(params['n_enc_shared_blk'])]
+                                          + [GaussianNoiseLayer()]))
+        self.dec_shared = nn.Sequential(*[LeakyINSResBlock(tch, tch) for _ in range(params['n_gen_shared_blk'])])
+        self.decode_A = decoder(tch, params['input_dim_a'])
+        self.decode_B = decoder(tch, params['input_dim_b'])
+
+    def _enc_shared(self, h, noise):
+        for blk in list(self.enc_shared)[:-1]:
+            h = blk(h)
+        return self.enc_shared[-1](h, noise)
+
+    def decode(self, z):
+        out = self.dec_shared(z)
+        return self.decode_A(out), self.decode_B(out)
+
+    def encode(self, x_A, x_B, noise_a=None, noise_b=None):
+        return self._enc_shared(self.encode_A(x_A), noise_a), self._enc_shared(self.encode_B(x_B), noise_b)
+
+    def forward(self, x_A, x_B, noise=None):
+        out = torch.cat((self.encode_A(x_A), self.encode_B(x_B)), 0)
+        shared = self._enc_shared(out, noise)
+        out = self.dec_shared(shared)
+        out_A, out_B = self.decode_A(out), self.decode_B(out)
+        x_Aa, x_Ba = torch.split(out_A, x_A.size(0), dim=0)
+        x_Ab, x_Bb = torch.split(out_B, x_A.size(0), dim=0)
+        return x_Aa, x_Ba, x_Ab, x_Bb, shared
+
+    def forward_a2b(self, x_A, noise=None):
+        shared = self._enc_shared(self.encode_A(x_A), noise)
+        return self.decode_B(self.dec_shared(shared)), shared
+
+    def forward_b2a(self, x_B, noise=None):
+        shared = self._enc_shared(self.encode_B(x_B), noise)
+        return self.decode_A(self.dec_shared(shared)), shared

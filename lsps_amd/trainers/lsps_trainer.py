@@ -1,0 +1,319 @@
+"""LSPSTrainer on the HIP kernels (reference: src/trainers/lsps_trainer.py:16-350).
+
+Same constructor, attributes (`dis gen vae map`, `*_opt`, `*_sch`, loss / accuracy scalars as
+numpy values) and method signatures as the reference, so `depth_train.py`'s loop drives it
+unchanged.  Differences, none of which changes a result:
+  * back-propagation the reference computes and then throws away is not launched: `dis_update`
+    and `post_update` run the generator without a tape (the reference back-props into `gen` and
+    zeroes/ignores those grads, :77,:144,:221), `gen_update` freezes the discriminator weights
+    (its dis grads are zeroed at :144);
+  * the optimizers step a flat HBM arena with one fused Adam launch (lsps_amd/optim.py);
+  * under `torch.distributed` (one process per GPU) gradients are all-reduced over RCCL in a few
+    large buckets overlapped with backward (lsps_amd/dist.py); single-process behaviour is unchanged;
+  * all per-step scalars are fetched with ONE device->host copy instead of one per loss;
+  * keyword-only `noise=` arguments inject the random draws for parity tests.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .lsps_nets import *  # noqa: F401,F403
+from .lsps_nets import Mapping, SharedDis, SharedResGen, poseVAE
+from .helpers import get_model_list, _compute_fake_acc, _compute_true_acc  # noqa: F401
+from .init import *  # noqa: F401,F403
+from .init import gaussian_weights_init
+from .. import dist as lsps_dist
+from .. import ops
+from ..optim import FlatAdam
+
+_NETS = {'Mapping': Mapping, 'poseVAE': poseVAE, 'SharedDis': SharedDis, 'SharedResGen': SharedResGen}
+
+
+def _net(spec):
+    name = spec['name']
+    if name not in _NETS:
+        raise KeyError("unknown network '%s' (available: %s)" % (name, sorted(_NETS)))
+    return _NETS[name](spec)
+
+
+class LSPSTrainer(nn.Module):
+    def __init__(self, hyperparameters):
+        super(LSPSTrainer, self).__init__()
+        lr = hyperparameters['lr']
+        self.dis = _net(hyperparameters['dis'])
+        self.gen = _net(hyperparameters['gen'])
+        self.vae = _net(hyperparameters['vae'])
+        self.map = _net(hyperparameters['map'])
+        # optimizers / schedulers (lsps_trainer.py:26-34)
+        self.dis_opt = FlatAdam(self.dis.parameters(), lr=lr, betas=(0.5, 0.999), weight_decay=0.0001)
+        self.gen_opt = FlatAdam(list(self.gen.parameters()) + list(self.map.parameters()), lr=lr, betas=(0.5, 0.999),
+                                weight_decay=0.0001)
+        self.vae_opt = FlatAdam(self.vae.parameters(), lr=lr * 10., betas=(0.5, 0.999), weight_decay=0.001)
+        MS = torch.optim.lr_scheduler.MultiStepLR
+        self.dis_sch = MS(self.dis_opt, milestones=[200, 300, 400, 450], gamma=0.5)
+        self.gen_sch = MS(self.gen_opt, milestones=[200, 300, 400, 450], gamma=0.5)
+        self.vae_sch = MS(self.vae_opt, milestones=[125, 175], gamma=0.1)
+        for net in (self.dis, self.gen, self.vae, self.map):                      # :37-40
+            net.apply(gaussian_weights_init)
+        self.gpu = None
+        self._reducers = {}
+
+    # ------------------------------------------------------------------ device / arenas
+    def cuda(self, gpu=None):
+        """Moves the nets to HIP device `gpu` and builds the flat parameter arenas (:334-347)."""
+        if not torch.cuda.is_available():
+            raise ops._lib.LspsHipError("LSPSTrainer.cuda(): no HIP device visible; there is no CPU path")
+        self.gpu = torch.cuda.current_device() if gpu is None else gpu
+        dev = torch.device('cuda', self.gpu)
+        torch.cuda.set_device(dev)
+        for net in (self.dis, self.gen, self.vae, self.map):
+            nn.Module.cuda(net, dev)
+        for key, opt, nets in (('dis', self.dis_opt, (self.dis,)), ('gen', self.gen_opt, (self.gen, self.map)),
+                               ('vae', self.vae_opt, (self.vae,))):
+            arena = opt.attach()
+            for n_ in nets:
+                n_._arena = arena
+            opt.grad_scale = 1.0 / lsps_dist.world()
+            self._reducers[key] = lsps_dist.GradReducer(arena)
+        return self
+
+    def _step(self, key, opt, loss, expected_net=None):
+        red = self._reducers[key]
+        expected = None
+        if lsps_dist.world() > 1 and expected_net is not None:
+            ids = set(id(p) for p in expected_net)
+            expected = [i for i, p in enumerate(red.arena.params) if id(p) in ids]
+        red.begin(expected)
+        loss.backward()
+        red.finish()
+        opt.step()
+
+    def _publish(self, names, tensors, extra=None):
+        """One device->host copy for all per-step scalars; stored as numpy values like the reference."""
+        vals = torch.stack([t.detach().reshape(()).float() for t in tensors]).cpu().numpy()
+        if lsps_dist.world() > 1:
+            vals = np.asarray(lsps_dist.all_reduce_mean_scalars([float(v) for v in vals], 'cuda'), dtype=np.float32)
+        out = dict(zip(names, vals))
+        for k, v in out.items():
+            if extra is None or k not in extra:
+                setattr(self, k, np.asarray(v, dtype=np.float32))
+        return out
+
+    # ------------------------------------------------------------------ loss helpers (:42-60)
+    def _compute_ll_loss(self, a, b):
+        return ops.l1_loss(a, b)
+
+    def _compute_l2_loss(self, a, b):
+        return ops.l2_loss(a, b)
+
+    def _compute_kl(self, mu, sd=None):
+        return ops.kl_loss(mu, sd)
+
+    # ------------------------------------------------------------------ :62-74
+    def vae_update(self, y, hyperparameters, noise=None):
+        self.vae.zero_grad()
+        dec, z, mu, sd = self.vae(y, noise=noise)
+        enc_loss = self._compute_kl(mu, sd)
+        ll_loss = self._compute_ll_loss(dec, y)
+        total_loss = hyperparameters['kl_loss_vae'] * enc_loss + hyperparameters['ll_loss_vae'] * ll_loss
+        self._step('vae', self.vae_opt, total_loss)
+        self._publish(['vae_total_loss'], [total_loss])
+        return dec
+
+    # ------------------------------------------------------------------ :76-141
+    def gen_update(self, images_a, labels_a, images_b, labels_b, hyperparameters, noise=(None, None, None)):
+        hp = hyperparameters
+        if hp['train_map']:
+            raise NotImplementedError("train_map=True (Mapping branch, lsps_trainer.py:84-100) is not built yet")
+        self.gen.zero_grad()
+        x_aa, x_ba, x_ab, x_bb, shared = self.gen(images_a, images_b, noise=noise[0])
+        x_bab, shared_bab = self.gen.forward_a2b(x_ba, noise=noise[1])
+        x_aba, shared_aba = self.gen.forward_b2a(x_ab, noise=noise[2])
+        decode_A, decode_B = x_ba, x_ab
+        with self.dis.frozen():
+            outs_a, outs_b, _, _ = self.dis(x_ba, x_ab)
+        ad_loss_a, _ = ops.bce_sigmoid(outs_a, 1.0)
+        ad_loss_b, _ = ops.bce_sigmoid(outs_b, 1.0)
+        enc_loss = self._compute_kl(shared)
+        enc_bab_loss, enc_aba_loss = self._compute_kl(shared_bab), self._compute_kl(shared_aba)
+        ll_loss_a, ll_loss_b = self._compute_ll_loss(x_aa, images_a), self._compute_ll_loss(x_bb, images_b)
+        ll_loss_aba, ll_loss_bab = self._compute_ll_loss(x_aba, images_a), self._compute_ll_loss(x_bab, images_b)
+        total_loss = hp['gan_w'] * (ad_loss_a + ad_loss_b) + \
+            hp['ll_direct_link_w'] * (ll_loss_a + ll_loss_b) + \
+            hp['ll_cycle_link_w'] * (ll_loss_aba + ll_loss_bab) + \
+            hp['kl_direct_link_w'] * (enc_loss + enc_loss) + \
+            hp['kl_cycle_link_w'] * (enc_bab_loss + enc_aba_loss)                 # enc_loss doubled as in :124
+        self._step('gen', self.gen_opt, total_loss, expected_net=list(self.gen.parameters()))
+        self._publish(['gen_enc_loss', 'gen_enc_loss2', 'gen_ad_loss', 'gen_ll_loss', 'gen_ll_loss2', 'gen_total_loss'],
+                      [enc_loss, enc_aba_loss + enc_bab_loss, ad_loss_a + ad_loss_b, ll_loss_a + ll_loss_b,
+                       ll_loss_bab + ll_loss_aba, total_loss])
+        return (x_aa, x_ba, x_ab, x_bb, x_aba, x_bab, decode_A, decode_B)
+
+    # ------------------------------------------------------------------ :143-218
+    def dis_update(self, images_a, labels_a, images_b, labels_b, com_a, com_b, hyperparameters, feat_mat=True,
+                   noise=None):
+        hp = hyperparameters
+        if hp['train_map']:
+            raise NotImplementedError("train_map=True (Mapping branch, lsps_trainer.py:147-158) is not built yet")
+        self.dis.zero_grad()
+        with torch.no_grad():
+            x_aa, x_ba, x_ab, x_bb, _ = self.gen(images_a, images_b, noise=noise)
+        if feat_mat:
+            data_a, data_b, ndiv = torch.cat((images_a, x_ba, x_aa), 0), torch.cat((images_b, x_ab, x_bb), 0), 3
+        else:
+            data_a, data_b, ndiv = torch.cat((images_a, x_ba), 0), torch.cat((images_b, x_ab), 0), 2
+        res_a, res_b, feats_a, feats_b = self.dis(data_a, data_b)
+        names, vals = [], []
+        feature_loss = None
+        if feat_mat:                                                              # :171-177
+            feat_as = torch.split(feats_a, feats_a.size(0) // ndiv, 0)
+            feat_bs = torch.split(feats_b, feats_a.size(0) // ndiv, 0)
+            feature_loss = self._compute_ll_loss(feat_bs[1], feat_as[2]) + self._compute_ll_loss(feat_as[1], feat_bs[2])
+        ra = torch.split(res_a, res_a.size(0) // ndiv, 0)
+        rb = torch.split(res_b, res_b.size(0) // ndiv, 0)
+        true_a, cnt_ta = ops.bce_sigmoid(ra[0], 1.0)                              # :189-192
+        true_b, cnt_tb = ops.bce_sigmoid(rb[0], 1.0)
+        fake_a, cnt_fa = ops.bce_sigmoid(ra[1], 0.0)
+        fake_b, cnt_fb = ops.bce_sigmoid(rb[1], 0.0)
+        n_true, n_fake = float(ra[0].numel()), float(ra[1].numel())
+        true_acc = 0.5 * (cnt_ta[0] + cnt_tb[0]) / n_true                         # helpers.py:20-32, :194-199
+        fake_acc = 0.5 * (cnt_fa[1] + cnt_fb[1]) / n_fake
+        ad_loss = (true_a + fake_a) + (true_b + fake_b)
+        loss = hp['gan_w'] * ad_loss
+        if feat_mat:
+            loss = loss + hp['feature_w'] * feature_loss
+        self._step('dis', self.dis_opt, loss)
+        names = ['dis_ad_loss', 'dis_loss', 'dis_true_acc', 'dis_fake_acc']
+        vals = [ad_loss, loss, true_acc, fake_acc]
+        if feat_mat:
+            names.append('dis_feat_loss')
+            vals.append(feature_loss)
+        self._publish(names, vals)
+        return
+
+    # ------------------------------------------------------------------ :220-262
+    def post_update(self, images_a, labels_a, images_b, labels_b, com_a, com_b, mode, hyperparameters, noise=None):
+        hp = hyperparameters
+        noise = noise or {}
+        self.dis.zero_grad()
+        x_aa, x_ba, x_ab, x_bb = images_a, images_a, images_b, images_b
+        terms_reg, terms_feat = [], []
+
+        def regression(front, images, labels, nz):
+            _, pred, _ = front(images)
+            with torch.no_grad():                                                 # target: noisy vae code (:229,:246)
+                target, _, _ = self.vae.encode(labels, noise=nz)
+            return self._compute_l2_loss(pred, target.reshape(pred.shape))
+
+        if mode == 0:
+            terms_reg.append(regression(self.dis.regress_a, images_a, labels_a, noise.get('vae_a')))
+        elif mode == 1:
+            terms_reg.append(regression(self.dis.regress_b, images_b, labels_b, noise.get('vae_b')))
+        else:
+            first_a, first_b = images_a[0:4], images_b[0:4]                       # :238 — only the first 4 samples
+            if lsps_dist.world() > 1:
+                # exact global-batch parity: every rank evaluates the SAME (global first-4) feature term
+                first_a, first_b = first_a.clone(), first_b.clone()
+                torch.distributed.broadcast(first_a, 0)
+                torch.distributed.broadcast(first_b, 0)
+            with torch.no_grad():
+                x_aa, x_ba, x_ab, x_bb, _ = self.gen(first_a, first_b, noise=noise.get('gen'))
+            f_x_aa, f_x_ba, f_x_ab, f_x_bb = self.dis.feats(x_aa, x_ba, x_ab, x_bb)
+            terms_feat.append(self._compute_ll_loss(f_x_ab, f_x_aa))
+            terms_feat.append(self._compute_ll_loss(f_x_ba, f_x_bb))
+            terms_reg.append(regression(self.dis.regress_a, images_a, labels_a, noise.get('vae_a')))
+            if mode == 4:
+                terms_reg.append(regression(self.dis.regress_b, images_b, labels_b, noise.get('vae_b')))
+        reg_loss = sum(terms_reg[1:], terms_reg[0])
+        total_loss = hp['reg_w'] * reg_loss
+        if terms_feat:
+            total_loss = total_loss + hp['feature_w_reg'] * (terms_feat[0] + terms_feat[1])
+        self._step('dis', self.dis_opt, total_loss)
+        self._publish(['dis_reg_loss', 'dis_total_loss'], [reg_loss, total_loss])
+        return (x_aa, x_ba, x_ab, x_bb, x_aa, x_bb, x_aa, x_bb)
+
+    # ------------------------------------------------------------------ :264-276, 349-350
+    def normalize_image(self, x):
+        return x[:, 0:3, :, :]
+
+    def assemble_outputs(self, images_a, images_b, network_outputs):
+        o = [self.normalize_image(t) for t in network_outputs]
+        a, b = self.normalize_image(images_a), self.normalize_image(images_b)
+        x_aa, x_ba, x_ab, x_bb, x_aba, x_bab, dec_a, dec_b = o
+        return torch.cat((a[0:1], x_aa[0:1], x_ab[0:1], x_aba[0:1], dec_a[0:1], dec_b[0:1],
+                          b[0:1], x_bb[0:1], x_ba[0:1], x_bab[0:1]), 3)
+
+    # ------------------------------------------------------------------ checkpoints (:278-332)
+    @staticmethod
+    def _load(path):
+        return torch.load(path, map_location='cpu')
+
+    def resume(self, snapshot_prefix, idx=-1, load_opt=False, est=False):
+        dirname = os.path.dirname(snapshot_prefix)
+        last_model_name = get_model_list(dirname, "est_gen" if est else "gen", idx)
+        if last_model_name is None:
+            return 0
+        self.gen.load_state_dict(self._load(last_model_name), strict=False)
+        iterations = int(last_model_name[-12:-4])
+        last_model_name = get_model_list(dirname, "est_dis" if est else "dis", idx)
+        self.dis.load_state_dict(self._load(last_model_name), strict=False)
+        if load_opt:
+            try:
+                self.gen_opt.load_state_dict(self._load(get_model_list(dirname, "optg", idx)))
+                self.dis_opt.load_state_dict(self._load(get_model_list(dirname, "optd", idx)))
+                print('-----optimizer parameters loaded!')
+            except Exception:
+                print('-----Failed to load optimizer parameters!')
+        try:
+            self.map.load_state_dict(self._load(get_model_list(dirname, "map", idx)), strict=False)
+        except Exception:
+            print('-----Failed to load map parameters!')
+        print('Resume from iteration %d' % iterations)
+        return iterations
+
+    @staticmethod
+    def _dense_state(net):
+        return dict((k, v.detach().clone()) for k, v in net.state_dict().items())   # not views of the arena
+
+    def save(self, snapshot_prefix, iterations):
+        torch.save(self._dense_state(self.gen), '%s_gen_%08d.pkl' % (snapshot_prefix, iterations + 1))
+        torch.save(self._dense_state(self.dis), '%s_dis_%08d.pkl' % (snapshot_prefix, iterations + 1))
+
+    def save_vae(self, snapshot_prefix, iterations, frac):
+        torch.save(self._dense_state(self.vae), '%s_vae_%.2f_%08d.pkl' % (snapshot_prefix, frac, iterations + 1))
+
+    def load_vae(self, snapshot_prefix, frac):
+        dirname = os.path.dirname(snapshot_prefix)
+        last_model_name = get_model_list(dirname, 'vae_%.2f' % frac)
+        if last_model_name is None:
+            return 0
+        self.vae.load_state_dict(self._load(last_model_name))
+        print('Loading pretrained VAE parameters from %s' % last_model_name)
+        return 0
+
+
+# ---------------------------------------------------------------------------------------------
+# harness hooks used by tests/golden/cases.py (NativeAdapter)
+# ---------------------------------------------------------------------------------------------
+def make_trainer(hp, device='cuda'):
+    tr = LSPSTrainer(hp)
+    dev = torch.device(device)
+    tr.cuda(dev.index if dev.index is not None else torch.cuda.current_device())
+    return tr
+
+
+def set_training(gen, flag):
+    gen.train(bool(flag))
+
+
+def named_grads(net, to_numpy):
+    arena = net._arena
+    touched = {}
+    if arena is not None:
+        touched = dict((id(p), t) for p, t in zip(arena.params, arena.touched))
+    out = {}
+    for k, p in net.named_parameters():
+        out[k] = to_numpy(p.grad) if (p.grad is not None and touched.get(id(p), True)) else None
+    return out

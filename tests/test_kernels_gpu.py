@@ -1,0 +1,246 @@
+"""Per-kernel parity of liblsps_hip.so (through the C-ABI, via lsps_amd.ops) against plain torch
+fp32 CPU ops — the same torch ops the oracle is made of.  Tolerance: 1e-4 relative to the
+reference tensor's abs-max for forward / dgrad, 2e-4 for weight gradients (long fp32 reductions).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / max(b.abs().max().item(), 1e-30))
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+# (N, C, H, W, K, R, stride, pad) — every conv geometry of SharedResGen / SharedDis (ch=64 and tiny),
+# plus ragged sizes that do not fill tiles.
+CONV_CASES = [
+    (2, 1, 128, 128, 64, 7, 1, 3),      # gen stem
+    (2, 64, 128, 128, 128, 3, 2, 1),    # gen down 1
+    (2, 128, 64, 64, 256, 3, 2, 1),     # gen down 2
+    (3, 256, 32, 32, 256, 3, 1, 1),     # residual conv (dominant)
+    (2, 1, 128, 128, 64, 7, 2, 3),      # dis stem
+    (2, 64, 64, 64, 128, 3, 2, 1),      # dis front
+    (4, 128, 32, 32, 256, 3, 2, 1),     # dis shared 0
+    (4, 256, 16, 16, 512, 3, 2, 1),
+    (4, 512, 8, 8, 1024, 3, 2, 1),
+    (4, 1024, 4, 4, 2048, 3, 2, 1),
+    (6, 2048, 2, 2, 1, 1, 1, 0),        # D head
+    (6, 2048, 2, 2, 20, 2, 1, 0),       # Post head
+    (1, 2048, 2, 2, 20, 2, 1, 0),       # Post head, n = 1
+    (2, 8, 128, 128, 16, 3, 2, 1),      # tiny-width layers
+    (5, 3, 17, 13, 37, 3, 1, 1),        # ragged everything
+    (3, 5, 19, 23, 70, 5, 2, 2),        # 5x5 stride 2, ragged
+    (2, 33, 9, 9, 129, 3, 3, 0),        # stride 3
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_fwd_dgrad_wgrad(case):
+    _need_gpu()
+    from lsps_amd import ops
+    N, C, H, W, K, R, st, pad = case
+    x = _rand(N, C, H, W, seed=1).requires_grad_(True)
+    w = _rand(K, C, R, R, seed=2, scale=0.1).requires_grad_(True)
+    b = _rand(K, seed=3, scale=0.1).requires_grad_(True)
+    y_ref = F.leaky_relu(F.conv2d(x, w, b, stride=st, padding=pad), 0.01)
+    gy = _rand(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+
+    xd, wd, bd = (t.detach().cuda().requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xd, wd, bd, st, pad, ops.ACT_LRELU, 0.01)
+    y.backward(gy.cuda())
+    assert y.shape == y_ref.shape
+    assert _rel(y, y_ref) < 1e-4
+    assert _rel(xd.grad, x.grad) < 1e-4
+    assert _rel(wd.grad, w.grad) < 2e-4
+    assert _rel(bd.grad, b.grad) < 2e-4
+
+
+# (N, Ci, H, W, Co, R, stride, pad, outpad)
+CONVT_CASES = [
+    (2, 256, 32, 32, 128, 3, 2, 1, 1),   # gen up 1
+    (2, 128, 64, 64, 64, 3, 2, 1, 1),    # gen up 2
+    (2, 64, 128, 128, 1, 1, 1, 0, 0),    # gen output 1x1
+    (3, 20, 1, 1, 64, 4, 1, 0, 0),       # Mapping layer 0 (narrow)
+    (3, 64, 4, 4, 48, 4, 2, 1, 0),       # Mapping 4x4 stride 2
+    (2, 7, 5, 6, 9, 3, 2, 1, 1),         # ragged
+    (2, 6, 7, 5, 10, 3, 1, 1, 0),        # stride 1
+    (2, 5, 6, 6, 4, 5, 3, 2, 2),         # stride 3
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("act", ["lrelu", "tanh", "none"])
+def test_conv_transpose2d(case, act):
+    _need_gpu()
+    from lsps_amd import ops
+    N, Ci, H, W, Co, R, st, pad, op = case
+    x = _rand(N, Ci, H, W, seed=5).requires_grad_(True)
+    w = _rand(Ci, Co, R, R, seed=6, scale=0.1).requires_grad_(True)
+    b = _rand(Co, seed=7, scale=0.1).requires_grad_(True)
+    pre = F.conv_transpose2d(x, w, b, stride=st, padding=pad, output_padding=op)
+    y_ref = {'lrelu': lambda t: F.leaky_relu(t, 0.01), 'tanh': torch.tanh, 'none': lambda t: t}[act](pre)
+    gy = _rand(*y_ref.shape, seed=8)
+    y_ref.backward(gy)
+    code = {'lrelu': ops.ACT_LRELU, 'tanh': ops.ACT_TANH, 'none': ops.ACT_NONE}[act]
+    xd, wd, bd = (t.detach().cuda().requires_grad_(True) for t in (x, w, b))
+    y = ops.conv_transpose2d(xd, wd, bd, st, pad, op, code, 0.01)
+    y.backward(gy.cuda())
+    assert y.shape == y_ref.shape
+    assert _rel(y, y_ref) < 1e-4
+    assert _rel(xd.grad, x.grad) < 1e-4
+    assert _rel(wd.grad, w.grad) < 2e-4
+    assert _rel(bd.grad, b.grad) < 2e-4
+
+
+@pytest.mark.parametrize("shape", [(3, 256, 32, 32), (2, 8, 64, 64), (2, 5, 7, 9), (1, 3, 128, 128)])
+@pytest.mark.parametrize("variant", ["lrelu", "residual", "plain"])
+def test_instance_norm_fused(shape, variant):
+    _need_gpu()
+    from lsps_amd import ops
+    y = _rand(*shape, seed=9, scale=3.0).requires_grad_(True)
+    r = _rand(*shape, seed=10).requires_grad_(True)
+    ref = F.instance_norm(y, eps=1e-5)
+    if variant == 'lrelu':
+        ref = F.leaky_relu(ref, 0.01)
+    elif variant == 'residual':
+        ref = ref + r
+    g = _rand(*shape, seed=11)
+    ref.backward(g)
+
+    yd = y.detach().cuda().requires_grad_(True)
+    rd = r.detach().cuda().requires_grad_(True)
+    pre = yd * 1.0                                   # a non-leaf the op may overwrite in place
+    out = ops.instance_norm_(pre, rd if variant == 'residual' else None, 0.01 if variant == 'lrelu' else -1.0)
+    out.backward(g.cuda())
+    assert _rel(out, ref) < 1e-4
+    assert _rel(yd.grad, y.grad) < 2e-4
+    if variant == 'residual':
+        assert _rel(rd.grad, r.grad) < 1e-6
+
+
+@pytest.mark.parametrize("n", [1, 7, 4096, 100003, 3 * 1024 * 1024 + 5])
+def test_losses(n):
+    _need_gpu()
+    from lsps_amd import ops
+    a = _rand(n, seed=12).requires_grad_(True)
+    b = _rand(n, seed=13).requires_grad_(True)
+    ad, bd = a.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    cases = [
+        (lambda p, q: (p - q).abs().mean(), lambda p, q: ops.l1_loss(p, q)),
+        (lambda p, q: ((p - q) ** 2).mean(), lambda p, q: ops.l2_loss(p, q)),
+        (lambda p, q: (p ** 2).mean() + 0 * q.sum(), lambda p, q: ops.kl_loss(p)),
+    ]
+    for ref_fn, hip_fn in cases:
+        for t in (a, b, ad, bd):
+            t.grad = None
+        lr = ref_fn(a, b) * 3.0
+        lr.backward()
+        lh = hip_fn(ad, bd) * 3.0
+        lh.backward()
+        assert abs(lh.item() - lr.item()) <= 1e-5 * max(1.0, abs(lr.item()))
+        assert _rel(ad.grad, a.grad) < 1e-5
+        if bd.grad is not None and b.grad is not None and b.grad.abs().max() > 0:
+            assert _rel(bd.grad, b.grad) < 1e-5
+
+
+def test_l1_against_zero_and_kl_sd():
+    _need_gpu()
+    from lsps_amd import ops
+    a = _rand(6, 20, seed=14).requires_grad_(True)
+    sd = (_rand(6, 20, seed=15).abs() + 0.1).requires_grad_(True)
+    ad, sdd = a.detach().cuda().requires_grad_(True), sd.detach().cuda().requires_grad_(True)
+    ref = (a ** 2 + sd ** 2 - torch.log(sd ** 2)).sum() / a.size(0)
+    ref.backward()
+    hip = ops.kl_loss(ad, sdd)
+    hip.backward()
+    assert abs(hip.item() - ref.item()) < 1e-5 * abs(ref.item())
+    assert _rel(ad.grad, a.grad) < 1e-5 and _rel(sdd.grad, sd.grad) < 1e-5
+    z = ops.l1_loss(ad.detach())
+    assert abs(z.item() - a.detach().abs().mean().item()) < 1e-6
+
+
+@pytest.mark.parametrize("n", [8, 513, 4 * 768])
+@pytest.mark.parametrize("target", [1.0, 0.0])
+def test_bce_sigmoid(n, target):
+    _need_gpu()
+    from lsps_amd import ops
+    x = (_rand(n, seed=16) * 6).requires_grad_(True)
+    with torch.no_grad():
+        x[0] = 40.0       # saturates sigmoid in fp32: exercises torch's log clamp at -100
+        x[1] = -40.0
+    p = torch.sigmoid(x)
+    ref = F.binary_cross_entropy(p, torch.full_like(p, target))
+    ref.backward()
+    xd = x.detach().cuda().requires_grad_(True)
+    loss, counts = ops.bce_sigmoid(xd, target)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+    assert _rel(xd.grad, x.grad) < 1e-5
+    assert int(counts[0].item()) == int((p >= 0.5).sum().item())
+    assert int(counts[1].item()) == int((p <= 0.5).sum().item())
+
+
+@pytest.mark.parametrize("act", ["none", "lrelu", "softplus"])
+def test_linear(act):
+    _need_gpu()
+    from lsps_amd import ops
+    x = _rand(9, 108, seed=17).requires_grad_(True)
+    w = _rand(50, 108, seed=18, scale=0.2).requires_grad_(True)
+    b = _rand(50, seed=19, scale=0.2).requires_grad_(True)
+    pre = F.linear(x, w, b)
+    ref = {'none': lambda t: t, 'lrelu': lambda t: F.leaky_relu(t, 0.01), 'softplus': F.softplus}[act](pre)
+    g = _rand(9, 50, seed=20)
+    ref.backward(g)
+    code = {'none': ops.ACT_NONE, 'lrelu': ops.ACT_LRELU, 'softplus': ops.ACT_SOFTPLUS}[act]
+    xd, wd, bd = (t.detach().cuda().requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xd, wd, bd, code, 0.01)
+    y.backward(g.cuda())
+    assert _rel(y, ref) < 1e-5
+    assert _rel(xd.grad, x.grad) < 1e-5 and _rel(wd.grad, w.grad) < 1e-5 and _rel(bd.grad, b.grad) < 1e-5
+
+
+def test_flat_adam_matches_torch_adam():
+    """FlatAdam over the arena == torch.optim.Adam, including the skip of gradient-less tensors and
+    per-parameter step counts."""
+    _need_gpu()
+    from lsps_amd.optim import FlatAdam
+    shapes = [(64, 1, 7, 7), (64,), (5000,), (3, 3), (20, 2048, 2, 2)]
+    ps_ref = [torch.nn.Parameter(_rand(*s, seed=30 + i, scale=0.05)) for i, s in enumerate(shapes)]
+    ps_hip = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ps_ref]
+    ref = torch.optim.Adam(ps_ref, lr=1e-3, betas=(0.5, 0.999), weight_decay=1e-4)
+    hip = FlatAdam(ps_hip, lr=1e-3, betas=(0.5, 0.999), weight_decay=1e-4)
+    hip.attach()
+    for step in range(4):
+        ref.zero_grad()
+        hip.zero_grad()
+        for i, (pr, ph) in enumerate(zip(ps_ref, ps_hip)):
+            if step % 2 == 1 and i == 2:
+                continue                      # tensor 2 gets no gradient on odd steps
+            g = _rand(*pr.shape, seed=100 * step + i, scale=0.01)
+            (pr * g).sum().backward()
+            (ph * g.cuda()).sum().backward()
+        ref.step()
+        hip.step()
+    for pr, ph in zip(ps_ref, ps_hip):
+        assert _rel(ph, pr) < 1e-5
+
+
+def test_ops_reject_cpu_tensors():
+    from lsps_amd import ops, _lib
+    with pytest.raises(Exception):
+        ops.conv2d(torch.zeros(1, 1, 4, 4), torch.zeros(1, 1, 3, 3), None, 1, 1)

@@ -1,0 +1,92 @@
+"""End-to-end parity of the HIP product path (lsps_amd.trainers, through the C-ABI) against
+  (a) the golden vectors captured from the REAL reference (tests/golden/golden_*.npz), and
+  (b) the CPU oracle run on the same seeded inputs here.
+Tolerances (north_star: 1e-3 rel fp32): forward tensors and loss scalars 1e-3 of abs-max;
+gradients 2e-2 (discontinuous in the activations, see cases.compare); post-Adam weights via the
+robust rule in cases.compare."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import lsps_ref
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3
+
+
+def _adapter():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import lsps_amd.trainers as prod
+    return cases.NativeAdapter(prod, 'cuda')
+
+
+@pytest.mark.parametrize("config", ["tiny", "full"])
+def test_modules_match_reference_golden(config, golden):
+    A = _adapter()
+    R = cases.run_module_cases(A, config, lsps_ref)
+    g = {k: v for k, v in golden(config).items() if k.split('/')[0] in R}
+    bad, worst = cases.compare(R, g, RTOL)
+    print("worst rel err", worst)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
+
+
+@pytest.mark.parametrize("config", ["tiny", "full"])
+def test_steps_match_reference_golden(config, golden):
+    A = _adapter()
+    R = cases.run_step_cases(A, config, lsps_ref)
+    g = {k: v for k, v in golden(config).items() if k.split('/')[0] in R}
+    bad, worst = cases.compare(R, g, RTOL, grad_rtol=2e-2)
+    print("worst rel err", worst)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
+
+
+def test_joint_readout_matches_oracle():
+    """A12: regress_b -> vae.decode -> mm joints; worst-joint argmax and <=40 mm decisions identical,
+    joint coordinates within 1e-3 (depth_train.py:200-253, handpose_evaluation.py:97,130-136,203)."""
+    A = _adapter()
+    hp = cases.hp_for('full')
+    sds = cases.make_weights(hp, lsps_ref)
+    n = 16
+    b = cases.make_inputs(n)
+    cube = np.array([300.0, 300.0, 300.0], np.float32)
+    ref_tr = cases.NativeAdapter(lsps_ref, 'cpu').make_trainer(hp, sds)
+    ref = lsps_ref.joint_readout(ref_tr.dis, ref_tr.vae, torch.as_tensor(b['xb']), torch.as_tensor(b['lb']), b['cb'], cube)
+    tr = A.make_trainer(hp, sds)
+    tr.dis.eval()
+    with torch.no_grad():
+        _, post, _ = tr.dis.regress_b(A.T(b['xb']))
+        pose = tr.vae.decode(post).cpu().numpy()
+    gt = b['lb'].reshape(n, -1, 3)[:, lsps_ref.NYU_EVAL_JOINTS]
+    pr = pose.reshape(n, -1, 3)[:, lsps_ref.NYU_EVAL_JOINTS]
+    com = b['cb'].reshape(n, 1, 3)
+    pr3d, gt3d = pr * (cube[0] / 2.) + com, gt * (cube[0] / 2.) + com
+    err = np.sqrt(np.square(gt3d - pr3d).sum(axis=2))
+    assert np.abs(pose - ref['pose']).max() <= 1e-3 * np.abs(ref['pose']).max()
+    assert (np.argmax(err, axis=1) == ref['worst_joint']).all()
+    assert int((np.nanmax(err, axis=1) <= 40).sum()) == ref['frames_within_40']
+    assert abs(np.nanmean(np.nanmean(err, axis=1)) - ref['mean_err']) <= 1e-3 * ref['mean_err']
+
+
+def test_full_batch_properties():
+    """Size-independent checks at BASELINE's full size (bs=128 per domain, ch=64), where the oracle is
+    too slow to run: per-sample independence (a sample's output does not depend on its batch-mates),
+    linearity of conv in its input, and tanh range."""
+    A = _adapter()
+    hp = cases.hp_for('full')
+    sds = cases.make_weights(hp, lsps_ref)
+    tr = A.make_trainer(hp, sds)
+    A.set_train(tr, False)
+    n = 128
+    b = cases.make_inputs(n)
+    with torch.no_grad():
+        xa, xb = A.T(b['xa']), A.T(b['xb'])
+        big = tr.gen(xa, xb)
+        small = tr.gen(xa[5:7].contiguous(), xb[5:7].contiguous())
+        for t_big, t_small in zip(big[:4], small[:4]):
+            assert float((t_big[5:7] - t_small).abs().max()) <= 1e-5
+            assert float(t_big.abs().max()) <= 1.0
+        post_big = tr.dis.regress_b(xb)[1]
+        post_small = tr.dis.regress_b(xb[40:44].contiguous())[1]
+        assert float((post_big[40:44] - post_small).abs().max()) <= 1e-4 * float(post_big.abs().max())
