@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""depth_train throughput on MI355X (BASELINE.json: "depth_train steps/sec (128x128x1, bs=128)").
+
+A "step" = one pretrain iteration of depth_train.py's hot loop (reference
+src/depth_train.py:152-160): `dis_update` then `gen_update` of LSPSTrainer on one synthetic
+NYU-shape batch of 128 depth crops per domain (enc + dec + discriminator + KL / L1 / GAN losses,
+forward + dgrad + wgrad + Adam), all through the HIP kernels.  With --gpus N (launched by
+torch.distributed.run, one process per GPU) every rank runs 128 samples per domain (weak
+scaling) and gradients are all-reduced over RCCL; value = global steps/s of the whole job
+(N ranks x 128 samples advance one global step of batch 128*N).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for field definitions).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests', 'golden'))
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
+
+
+def load_hp():
+    import yaml
+    with open(os.path.join(REPO, 'exps', 'nnyu.yaml')) as f:
+        return yaml.safe_load(f)['train']['hyperparameters']
+
+
+def make_device_batch(n, device, seed_offset=0):
+    import torch
+    from lsps_amd import synth
+    xa, la, ca = synth.make_batch(n, synth.YAML_SEED + 10 * seed_offset)
+    xb, lb, cb = synth.make_batch(n, synth.YAML_SEED + 10 * seed_offset + 1)
+    t = lambda a: torch.as_tensor(a).to(device)   # noqa: E731
+    return dict(xa=t(xa), la=t(la), ca=t(ca), xb=t(xb), lb=t(lb), cb=t(cb))
+
+
+def cpu_baseline(hp, target_seconds=15.0):
+    """The oracle (CPU restatement of the reference, literal backward scope) timed on this host's cores
+    on a bounded sample of the same workload: one pretrain step at a reduced batch, scaled per sample."""
+    import torch
+    from oracle import lsps_ref
+    from lsps_amd import synth
+    threads = max(1, (os.cpu_count() or 2) // 2)          # physical cores
+    torch.set_num_threads(threads)
+    tr = lsps_ref.RefTrainer(hp, literal=True)
+    for net, shapes, seed in ((tr.gen, lsps_ref.gen_shapes(hp['gen']), 1), (tr.dis, lsps_ref.dis_shapes(hp['dis']), 2),
+                              (tr.vae, lsps_ref.vae_shapes(hp['vae']), 3)):
+        net.load_state_dict(synth.make_state_dict(shapes, seed))
+
+    def step(n):
+        xa, la, ca = synth.make_batch(n, synth.YAML_SEED)
+        xb, lb, cb = synth.make_batch(n, synth.YAML_SEED + 1)
+        T = torch.as_tensor
+        t0 = time.time()
+        tr.dis_update(T(xa), T(la), T(xb), T(lb), T(ca), T(cb), hp)
+        tr.gen_update(T(xa), T(la), T(xb), T(lb), hp)
+        return time.time() - t0
+
+    step(2)                                                # warm-up (thread pools, oneDNN primitives)
+    t4 = step(4)
+    n = int(max(4, min(32, 4 * round(target_seconds / max(t4, 1e-3) / 1.0))))
+    n = max(4, (n // 4) * 4)
+    times = [step(n) for _ in range(2)] if n > 4 else [t4, step(4)]
+    t = min(times)
+    return dict(value=(1.0 / t) * (n / 128.0), unit='steps/s', cores=threads, kind='port',
+                sample='1 warm-up + %d timed pretrain steps (dis_update+gen_update, literal reference backward scope) at '
+                       'bs=%d per domain, %.2f s/step min; scaled linearly to bs=128 (x %d/128); torch %s CPU, %d threads'
+                       % (len(times), n, t, n, torch.__version__, threads))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=128, help='samples per domain per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the secondary workloads (estimate3, fwd-only)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one process per GPU)" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import lsps_amd.trainers as trainers
+    from lsps_amd import ops, synth
+    from oracle import lsps_ref            # only for the key->shape tables of the seeded weights + cpu_baseline
+
+    hp = load_hp()
+    tr = trainers.LSPSTrainer(hp)
+    tr.cuda(local_rank)
+    for net, shapes, seed in ((tr.gen, lsps_ref.gen_shapes(hp['gen']), 1), (tr.dis, lsps_ref.dis_shapes(hp['dis']), 2),
+                              (tr.vae, lsps_ref.vae_shapes(hp['vae']), 3)):
+        net.load_state_dict({k: torch.as_tensor(v) for k, v in synth.make_state_dict(shapes, seed).items()})
+    tr.gen.train()
+    tr.dis.train()
+    b = make_device_batch(args.batch, dev, seed_offset=rank)
+
+    def pretrain_step():
+        tr.dis_update(b['xa'], b['la'], b['xb'], b['lb'], b['ca'], b['cb'], hp)
+        tr.gen_update(b['xa'], b['la'], b['xb'], b['lb'], hp)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pretrain_step()
+    ops.profiler.reset()
+    ops.profiler.enabled = True
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pretrain_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.profiler.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = ops.profiler.summary()
+
+    extra = {}
+    if not args.no_extra and world == 1:
+        def timed(fn, k):
+            fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(k):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / k
+        t_est = timed(lambda: tr.post_update(b['xa'], b['la'], b['xb'], b['lb'], b['ca'], b['cb'], 3, hp), 5)
+        tr.gen.eval()
+        with torch.no_grad():
+            t_fwd = timed(lambda: tr.gen(b['xa'], b['xb']), 3)
+        tr.gen.train()
+        extra = {'estimate3_step_bs%d' % args.batch: {'steps_per_s': 1.0 / t_est, 'ms_per_step': 1e3 * t_est,
+                                                       'algorithmic_tflop_per_step': 0.579 * args.batch / 128.0},
+                 'gen_forward_bs%d' % args.batch: {'calls_per_s': 1.0 / t_fwd, 'ms_per_call': 1e3 * t_fwd,
+                                                   'tflops': 7.76 * args.batch / 128.0 / t_fwd}}
+
+    if rank == 0:
+        dom = prof.get('igemm_f<128x128>', None)
+        roofline = None
+        if dom:
+            roofline = {'bound': 'mfma', 'kernel': 'igemm_f_kernel<2,2,2,2> (implicit-GEMM conv, f32 MFMA 32x32x2)',
+                        'achieved': dom['tflops'], 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': dom['tflops'] / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                        'launches': dom['launches'], 'avg_launch_ms': dom['avg_ms'],
+                        'algorithmic_gflop_per_launch': dom['gflop_per_launch'],
+                        'share_of_step_time': dom['total_ms'] / (1e3 * elapsed),
+                        'per_kernel': prof}
+        out = {
+            'metric': 'depth_train steps/sec (128x128x1, bs=128)', 'value': args.steps / elapsed, 'unit': 'steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'pretrain step = LSPSTrainer.dis_update + gen_update (enc+dec+disc+KL), exps/nnyu.yaml nets '
+                                   '(gen.ch=64, dis.ch=64), synthetic NYU-shape 128x128x1 depth crops',
+                       'batch_per_domain_per_gpu': args.batch, 'global_batch_per_domain': args.batch * world,
+                       'parallelism': 'dp%d' % world, 'algorithmic_tflop_per_step_per_gpu': 50.0 * args.batch / 128.0},
+            'step_tflops_per_gpu': 50.0 * args.batch / 128.0 / (elapsed / args.steps),
+            'roofline': roofline, 'other_workloads': extra,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(hp)
+            out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -54,6 +54,9 @@ def lib():
     """Loads (once) and returns the ctypes handle; raises if the library has not been built."""
     global _lib
     if _lib is None:
+        # torch must load ITS libamdhip64 first: liblsps_hip.so then binds to the same HIP runtime
+        # (two runtimes in one process => "no ROCm-capable device" on the second one).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise LspsHipError("liblsps_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`"
                                % LIB_PATH)

@@ -668,6 +668,7 @@ size_t lsps_conv2d_workspace_bytes(int N, int C, int H, int W, int K, int R, int
 
 int lsps_conv2d_fwd(const float *x, const float *w, const float *bias, float *y, int N, int C, int H, int W, int K,
                     int R, int S, int stride, int pad, int act, float slope, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(x && w && y && ws, "conv2d_fwd: null pointer");
   LSPS_CHECK_ARG(conv_args_ok(N, C, H, W, K, R, S, stride, pad), "conv2d_fwd: unsupported geometry");
   const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
@@ -678,6 +679,7 @@ int lsps_conv2d_fwd(const float *x, const float *w, const float *bias, float *y,
 
 int lsps_conv2d_dgrad(const float *dy, const float *w, float *dx, int N, int C, int H, int W, int K, int R, int S,
                       int stride, int pad, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(dy && w && dx && ws, "conv2d_dgrad: null pointer");
   LSPS_CHECK_ARG(conv_args_ok(N, C, H, W, K, R, S, stride, pad), "conv2d_dgrad: unsupported geometry");
   const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
@@ -688,6 +690,7 @@ int lsps_conv2d_dgrad(const float *dy, const float *w, float *dx, int N, int C, 
 
 int lsps_conv2d_wgrad(const float *x, const float *dy, float *dw, float *db, int N, int C, int H, int W, int K, int R,
                       int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(x && dy && dw && ws, "conv2d_wgrad: null pointer");
   LSPS_CHECK_ARG(conv_args_ok(N, C, H, W, K, R, S, stride, pad), "conv2d_wgrad: unsupported geometry");
   const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
@@ -707,6 +710,7 @@ size_t lsps_convT2d_workspace_bytes(int N, int Ci, int H, int W, int Co, int R, 
 int lsps_convT2d_fwd(const float *x, const float *w, const float *bias, float *y, int N, int Ci, int H, int W, int Co,
                      int R, int S, int stride, int pad, int outpad, int act, float slope, void *ws, size_t ws_bytes,
                      void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(x && w && y && ws, "convT2d_fwd: null pointer");
   LSPS_CHECK_ARG(conv_args_ok(N, Ci, H, W, Co, R, S, stride, pad) && outpad >= 0 && (outpad == 0 || outpad < stride),
                  "convT2d_fwd: unsupported geometry");
@@ -719,6 +723,7 @@ int lsps_convT2d_fwd(const float *x, const float *w, const float *bias, float *y
 
 int lsps_convT2d_dgrad(const float *dy, const float *w, float *dx, int N, int Ci, int H, int W, int Co, int R, int S,
                        int stride, int pad, int outpad, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(dy && w && dx && ws, "convT2d_dgrad: null pointer");
   LSPS_CHECK_ARG(conv_args_ok(N, Ci, H, W, Co, R, S, stride, pad), "convT2d_dgrad: unsupported geometry");
   const int Ho = (H - 1) * stride - 2 * pad + R + outpad, Wo = (W - 1) * stride - 2 * pad + S + outpad;
@@ -729,6 +734,7 @@ int lsps_convT2d_dgrad(const float *dy, const float *w, float *dx, int N, int Ci
 
 int lsps_convT2d_wgrad(const float *x, const float *dy, float *dw, float *db, int N, int Ci, int H, int W, int Co,
                        int R, int S, int stride, int pad, int outpad, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(x && dy && dw && ws, "convT2d_wgrad: null pointer");
   LSPS_CHECK_ARG(conv_args_ok(N, Ci, H, W, Co, R, S, stride, pad), "convT2d_wgrad: unsupported geometry");
   const int Ho = (H - 1) * stride - 2 * pad + R + outpad, Wo = (W - 1) * stride - 2 * pad + S + outpad;

@@ -136,6 +136,7 @@ size_t lsps_loss_workspace_bytes(long n) {
 
 int lsps_loss_fwd(int kind, const float *a, const float *b, long n, float denom, float *out, void *ws, size_t ws_bytes,
                   void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(a && out && ws && n > 0 && denom != 0.f, "loss_fwd: bad argument");
   LSPS_CHECK_ARG(kind >= LSPS_LOSS_L1 && kind <= LSPS_LOSS_KLSD, "loss_fwd: unknown kind");
   LSPS_CHECK_ARG(kind != LSPS_LOSS_KLSD || b, "loss_fwd: KLSD needs sd");
@@ -154,6 +155,7 @@ int lsps_loss_fwd(int kind, const float *a, const float *b, long n, float denom,
 
 int lsps_loss_bwd(int kind, const float *a, const float *b, long n, float denom, const float *gout, float *da,
                   float *db, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(a && gout && da && n > 0 && denom != 0.f, "loss_bwd: bad argument");
   LSPS_CHECK_ARG(kind >= LSPS_LOSS_L1 && kind <= LSPS_LOSS_KLSD, "loss_bwd: unknown kind");
   long blocks = (n + 255) / 256;
@@ -166,6 +168,7 @@ int lsps_loss_bwd(int kind, const float *a, const float *b, long n, float denom,
 
 int lsps_bce_sigmoid_fwd(const float *logits, long n, float target, float *out3, void *ws, size_t ws_bytes,
                          void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(logits && out3 && ws && n > 0, "bce_fwd: bad argument");
   if (ws_bytes < lsps_loss_workspace_bytes(n)) {
     set_error("bce_fwd: workspace too small");
@@ -182,6 +185,7 @@ int lsps_bce_sigmoid_fwd(const float *logits, long n, float target, float *out3,
 }
 
 int lsps_bce_sigmoid_bwd(const float *logits, long n, float target, const float *gout, float *dlogits, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(logits && gout && dlogits && n > 0, "bce_bwd: bad argument");
   long nb = (n + 255) / 256;
   if (nb > 4096) nb = 4096;

@@ -100,6 +100,7 @@ extern "C" {
 
 int lsps_linear_fwd(const float *x, const float *w, const float *b, float *y, int n, int in, int out, int act,
                     float slope, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(x && w && y && n > 0 && in > 0 && out > 0, "linear_fwd: bad argument");
   const long total = (long)n * out;
   hipLaunchKernelGGL(linear_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, n, in,
@@ -110,6 +111,7 @@ int lsps_linear_fwd(const float *x, const float *w, const float *b, float *y, in
 
 int lsps_linear_bwd(const float *x, const float *w, const float *y, const float *dy, float *dx, float *dw, float *db,
                     int n, int in, int out, int act, float slope, float *ws_dz, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(x && w && y && dy && dw && ws_dz && n > 0 && in > 0 && out > 0, "linear_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const long total = (long)n * out;
@@ -129,6 +131,7 @@ int lsps_linear_bwd(const float *x, const float *w, const float *y, const float 
 int lsps_adam_step(float *p, const float *g, float *m, float *v, const long *seg_off, const int *seg_len,
                    const float *seg_bc1, const float *seg_bc2s, int nseg, int max_seg_len, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float gscale, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(p && g && m && v && seg_off && seg_len && seg_bc1 && seg_bc2s && nseg > 0 && max_seg_len > 0,
                  "adam_step: bad argument");
   LSPS_CHECK_ARG(nseg <= 65535, "adam_step: too many segments");

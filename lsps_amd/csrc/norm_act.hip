@@ -216,6 +216,7 @@ extern "C" {
 
 int lsps_inorm_fwd(const float *y, const float *residual, float *out, float *rstd, int planes, int hw, float eps,
                    float slope, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(y && out && rstd && planes > 0 && hw > 0, "inorm_fwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const bool al = (((uintptr_t)y | (uintptr_t)out | (uintptr_t)residual) & 15) == 0;
@@ -231,6 +232,7 @@ int lsps_inorm_fwd(const float *y, const float *residual, float *out, float *rst
 
 int lsps_inorm_bwd(const float *dout, const float *out, const float *residual, const float *rstd, float *dy, int planes,
                    int hw, float slope, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(dout && out && rstd && dy && planes > 0 && hw > 0, "inorm_bwd: bad argument");
   LSPS_CHECK_ARG(!(slope == 0.f), "inorm_bwd: slope 0 (ReLU) cannot be inverted from the output");
   hipStream_t st = (hipStream_t)stream;
@@ -246,6 +248,7 @@ int lsps_inorm_bwd(const float *dout, const float *out, const float *residual, c
 }
 
 int lsps_act_bwd(const float *dy, const float *out, float *dx, long n, int kind, float slope, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(dy && out && dx && n >= 0, "act_bwd: bad argument");
   LSPS_CHECK_ARG(kind == LSPS_ACT_LRELU || kind == LSPS_ACT_TANH, "act_bwd: unknown activation");
   LSPS_CHECK_ARG((((uintptr_t)dy | (uintptr_t)out | (uintptr_t)dx) & 15) == 0, "act_bwd: pointers must be 16-byte aligned");
@@ -256,6 +259,7 @@ int lsps_act_bwd(const float *dy, const float *out, float *dx, long n, int kind,
 }
 
 int lsps_axpy(const float *x, const float *y, float alpha, float *out, long n, void *stream) {
+  (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(x && y && out && n >= 0, "axpy: bad argument");
   LSPS_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)out) & 15) == 0, "axpy: pointers must be 16-byte aligned");
   if (n == 0) return 0;

@@ -17,6 +17,61 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class _Span(object):
+    def __init__(self, prof, key, flops, launches):
+        self.prof, self.key, self.flops, self.launches = prof, key, flops, launches
+
+    def __enter__(self):
+        if self.prof.enabled:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()            # torch's current stream == the stream the kernels are launched on
+
+    def __exit__(self, *a):
+        if self.prof.enabled:
+            self.e1.record()
+            self.prof.records.append((self.key, self.e0, self.e1, self.flops, self.launches))
+
+
+class Profiler(object):
+    """HIP-event timing of the conv kernels inside a timed region (bench.py `roofline`).  A span brackets
+    one C-ABI conv call on the launch stream; `flops` are ALGORITHMIC (2*N*K*P*Q*C*R*S)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def reset(self):
+        self.records = []
+
+    @staticmethod
+    def f_kernel(M):
+        return 'igemm_f<128x128>' if M >= 128 else ('igemm_f<64x256>' if M >= 64 else 'igemm_f<32x256>')
+
+    def span(self, key, flops, launches):
+        return _Span(self, key, flops, launches)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, e0, e1, flops, launches in self.records:
+            a = agg.setdefault(key, dict(calls=0, launches=0, total_ms=0.0, flop=0.0))
+            a['calls'] += 1
+            a['launches'] += launches
+            a['total_ms'] += e0.elapsed_time(e1)
+            a['flop'] += flops
+        out = {}
+        for key, a in agg.items():
+            out[key] = dict(calls=a['calls'], launches=a['launches'], total_ms=a['total_ms'],
+                            avg_ms=a['total_ms'] / max(a['launches'], 1),
+                            gflop_per_launch=a['flop'] / max(a['launches'], 1) / 1e9,
+                            tflops=a['flop'] / max(a['total_ms'], 1e-9) / 1e9)
+        return out
+
+
+profiler = Profiler()
+
+
 def conv_out_size(h, r, stride, pad):
     return (h + 2 * pad - r) // stride + 1
 
@@ -41,8 +96,9 @@ class _Conv2dFn(torch.autograd.Function):
         P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
         y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
         ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, R, S, stride, pad), x.device)
-        _lib.check(L.lsps_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, C, H, W, K, R, S,
-                                     stride, pad, act, slope, ws, wsb, _lib.stream()), 'conv2d_fwd')
+        with profiler.span(Profiler.f_kernel(K), 2.0 * N * K * P * Q * C * R * S, 1):
+            _lib.check(L.lsps_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, C, H, W, K, R, S,
+                                         stride, pad, act, slope, ws, wsb, _lib.stream()), 'conv2d_fwd')
         ctx.geom = (N, C, H, W, K, R, S, stride, pad, act, slope)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
@@ -55,6 +111,7 @@ class _Conv2dFn(torch.autograd.Function):
         N, C, H, W, K, R, S, stride, pad, act, slope = ctx.geom
         dy = _c(dy)
         st = _lib.stream()
+        flops = 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S
         if act != ACT_NONE:
             dpre = torch.empty_like(dy)
             _lib.check(L.lsps_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dpre), dy.numel(), act, slope, st), 'act_bwd')
@@ -63,14 +120,16 @@ class _Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.check(L.lsps_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, C, H, W, K, R, S, stride, pad,
-                                           ws, wsb, st), 'conv2d_dgrad')
+            with profiler.span(Profiler.f_kernel(C), flops, stride * stride):
+                _lib.check(L.lsps_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, C, H, W, K, R, S, stride,
+                                               pad, ws, wsb, st), 'conv2d_dgrad')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = torch.empty(K, dtype=torch.float32, device=x.device)
-            _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), N, C, H, W, K, R, S,
-                                           stride, pad, ws, wsb, st), 'conv2d_wgrad')
+            with profiler.span('igemm_w<128x128x64>', flops, 1):
+                _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), N, C, H, W, K, R,
+                                               S, stride, pad, ws, wsb, st), 'conv2d_wgrad')
         return dx, dw, db, None, None, None, None
 
 
@@ -94,8 +153,9 @@ class _ConvT2dFn(torch.autograd.Function):
         Ho, Wo = convT_out_size(H, R, stride, pad, outpad), convT_out_size(W, S, stride, pad, outpad)
         y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
         ws, wsb = _lib.workspace(L.lsps_convT2d_workspace_bytes(N, Ci, H, W, Co, R, S, stride, pad, outpad), x.device)
-        _lib.check(L.lsps_convT2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, Ci, H, W, Co, R, S,
-                                      stride, pad, outpad, act, slope, ws, wsb, _lib.stream()), 'convT2d_fwd')
+        with profiler.span(Profiler.f_kernel(Co), 2.0 * N * Ci * H * W * Co * R * S, stride * stride):
+            _lib.check(L.lsps_convT2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, Ci, H, W, Co, R, S,
+                                          stride, pad, outpad, act, slope, ws, wsb, _lib.stream()), 'convT2d_fwd')
         ctx.geom = (N, Ci, H, W, Co, R, S, stride, pad, outpad, act, slope)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
@@ -108,6 +168,7 @@ class _ConvT2dFn(torch.autograd.Function):
         N, Ci, H, W, Co, R, S, stride, pad, outpad, act, slope = ctx.geom
         dy = _c(dy)
         st = _lib.stream()
+        flops = 2.0 * N * Ci * H * W * Co * R * S
         if act != ACT_NONE:
             dpre = torch.empty_like(dy)
             _lib.check(L.lsps_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dpre), dy.numel(), act, slope, st), 'act_bwd')
@@ -116,14 +177,16 @@ class _ConvT2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.check(L.lsps_convT2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, Ci, H, W, Co, R, S, stride,
-                                            pad, outpad, ws, wsb, st), 'convT2d_dgrad')
+            with profiler.span(Profiler.f_kernel(Ci), flops, 1):
+                _lib.check(L.lsps_convT2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, Ci, H, W, Co, R, S, stride,
+                                                pad, outpad, ws, wsb, st), 'convT2d_dgrad')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = torch.empty(Co, dtype=torch.float32, device=x.device)
-            _lib.check(L.lsps_convT2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), N, Ci, H, W, Co, R,
-                                            S, stride, pad, outpad, ws, wsb, st), 'convT2d_wgrad')
+            with profiler.span('igemm_w<128x128x64>', flops, 1):
+                _lib.check(L.lsps_convT2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), N, Ci, H, W, Co,
+                                                R, S, stride, pad, outpad, ws, wsb, st), 'convT2d_wgrad')
         return dx, dw, db, None, None, None, None, None
 
 
