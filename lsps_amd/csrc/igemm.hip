@@ -37,6 +37,7 @@ void set_error(const char *fmt, ...) {
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 struct defeats SROA (scratch)
 
 #define LSPS_MAXT 49
 #define BK_F 32   // reduction chunk of the F kernel
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackParams p) {
 // F kernel
 // -------------------------------------------------------------------------------------------
 template <int WM, int WN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void igemm_f_kernel(FParams p) {
+__global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
   constexpr int BM = WM * 32 * WAVES_M, BN = WN * 32 * WAVES_N, BK = BK_F;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(BN == 128 || BN == 256, "pixel tile");
@@ -157,59 +158,65 @@ __global__ __launch_bounds__(256) void igemm_f_kernel(FParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float breg[NB];
-  float4 areg[A4];
+  f32x4 areg[A4];
   const int T = p.taps.T;
-
-  auto prefetch = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < A4; ++i) {
-      const int u = tid + 256 * i;
-      const int row = u / (BM / 4), c4 = u % (BM / 4);
-      areg[i] = *reinterpret_cast<const float4 *>(p.Wp + (long)(k0 + row) * p.Mp + m0 + c4 * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int red = __builtin_amdgcn_readfirstlane(k0 + rbase + RSTEP * i);
-      const int c = (T == 1) ? red : (int)__umulhi((unsigned)red, p.magicT);
-      const int t = red - c * T;
-      const bool ok = (c < p.Cx) && ((mask >> t) & 1ull);
-      const int off = c * p.HxWx + p.taps.toff[t];
-      breg[i] = ok ? xb[off] : 0.f;
-    }
-  };
-
   const int nchunks = p.REDp / BK;
-  if (nchunks > 0) prefetch(0);
-
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, half = lane >> 5;
 
-  for (int ch = 0; ch < nchunks; ++ch) {
-    __syncthreads();
+  // Software pipeline, one copy of each phase: iteration `ch` first moves the registers prefetched for
+  // chunk ch into LDS, then issues the global loads of chunk ch+1 (in flight during the MFMA chain), then
+  // runs the MFMA chain of chunk ch.
+  for (int ch = -1; ch < nchunks; ++ch) {
+    if (ch >= 0) {
+      __syncthreads();
 #pragma unroll
-    for (int i = 0; i < A4; ++i) {
-      const int u = tid + 256 * i;
-      const int row = u / (BM / 4), c4 = u % (BM / 4);
-      *reinterpret_cast<float4 *>(As + row * BM + c4 * 4) = areg[i];
+      for (int i = 0; i < A4; ++i) {
+        const int u = tid + 256 * i;
+        const int row = u / (BM / 4), c4 = u % (BM / 4);
+        *reinterpret_cast<f32x4 *>(As + row * BM + c4 * 4) = areg[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) Bs[(rbase + RSTEP * i) * BN + pcol] = breg[i];
+      __syncthreads();
     }
+    if (ch + 1 < nchunks) {
+      const int k0 = (ch + 1) * BK;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) Bs[(rbase + RSTEP * i) * BN + pcol] = breg[i];
-    __syncthreads();
-    if (ch + 1 < nchunks) prefetch((ch + 1) * BK);
-
-#pragma unroll 4
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[WM], b[WN];
-      const int row = 2 * kk + half;
+      for (int i = 0; i < A4; ++i) {
+        const int u = tid + 256 * i;
+        const int row = u / (BM / 4), c4 = u % (BM / 4);
+        areg[i] = *reinterpret_cast<const f32x4 *>(p.Wp + (long)(k0 + row) * p.Mp + m0 + c4 * 4);
+      }
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = As[row * BM + (wm * WM + i) * 32 + l31];
+      for (int i = 0; i < NB; ++i) {
+        const int red = __builtin_amdgcn_readfirstlane(k0 + rbase + RSTEP * i);
+        const int c = (T == 1) ? red : (int)__umulhi((unsigned)red, p.magicT);
+        const int t = red - c * T;                     // < T <= 49: always a valid table index
+        const bool ok = (c < p.Cx) && ((mask >> t) & 1ull);
+        // Unconditional load from an always-valid address + select: a predicated load would make hipcc
+        // branch around every gather and serialise them behind per-load waits.
+        const int off = ok ? (c * p.HxWx + p.taps.toff[t]) : 0;
+        const float *src = ok ? (xb + off) : p.X;
+        const float v = *src;
+        breg[i] = ok ? v : 0.f;
+      }
+    }
+    if (ch >= 0) {
+#pragma unroll 8
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float a[WM], b[WN];
+        const int row = 2 * kk + half;
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = Bs[row * BN + (wn * WN + j) * 32 + l31];
+        for (int i = 0; i < WM; ++i) a[i] = As[row * BM + (wm * WM + i) * 32 + l31];
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+        for (int j = 0; j < WN; ++j) b[j] = Bs[row * BN + (wn * WN + j) * 32 + l31];
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
     }
   }
 
@@ -263,67 +270,72 @@ __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float areg[32], breg[32];
-
-  auto prefetch = [&](int ch) {
-    const long q = (long)ch * BK + lane;          // this lane's pixel of the chunk
-    const bool pv = q < p.NPIX;
-    int n = 0, ph = 0, pw = 0, pp = 0;
-    if (pv) {
-      n = (int)(q / p.P);
-      pp = (int)(q - (long)n * p.P);
-      ph = pp / p.PW;
-      pw = pp - ph * p.PW;
-    }
-    const int ih0 = ph * p.ist, iw0 = pw * p.ist;
-    unsigned long long mask = 0ull;
-    for (int t = 0; t < T; ++t) {
-      const int ih = ih0 + p.taps.dh[t], iw = iw0 + p.taps.dw[t];
-      if (pv && ih >= 0 && ih < p.Hx && iw >= 0 && iw < p.Wx) mask |= (1ull << t);
-    }
-    const float *sb = p.Small + (long)n * p.M * p.P + pp;
-    const float *xb = p.Big + ((long)n * p.Cx * p.Hx + ih0) * p.Wx + iw0;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int m = m0 + wave + 4 * i;            // wave-uniform row
-      areg[i] = (pv && m < p.M) ? sb[(long)m * p.P] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int j = __builtin_amdgcn_readfirstlane(j0 + wave + 4 * i);
-      const int c = (T == 1) ? j : (int)__umulhi((unsigned)j, p.magicT);
-      const int t = j - c * T;
-      const bool ok = (j < p.J) && ((mask >> t) & 1ull);
-      const int off = c * p.HxWx + p.taps.toff[t];
-      breg[i] = ok ? xb[off] : 0.f;
-    }
-  };
-
-  if (ch_begin < ch_end) prefetch(ch_begin);
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
 
-  for (int ch = ch_begin; ch < ch_end; ++ch) {
-    __syncthreads();
+  for (int ch = ch_begin - 1; ch < ch_end; ++ch) {
+    if (ch >= ch_begin) {
+      __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      As[(wave + 4 * i) * LDW + lane] = areg[i];
-      Bs[(wave + 4 * i) * LDW + lane] = breg[i];
+      for (int i = 0; i < 32; ++i) {
+        As[(wave + 4 * i) * LDW + lane] = areg[i];
+        Bs[(wave + 4 * i) * LDW + lane] = breg[i];
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    if (ch + 1 < ch_end) prefetch(ch + 1);
-#pragma unroll 4
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[2], b[2];
-      const int col = 2 * kk + half;
+    if (ch + 1 < ch_end) {
+      const long q = (long)(ch + 1) * BK + lane;    // this lane's pixel of the chunk
+      const bool pv = q < p.NPIX;
+      int n = 0, ph = 0, pw = 0, pp = 0;
+      if (pv) {
+        n = (int)(q / p.P);
+        pp = (int)(q - (long)n * p.P);
+        ph = pp / p.PW;
+        pw = pp - ph * p.PW;
+      }
+      const int ih0 = ph * p.ist, iw0 = pw * p.ist;
+      unsigned long long mask = 0ull;
+      for (int t = 0; t < T; ++t) {
+        const int ih = ih0 + p.taps.dh[t], iw = iw0 + p.taps.dw[t];
+        if (pv && ih >= 0 && ih < p.Hx && iw >= 0 && iw < p.Wx) mask |= (1ull << t);
+      }
+      const float *sb = p.Small + (long)n * p.M * p.P + pp;
+      const float *xb = p.Big + ((long)n * p.Cx * p.Hx + ih0) * p.Wx + iw0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[((wm * 2 + i) * 32 + l31) * LDW + col];
+      for (int i = 0; i < 32; ++i) {
+        const int m = m0 + wave + 4 * i;            // wave-uniform row
+        const bool ok = pv && m < p.M;
+        const float *src = ok ? (sb + (long)m * p.P) : p.Small;   // unconditional load + select (see F kernel)
+        const float v = *src;
+        areg[i] = ok ? v : 0.f;
+      }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[((wn * 2 + j) * 32 + l31) * LDW + col];
+      for (int i = 0; i < 32; ++i) {
+        const int j = __builtin_amdgcn_readfirstlane(j0 + wave + 4 * i);
+        const int c = (T == 1) ? j : (int)__umulhi((unsigned)j, p.magicT);
+        const int t = j - c * T;
+        const bool ok = (j < p.J) && ((mask >> t) & 1ull);
+        const int off = ok ? (c * p.HxWx + p.taps.toff[t]) : 0;
+        const float *src = ok ? (xb + off) : p.Big;
+        const float v = *src;
+        breg[i] = ok ? v : 0.f;
+      }
+    }
+    if (ch >= ch_begin) {
+#pragma unroll 8
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float a[2], b[2];
+        const int col = 2 * kk + half;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) a[i] = As[((wm * 2 + i) * 32 + l31) * LDW + col];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) b[j] = Bs[((wn * 2 + j) * 32 + l31) * LDW + col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
     }
   }
 
@@ -350,17 +362,33 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *part,
   out[i] = s;
 }
 
-// db[c] = sum_{n,p} t[n][c][p] ; one workgroup per channel
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float *t, float *db, int N, int C, int HW) {
+// db[c] = sum_{n,p} t[n][c][p].  Stage 1: grid (C, S): block (c,s) sums slice s of the N*HW elements of
+// channel c into part[c*S+s]; stage 2 (reduce_partials_kernel with n=C... see run_bias_grad) adds the S slices.
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float *__restrict__ t, float *__restrict__ part,
+                                                                int N, int C, int HW, long slice) {
   __shared__ float red[4];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, sidx = blockIdx.y;
+  const long total = (long)N * HW;
+  const long e0 = (long)sidx * slice;
+  long e1 = e0 + slice;
+  if (e1 > total) e1 = total;
   float s = 0.f;
-  for (int n = 0; n < N; ++n) {
-    const float *base = t + ((long)n * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += 256) s += base[i];
+  if ((HW & 3) == 0) {
+    for (long e = e0 + (long)threadIdx.x * 4; e < e1; e += 1024) {
+      const long n = e / HW;
+      const long i = e - n * HW;
+      const float4 v = *reinterpret_cast<const float4 *>(t + (n * C + c) * HW + i);
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+      const long n = e / HW;
+      const long i = e - n * HW;
+      s += t[(n * C + c) * HW + i];
+    }
   }
   s = block_sum_256(s, red);
-  if (threadIdx.x == 0) db[c] = s;
+  if (threadIdx.x == 0) part[(long)sidx * C + c] = s;   // layout [S][C] so that reduce_partials sums over S
 }
 
 // -------------------------------------------------------------------------------------------
@@ -560,8 +588,9 @@ static int run_transposed_dir(const float *in, const float *W, const float *bias
 }
 
 static int wgrad_splits(int M, int J, int nchunks) {
+  // the W kernel runs 2 workgroups per CU (LDS-bound): aim at just under two full rounds of 256 CUs x 2
   const long tiles = (long)ceil_div(M, 128) * ceil_div(J, 128);
-  long s = (1024 + tiles - 1) / tiles;
+  long s = 1024 / tiles;
   if (s > 64) s = 64;
   if (s > nchunks) s = nchunks;
   if (s < 1) s = 1;
@@ -621,9 +650,27 @@ static int run_wgrad(const float *small, const float *big, float *dW, int N, int
   return 0;
 }
 
-static int run_bias_grad(const float *t, float *db, int N, int C, int HW, hipStream_t st) {
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, st, t, db, N, C, HW);
-  LSPS_CHECK_LAUNCH("bias_grad");
+#define BIAS_WS_BYTES ((size_t)1 << 20)   // head of every conv workspace: [S<=64][C<=4096] bias partials
+
+static int run_bias_grad(const float *t, float *db, int N, int C, int HW, void *ws, size_t ws_bytes, hipStream_t st) {
+  const long total = (long)N * HW;
+  long S = (total + 32767) / 32768;           // >= 32 K elements per block
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  if ((size_t)S * C * sizeof(float) > BIAS_WS_BYTES || ws_bytes < BIAS_WS_BYTES) {
+    set_error("bias_grad: workspace too small (C=%d)", C);
+    return LSPS_E_WS;
+  }
+  long slice = (total + S - 1) / S;
+  slice = (slice + 3) / 4 * 4;
+  float *part = (float *)ws;
+  hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(C, (int)S), dim3(256), 0, st, t, S == 1 ? db : part, N, C, HW, slice);
+  LSPS_CHECK_LAUNCH("bias_grad_partial");
+  if (S > 1) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)part, db,
+                       (long)C, (int)S);
+    LSPS_CHECK_LAUNCH("bias_grad_reduce");
+  }
   return 0;
 }
 
@@ -636,7 +683,7 @@ static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int W
   const size_t wg = splits > 1 ? (size_t)splits * Cs * J : 0;
   size_t m = fwd > tr ? fwd : tr;
   if (wg > m) m = wg;
-  return m * sizeof(float) + 256;
+  return BIAS_WS_BYTES + m * sizeof(float) + 256;
 }
 
 static bool conv_args_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
@@ -694,9 +741,11 @@ int lsps_conv2d_wgrad(const float *x, const float *dy, float *dw, float *db, int
   LSPS_CHECK_ARG(x && dy && dw && ws, "conv2d_wgrad: null pointer");
   LSPS_CHECK_ARG(conv_args_ok(N, C, H, W, K, R, S, stride, pad), "conv2d_wgrad: unsupported geometry");
   const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
-  int rc = run_wgrad(dy, x, dw, N, C, H, W, K, P, Q, R, S, stride, pad, ws, ws_bytes, (hipStream_t)stream);
+  LSPS_CHECK_ARG(ws_bytes >= BIAS_WS_BYTES, "conv2d_wgrad: workspace too small");
+  int rc = run_wgrad(dy, x, dw, N, C, H, W, K, P, Q, R, S, stride, pad, (char *)ws + BIAS_WS_BYTES,
+                     ws_bytes - BIAS_WS_BYTES, (hipStream_t)stream);
   if (rc) return rc;
-  if (db) return run_bias_grad(dy, db, N, K, P * Q, (hipStream_t)stream);
+  if (db) return run_bias_grad(dy, db, N, K, P * Q, ws, ws_bytes, (hipStream_t)stream);
   return 0;
 }
 
@@ -738,9 +787,11 @@ int lsps_convT2d_wgrad(const float *x, const float *dy, float *dw, float *db, in
   LSPS_CHECK_ARG(x && dy && dw && ws, "convT2d_wgrad: null pointer");
   LSPS_CHECK_ARG(conv_args_ok(N, Ci, H, W, Co, R, S, stride, pad), "convT2d_wgrad: unsupported geometry");
   const int Ho = (H - 1) * stride - 2 * pad + R + outpad, Wo = (W - 1) * stride - 2 * pad + S + outpad;
-  int rc = run_wgrad(x, dy, dw, N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad, ws, ws_bytes, (hipStream_t)stream);
+  LSPS_CHECK_ARG(ws_bytes >= BIAS_WS_BYTES, "convT2d_wgrad: workspace too small");
+  int rc = run_wgrad(x, dy, dw, N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad, (char *)ws + BIAS_WS_BYTES,
+                     ws_bytes - BIAS_WS_BYTES, (hipStream_t)stream);
   if (rc) return rc;
-  if (db) return run_bias_grad(dy, db, N, Co, Ho * Wo, (hipStream_t)stream);
+  if (db) return run_bias_grad(dy, db, N, Co, Ho * Wo, ws, ws_bytes, (hipStream_t)stream);
   return 0;
 }
 
