@@ -588,10 +588,13 @@ static int run_transposed_dir(const float *in, const float *W, const float *bias
 }
 
 static int wgrad_splits(int M, int J, int nchunks) {
-  // the W kernel runs 2 workgroups per CU (LDS-bound): aim at just under two full rounds of 256 CUs x 2
+  // The W kernel runs 2 workgroups per CU (LDS-bound): aim at just under two full rounds of 256 CUs x 2.
+  // Few-tile problems (7x7 stem: 64x49 outputs; 1x1 head) get up to 1024 pixel splits so that the whole chip
+  // streams the activations; the partial buffer is capped at 256 MiB.
   const long tiles = (long)ceil_div(M, 128) * ceil_div(J, 128);
   long s = 1024 / tiles;
-  if (s > 64) s = 64;
+  const long cap = ((long)256 << 20) / ((long)M * J * 4);
+  if (s > cap) s = cap;
   if (s > nchunks) s = nchunks;
   if (s < 1) s = 1;
   return (int)s;
