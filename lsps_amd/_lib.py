@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'liblsps_hip.so')
+LIB_PATH = os.environ.get('LSPS_HIP_LIB', os.path.join(_HERE, 'liblsps_hip.so'))   # override: kernel A/B experiments
 
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2, 3
 LOSS_L1, LOSS_L2, LOSS_SQ, LOSS_KLSD = 0, 1, 2, 3

@@ -53,6 +53,8 @@ struct Taps {
 struct FParams {
   const float *X, *Wp, *bias;
   float *Y;
+  const int2 *gtab;              // [REDp] (element offset c*HxWx + toff[t], tap index t; t = 63 for padding rows)
+  const float *zero;             // >= 1 float of zeros: where masked-out gathers read from
   int Cx, Hx, Wx, HxWx;          // gather source [N][Cx][Hx][Wx]
   int PH, PW, P, NPIX;           // output pixel lattice per sample, P = PH*PW, NPIX = N*P
   int ist;                       // input step per lattice step
@@ -67,6 +69,8 @@ struct FParams {
 struct WParams {
   const float *Small, *Big;
   float *part;                   // [splits][M][J]
+  const int2 *jtab;              // [Jp = J rounded up to 128] (offset, tap) per column j = (c,t); tap 63 = padding
+  const float *zero;
   int Cx, Hx, Wx, HxWx;          // Big = [N][Cx][Hx][Wx]
   int PH, PW, P, NPIX;           // Small = [N][M][PH][PW]
   int ist;
@@ -85,27 +89,52 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 // -------------------------------------------------------------------------------------------
 // weight packing: Wp[red=(c,t)][m] = W[m*sm + c*sc + tapidx[t]], zero padded to [REDp][Mp]
 // -------------------------------------------------------------------------------------------
+#define ZERO_SLOT_FLOATS 64
 struct PackParams {
   const float *W;
-  float *Wp;
-  int M, Mp, RED, REDp, T;
+  float *Wp;                     // [REDp][Mp] followed by ZERO_SLOT_FLOATS zeros
+  int2 *gtab;                    // [REDp]
+  int M, Mp, RED, REDp, T, HxWx;
   unsigned magicT;
   long sm, sc;
   int tapidx[LSPS_MAXT];
+  int toff[LSPS_MAXT];
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(PackParams p) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const long total = (long)p.REDp * p.Mp;
-  if (idx >= total) return;
+  if (idx >= total + ZERO_SLOT_FLOATS) return;
+  if (idx >= total) {
+    p.Wp[idx] = 0.f;
+    return;
+  }
   const int red = (int)(idx / p.Mp), m = (int)(idx - (long)red * p.Mp);
   float v = 0.f;
-  if (red < p.RED && m < p.M) {
+  int2 g = make_int2(0, 63);
+  if (red < p.RED) {
     const int c = (p.T == 1) ? red : (int)__umulhi((unsigned)red, p.magicT);
     const int t = red - c * p.T;
-    v = p.W[(long)m * p.sm + (long)c * p.sc + p.tapidx[t]];
+    if (m < p.M) v = p.W[(long)m * p.sm + (long)c * p.sc + p.tapidx[t]];
+    g = make_int2(c * p.HxWx + p.toff[t], t);
   }
   p.Wp[idx] = v;
+  if (m == 0) p.gtab[red] = g;
+}
+
+// column table of the W kernel: j = (c,t) -> (offset, tap); also zeroes the slot masked gathers read
+__global__ __launch_bounds__(256) void build_jtab_kernel(int2 *jtab, float *zero, int J, int Jp, int T, unsigned magicT,
+                                                         int HxWx, Taps taps) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < ZERO_SLOT_FLOATS) zero[j] = 0.f;
+  if (j >= Jp) return;
+  int2 g = make_int2(0, 63);
+  if (j < J) {
+    const int c = (T == 1) ? j : (int)__umulhi((unsigned)j, magicT);
+    const int t = j - c * T;
+    g = make_int2(c * HxWx + taps.toff[t], t);
+  }
+  jtab[j] = g;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -117,17 +146,30 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(BN == 128 || BN == 256, "pixel tile");
   constexpr int PIXW = BN / 64;        // waves side by side along the pixel tile
-  constexpr int RSTEP = 4 / PIXW;      // reduction rows covered per pass of the 4 waves
-  constexpr int NB = BK / RSTEP;       // B gathers per thread per chunk
+  constexpr int RGROUPS = 4 / PIXW;    // wave groups stacked along the reduction rows
+  constexpr int NB = BK / RGROUPS;     // B gathers per thread per chunk: rows rbase*NB .. rbase*NB+NB-1
   constexpr int A4 = BK * BM / 4 / 256;
   static_assert(A4 >= 1, "A tile");
 
-  __shared__ __attribute__((aligned(16))) float lds[BK * BM + BK * BN];
+#ifndef LSPS_F_LDS_PAD
+#define LSPS_F_LDS_PAD 0
+#endif
+  __shared__ __attribute__((aligned(16))) float lds[BK * BM + BK * BN + LSPS_F_LDS_PAD];
   float *As = lds, *Bs = lds + BK * BM;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.y * BM;
+#ifdef LSPS_STAGGER_PRIO
+  // Workgroups sharing a CU otherwise march in lock-step (fair MFMA arbitration) and hit their
+  // load/store phases together; distinct static priorities order them so phases interleave.
+  switch ((blockIdx.x >> 3) & 3) {
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: break;
+  }
+#endif
 
   // ---- this thread's gather pixel (one column of the B tile)
   const int pcol = (wave % PIXW) * 64 + lane;
@@ -159,7 +201,6 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
 
   float breg[NB];
   f32x4 areg[A4];
-  const int T = p.taps.T;
   const int nchunks = p.REDp / BK;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, half = lane >> 5;
@@ -167,6 +208,8 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
   // Software pipeline, one copy of each phase: iteration `ch` first moves the registers prefetched for
   // chunk ch into LDS, then issues the global loads of chunk ch+1 (in flight during the MFMA chain), then
   // runs the MFMA chain of chunk ch.
+  int2 tabv = make_int2(0, 63);
+  if (nchunks > 0) tabv = p.gtab[rbase * NB + (lane & (NB - 1))];
   for (int ch = -1; ch < nchunks; ++ch) {
     if (ch >= 0) {
       __syncthreads();
@@ -177,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
         *reinterpret_cast<f32x4 *>(As + row * BM + c4 * 4) = areg[i];
       }
 #pragma unroll
-      for (int i = 0; i < NB; ++i) Bs[(rbase + RSTEP * i) * BN + pcol] = breg[i];
+      for (int i = 0; i < NB; ++i) Bs[(rbase * NB + i) * BN + pcol] = breg[i];
       __syncthreads();
     }
     if (ch + 1 < nchunks) {
@@ -188,20 +231,62 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
         const int row = u / (BM / 4), c4 = u % (BM / 4);
         areg[i] = *reinterpret_cast<const f32x4 *>(p.Wp + (long)(k0 + row) * p.Mp + m0 + c4 * 4);
       }
+      // The NB gather-table rows of this wave were fetched one chunk ago by ONE vector load (lane i holds
+      // row i) and are broadcast with v_readlane: no scalar-memory round trip per gather.  Masked-out lanes
+      // read the zero slot: no select after the load, so nothing waits for the gathers until they are stored
+      // to LDS after the MFMA chain.
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int red = __builtin_amdgcn_readfirstlane(k0 + rbase + RSTEP * i);
-        const int c = (T == 1) ? red : (int)__umulhi((unsigned)red, p.magicT);
-        const int t = red - c * T;                     // < T <= 49: always a valid table index
-        const bool ok = (c < p.Cx) && ((mask >> t) & 1ull);
-        // Unconditional load from an always-valid address + select: a predicated load would make hipcc
-        // branch around every gather and serialise them behind per-load waits.
-        const int off = ok ? (c * p.HxWx + p.taps.toff[t]) : 0;
-        const float *src = ok ? (xb + off) : p.X;
-        const float v = *src;
-        breg[i] = ok ? v : 0.f;
+        const int off = __builtin_amdgcn_readlane(tabv.x, i);
+        const int t = __builtin_amdgcn_readlane(tabv.y, i);
+        const bool ok = (mask >> t) & 1ull;
+        const float *src = ok ? (xb + off) : p.zero;
+        breg[i] = *src;
+      }
+      // table rows of the chunk after this one (clamped: the tail read is never used)
+      {
+        int nk = k0 + BK;
+        if (nk >= p.REDp) nk = 0;
+        tabv = p.gtab[nk + rbase * NB + (lane & (NB - 1))];
       }
     }
+#ifdef LSPS_OPERAND_DB   // measured SLOWER (103 -> 79 TFLOP/s on the 3x3 256->256 layer): kept for reference
+    if (ch >= 0) {
+      // MFMA chain with the operands of k-step kk+1 read from LDS BEFORE the MFMAs of k-step kk are issued
+      // (explicit register double buffer): a wave's own ds_read latency hides behind its own 4 MFMAs.
+      const float *Ap = As + half * BM + wm * WM * 32 + l31;
+      const float *Bp = Bs + half * BN + wn * WN * 32 + l31;
+      float a[2][WM], b[2][WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[0][i] = Ap[i * 32];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[0][j] = Bp[j * 32];
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 2) {
+#pragma unroll
+          for (int i = 0; i < WM; ++i) a[nxt][i] = Ap[(2 * kk + 2) * BM + i * 32];
+#pragma unroll
+          for (int j = 0; j < WN; ++j) b[nxt][j] = Bp[(2 * kk + 2) * BN + j * 32];
+        }
+        // Order fence: the LDS reads above may not sink below this point ("memory"), and the MFMAs below
+        // may not hoist above it (their operands pass through it).  hipcc otherwise sinks the reads under
+        // the MFMAs to reuse the operand registers, exposing the LDS latency on every k-step.
+#pragma unroll
+        for (int i = 0; i < WM; ++i) asm volatile("" : "+v"(a[cur][i])::"memory");
+#pragma unroll
+        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(b[cur][j])::"memory");
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+#else
     if (ch >= 0) {
 #pragma unroll 8
       for (int kk = 0; kk < BK / 2; ++kk) {
@@ -220,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
     }
   }
 
+#endif
   // ---- epilogue: lane holds pixel column l31 of each 32x32 tile, rows (r&3)+8*(r>>2)+4*half
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
@@ -272,14 +358,16 @@ __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
   float areg[32], breg[32];
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
+  // this wave's 32 column-table rows (fixed for the whole kernel): lane i holds row i, broadcast by v_readlane
+  const int2 tabv = p.jtab[j0 + wave * 32 + (lane & 31)];
 
   for (int ch = ch_begin - 1; ch < ch_end; ++ch) {
     if (ch >= ch_begin) {
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
-        As[(wave + 4 * i) * LDW + lane] = areg[i];
-        Bs[(wave + 4 * i) * LDW + lane] = breg[i];
+        As[(wave * 32 + i) * LDW + lane] = areg[i];
+        Bs[(wave * 32 + i) * LDW + lane] = breg[i];
       }
       __syncthreads();
     }
@@ -303,24 +391,56 @@ __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
       const float *xb = p.Big + ((long)n * p.Cx * p.Hx + ih0) * p.Wx + iw0;
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
-        const int m = m0 + wave + 4 * i;            // wave-uniform row
+        const int m = m0 + wave * 32 + i;           // wave-uniform row
         const bool ok = pv && m < p.M;
-        const float *src = ok ? (sb + (long)m * p.P) : p.Small;   // unconditional load + select (see F kernel)
-        const float v = *src;
-        areg[i] = ok ? v : 0.f;
+        const float *src = ok ? (sb + (long)m * p.P) : p.zero;   // masked lanes read the zero slot: no select
+        areg[i] = *src;
       }
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
-        const int j = __builtin_amdgcn_readfirstlane(j0 + wave + 4 * i);
-        const int c = (T == 1) ? j : (int)__umulhi((unsigned)j, p.magicT);
-        const int t = j - c * T;
-        const bool ok = (j < p.J) && ((mask >> t) & 1ull);
-        const int off = ok ? (c * p.HxWx + p.taps.toff[t]) : 0;
-        const float *src = ok ? (xb + off) : p.Big;
-        const float v = *src;
-        breg[i] = ok ? v : 0.f;
+        const int off = __builtin_amdgcn_readlane(tabv.x, i);
+        const int t = __builtin_amdgcn_readlane(tabv.y, i);
+        const bool ok = (mask >> t) & 1ull;
+        const float *src = ok ? (xb + off) : p.zero;
+        breg[i] = *src;
       }
     }
+#ifdef LSPS_OPERAND_DB
+    if (ch >= ch_begin) {
+      // same operand double buffering + order fence as the F kernel
+      const float *Ap = As + (wm * 64 + l31) * LDW + half;
+      const float *Bp = Bs + (wn * 64 + l31) * LDW + half;
+      float a[2][2], b[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[0][i] = Ap[i * 32 * LDW];
+        b[0][i] = Bp[i * 32 * LDW];
+      }
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 2) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            a[nxt][i] = Ap[i * 32 * LDW + 2 * kk + 2];
+            b[nxt][i] = Bp[i * 32 * LDW + 2 * kk + 2];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          asm volatile("" : "+v"(a[cur][i])::"memory");
+          asm volatile("" : "+v"(b[cur][i])::"memory");
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+#else
     if (ch >= ch_begin) {
 #pragma unroll 8
       for (int kk = 0; kk < BK / 2; ++kk) {
@@ -339,6 +459,7 @@ __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
     }
   }
 
+#endif
   float *out = p.part + (long)split * p.M * p.J;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -419,12 +540,26 @@ static void fill_taps(Taps &t, const TapList &l, int Wx) {
   }
 }
 
-static int launch_pack(const float *W, float *Wp, int M, int Mp, int RED, int REDp, const TapList &l, long sm, long sc,
-                       hipStream_t st) {
+// workspace carve of one packed class: [gtab: REDp int2][Wp: REDp*Mp floats][zero slot]
+static size_t class_bytes(int REDp, int Mp) {
+  return align_up((size_t)REDp * sizeof(int2), 256) + align_up(((size_t)REDp * Mp + ZERO_SLOT_FLOATS) * sizeof(float), 256);
+}
+
+static int launch_pack(const float *W, void *cls, int M, int Mp, int RED, int REDp, const TapList &l, long sm, long sc,
+                       int HxWx, int Wx, hipStream_t st, const float **Wp_out, const int2 **gtab_out,
+                       const float **zero_out) {
+  int2 *gtab = (int2 *)cls;
+  float *Wp = (float *)((char *)cls + align_up((size_t)REDp * sizeof(int2), 256));
+  *Wp_out = Wp;
+  *gtab_out = gtab;
+  *zero_out = Wp + (size_t)REDp * Mp;
   if (REDp == 0) return 0;
   PackParams pp;
   pp.W = W;
   pp.Wp = Wp;
+  pp.gtab = gtab;
+  pp.HxWx = HxWx;
+  for (int i = 0; i < LSPS_MAXT; ++i) pp.toff[i] = i < l.T ? l.dh[i] * Wx + l.dw[i] : 0;
   pp.M = M;
   pp.Mp = Mp;
   pp.RED = RED;
@@ -434,7 +569,7 @@ static int launch_pack(const float *W, float *Wp, int M, int Mp, int RED, int RE
   pp.sm = sm;
   pp.sc = sc;
   for (int i = 0; i < LSPS_MAXT; ++i) pp.tapidx[i] = i < l.T ? l.idx[i] : 0;
-  const long total = (long)REDp * Mp;
+  const long total = (long)REDp * Mp + ZERO_SLOT_FLOATS;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, pp);
   LSPS_CHECK_LAUNCH("pack_weights");
   return 0;
@@ -454,9 +589,10 @@ static int launch_f(const FParams &p, int cfg, hipStream_t st) {
   return 0;
 }
 
-static size_t packed_floats(int Cin, int taps_total, int classes, int M) {
-  const size_t Mp = align_up((size_t)M, 128);
-  return ((size_t)Cin * taps_total + (size_t)32 * classes) * Mp;
+static size_t packed_bytes(int Cin, int taps_total, int classes, int M) {
+  const int Mp = (int)align_up((size_t)M, 128);
+  // sum over classes of class_bytes(REDp_c, Mp) with sum REDp_c <= Cin*taps_total + 32*classes
+  return class_bytes(Cin * taps_total + 32 * classes, Mp) + (size_t)classes * 1024;
 }
 
 // "forward direction": in = big image [N][Cb][Hb][Wb], out = small image [N][Cs][Hs][Ws]
@@ -475,18 +611,16 @@ static int run_forward_dir(const float *in, const float *W, const float *bias, f
     }
   const int M = Cs, RED = Cb * l.T;
   const int Mp = (int)align_up(M, 128), REDp = (int)align_up(RED, BK_F);
-  const size_t need = (size_t)REDp * Mp * sizeof(float);
+  const size_t need = class_bytes(REDp, Mp);
   if (need > ws_bytes) {
     set_error("conv workspace too small: need %zu, have %zu", need, ws_bytes);
     return LSPS_E_WS;
   }
-  float *Wp = (float *)ws;
-  int rc = launch_pack(W, Wp, M, Mp, RED, REDp, l, sm, sc, st);
-  if (rc) return rc;
   FParams p;
   memset(&p, 0, sizeof(p));
+  int rc = launch_pack(W, ws, M, Mp, RED, REDp, l, sm, sc, Hb * Wb, Wb, st, &p.Wp, &p.gtab, &p.zero);
+  if (rc) return rc;
   p.X = in;
-  p.Wp = Wp;
   p.bias = bias;
   p.Y = out;
   p.Cx = Cb;
@@ -543,19 +677,17 @@ static int run_transposed_dir(const float *in, const float *W, const float *bias
       }
       const int RED = Cs * l.T;
       const int REDp = (int)align_up(RED, BK_F);
-      const size_t need = (size_t)REDp * Mp * sizeof(float);
+      const size_t need = class_bytes(REDp, Mp);
       if (used + need > ws_bytes) {
         set_error("conv workspace too small: need >= %zu, have %zu", used + need, ws_bytes);
         return LSPS_E_WS;
       }
-      float *Wp = (float *)((char *)ws + used);
-      used += need;
-      int rc = launch_pack(W, Wp, M, Mp, RED, REDp, l, sm, sc, st);
-      if (rc) return rc;
       FParams p;
       memset(&p, 0, sizeof(p));
+      int rc = launch_pack(W, (char *)ws + used, M, Mp, RED, REDp, l, sm, sc, Hs * Ws, Ws, st, &p.Wp, &p.gtab, &p.zero);
+      used += need;
+      if (rc) return rc;
       p.X = in;
-      p.Wp = Wp;
       p.bias = bias;
       p.Y = out;
       p.Cx = Cs;
@@ -632,16 +764,21 @@ static int run_wgrad(const float *small, const float *big, float *dW, int N, int
   p.chunks_per_split = ceil_div(p.nchunks, splits);
   fill_taps(p.taps, l, Wb);
   const long nW = (long)p.M * p.J;
-  if (splits > 1) {
-    const size_t need = (size_t)splits * nW * sizeof(float);
-    if (need > ws_bytes) {
-      set_error("wgrad workspace too small: need %zu, have %zu", need, ws_bytes);
-      return LSPS_E_WS;
-    }
-    p.part = (float *)ws;
-  } else {
-    p.part = dW;
+  const int Jp = (int)align_up((size_t)p.J, 128);
+  const size_t head = align_up((size_t)Jp * sizeof(int2), 256) + 256;
+  const size_t need = head + (splits > 1 ? (size_t)splits * nW * sizeof(float) : 0);
+  if (need > ws_bytes) {
+    set_error("wgrad workspace too small: need %zu, have %zu", need, ws_bytes);
+    return LSPS_E_WS;
   }
+  int2 *jtab = (int2 *)ws;
+  float *zero = (float *)((char *)ws + head - 256);
+  hipLaunchKernelGGL(build_jtab_kernel, dim3(ceil_div(Jp, 256)), dim3(256), 0, st, jtab, zero, p.J, Jp, l.T, p.magicT,
+                     Hb * Wb, p.taps);
+  LSPS_CHECK_LAUNCH("build_jtab");
+  p.jtab = jtab;
+  p.zero = zero;
+  p.part = splits > 1 ? (float *)((char *)ws + head) : dW;
   dim3 grid(ceil_div(p.J, 128), ceil_div(p.M, 128), splits);
   hipLaunchKernelGGL(igemm_w_kernel, grid, dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_w");
@@ -678,15 +815,16 @@ static int run_bias_grad(const float *t, float *db, int N, int C, int HW, void *
 }
 
 static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_) {
-  const size_t fwd = packed_floats(Cb, R * S, 1, Cs);
-  const size_t tr = packed_floats(Cs, R * S, st_ * st_, Cb);
+  const size_t fwd = packed_bytes(Cb, R * S, 1, Cs);
+  const size_t tr = packed_bytes(Cs, R * S, st_ * st_, Cb);
   const int J = Cb * R * S;
   const int nchunks = ceil_div((long)N * Hs * Ws, BK_W);
   const int splits = wgrad_splits(Cs, J, nchunks);
-  const size_t wg = splits > 1 ? (size_t)splits * Cs * J : 0;
+  const size_t wg = align_up(align_up((size_t)J, 128) * sizeof(int2), 256) + 256 +
+                    (splits > 1 ? (size_t)splits * Cs * J * sizeof(float) : 0);
   size_t m = fwd > tr ? fwd : tr;
   if (wg > m) m = wg;
-  return BIAS_WS_BYTES + m * sizeof(float) + 256;
+  return BIAS_WS_BYTES + m + 1024;
 }
 
 static bool conv_args_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
