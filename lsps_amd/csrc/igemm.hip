@@ -95,6 +95,7 @@ struct PackParams {
   float *Wp;                     // [REDp][Mp] followed by ZERO_SLOT_FLOATS zeros
   int2 *gtab;                    // [REDp]
   int M, Mp, RED, REDp, T, HxWx;
+  int cc;                        // 0: rows ordered (c,t); >0: rows ordered [c/cc][t][c%cc] (3x3 kernel)
   unsigned magicT;
   long sm, sc;
   int tapidx[LSPS_MAXT];
@@ -113,8 +114,15 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackParams p) {
   float v = 0.f;
   int2 g = make_int2(0, 63);
   if (red < p.RED) {
-    const int c = (p.T == 1) ? red : (int)__umulhi((unsigned)red, p.magicT);
-    const int t = red - c * p.T;
+    int c, t;
+    if (p.cc > 0) {
+      const int chunk = red / (p.T * p.cc), rem = red - chunk * p.T * p.cc;
+      t = rem / p.cc;
+      c = chunk * p.cc + (rem - t * p.cc);
+    } else {
+      c = (p.T == 1) ? red : (int)__umulhi((unsigned)red, p.magicT);
+      t = red - c * p.T;
+    }
     if (m < p.M) v = p.W[(long)m * p.sm + (long)c * p.sc + p.tapidx[t]];
     g = make_int2(c * p.HxWx + p.toff[t], t);
   }
@@ -212,7 +220,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
   if (nchunks > 0) tabv = p.gtab[rbase * NB + (lane & (NB - 1))];
   for (int ch = -1; ch < nchunks; ++ch) {
     if (ch >= 0) {
+#ifndef LSPS_ABL_NOBAR
       __syncthreads();
+#endif
+#ifndef LSPS_ABL_NOSTORE
 #pragma unroll
       for (int i = 0; i < A4; ++i) {
         const int u = tid + 256 * i;
@@ -221,9 +232,22 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) Bs[(rbase * NB + i) * BN + pcol] = breg[i];
+#endif
+#ifndef LSPS_ABL_NOBAR
       __syncthreads();
+#endif
     }
+#ifdef LSPS_ABL_NOLOAD
     if (ch + 1 < nchunks) {
+#pragma unroll
+      for (int i = 0; i < A4; ++i) areg[i] = (f32x4){1.f, 2.f, 3.f, (float)ch};
+#pragma unroll
+      for (int i = 0; i < NB; ++i) breg[i] = (float)(ch + i);
+    }
+    if (false) {
+#else
+    if (ch + 1 < nchunks) {
+#endif
       const int k0 = (ch + 1) * BK;
 #pragma unroll
       for (int i = 0; i < A4; ++i) {
@@ -240,7 +264,11 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
         const int off = __builtin_amdgcn_readlane(tabv.x, i);
         const int t = __builtin_amdgcn_readlane(tabv.y, i);
         const bool ok = (mask >> t) & 1ull;
+#ifdef LSPS_ABL_SAMEADDR
+        const float *src = ok ? (p.X + (off & 1023) + lane) : p.zero;     // same issue work, L1-resident data
+#else
         const float *src = ok ? (xb + off) : p.zero;
+#endif
         breg[i] = *src;
       }
       // table rows of the chunk after this one (clamped: the tail read is never used)
@@ -324,6 +352,155 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
           float v = acc[i][j][r];
           if (p.bias) v += p.bias[m];
           yb[(long)m * p.HyWy] = apply_act(v, p.act, p.slope);
+        }
+      }
+    }
+  }
+}
+
+
+// -------------------------------------------------------------------------------------------
+// F kernel specialised for the dominant layer class: 3x3 taps, stride 1, pad 1, image width 32
+// (the 28 residual convs = 88 % of the generator's MACs, forward and dgrad).
+// Instead of gathering every (c,tap) row of the B tile from global memory (9 loads per input element,
+// ~10 VALU instructions each: measured 20 % of the kernel), the raw input rows of CC channels are
+// staged ONCE in LDS with their zero halo, and the 9 taps are shifted LDS reads with compile-time
+// offsets.  Tile: 128 output channels x 128 pixels (4 full image rows), chunk = CC*9 reduction rows.
+// -------------------------------------------------------------------------------------------
+#define F3_CC 8
+#define F3_ROWS 6                 // 4 output rows + top/bottom halo
+#define F3_LDW 34                 // 32 pixels + left/right halo column (always zero: W == 32, pad == 1)
+#define F3_CH (F3_ROWS * F3_LDW)  // 204 floats per channel
+
+struct F3Params {
+  const float *X, *Wp, *bias, *zero;
+  float *Y;
+  int Cx, H, M, Mp, NT;          // NT = N * (H/4) pixel tiles
+  int tiles_per_img;             // H / 4
+  int act;
+  float slope;
+};
+
+__global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
+  constexpr int BM = 128, RC = F3_CC * 9;            // 72 reduction rows per chunk
+  constexpr int A4 = RC * BM / 4 / 256;              // 9 float4 of weights per thread per chunk
+  __shared__ __attribute__((aligned(16))) float lds[RC * BM + F3_CC * F3_CH];
+  float *As = lds, *Bs = lds + RC * BM;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.y * BM;
+  const int n = blockIdx.x / p.tiles_per_img;
+  const int row0 = (blockIdx.x - n * p.tiles_per_img) * 4;       // first output row of the tile
+  const int HW = p.H * 32;
+  const float *xn = p.X + (long)n * p.Cx * HW;
+
+  // zero the halo columns once (never overwritten): cols 0 and 33 of every (channel,row)
+  if (tid < F3_CC * F3_ROWS * 2) {
+    const int rr = tid >> 1;
+    Bs[rr * F3_LDW + (tid & 1) * 33] = 0.f;
+  }
+
+  // B staging assignment: 48 (channel,row) lines of 32 pixels = 384 float4; thread handles u = tid, tid+256
+  int b_lds[2];
+  long b_off[2];
+  bool b_use[2], b_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = tid + 256 * i;
+    b_use[i] = u < F3_CC * F3_ROWS * 8;
+    const int line = u >> 3, c4 = u & 7;
+    const int ch = line / F3_ROWS, r = line - ch * F3_ROWS;
+    const int img_row = row0 - 1 + r;
+    b_ok[i] = b_use[i] && img_row >= 0 && img_row < p.H;
+    b_lds[i] = ch * F3_CH + r * F3_LDW + 1 + c4 * 4;
+    b_off[i] = (long)ch * HW + (long)img_row * 32 + c4 * 4;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 areg[A4], breg[2];
+  const int nchunks = p.Cx / F3_CC;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const float *Ap = As + half * BM + wm * 64 + l31;
+  const float *Bp = Bs + half * F3_CH + wn * 2 * F3_LDW + l31;
+
+  for (int ch = -1; ch < nchunks; ++ch) {
+    if (ch >= 0) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < A4; ++i) {
+        const int u = tid + 256 * i;
+        *reinterpret_cast<f32x4 *>(As + u * 4) = areg[i];          // tile rows are contiguous: [72][128]
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (b_use[i]) {
+          float *d = Bs + b_lds[i];
+          d[0] = breg[i][0];
+          d[1] = breg[i][1];
+          d[2] = breg[i][2];
+          d[3] = breg[i][3];
+        }
+      __syncthreads();
+    }
+    if (ch + 1 < nchunks) {
+      const float *wsrc = p.Wp + (long)(ch + 1) * RC * p.Mp + m0;
+#pragma unroll
+      for (int i = 0; i < A4; ++i) {
+        const int u = tid + 256 * i;
+        const int row = u >> 5, c4 = u & 31;
+        areg[i] = *reinterpret_cast<const f32x4 *>(wsrc + (long)row * p.Mp + c4 * 4);
+      }
+      const float *xc = xn + (long)(ch + 1) * F3_CC * HW;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float *src = b_ok[i] ? (xc + b_off[i]) : p.zero;     // masked rows read the zero slot
+        breg[i] = *reinterpret_cast<const f32x4 *>(src);
+      }
+    }
+    if (ch >= 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int tr = t / 3, ts = t - tr * 3;
+#pragma unroll
+        for (int cp = 0; cp < F3_CC / 2; ++cp) {                   // channel pair (2cp, 2cp+1): k = half
+          const int kk = t * (F3_CC / 2) + cp;                     // k-step: reduction rows 2kk, 2kk+1
+          float a[2], b[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[i] = Ap[2 * kk * BM + i * 32];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) b[j] = Bp[2 * cp * F3_CH + (j + tr) * F3_LDW + ts];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // epilogue: wave's pixel rows wn*2 + j, column l31
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float *yb = p.Y + (long)n * p.M * HW + (long)(row0 + wn * 2 + j) * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < p.M) {
+          float v = acc[i][j][r];
+          if (p.bias) v += p.bias[m];
+          yb[(long)m * HW] = apply_act(v, p.act, p.slope);
         }
       }
     }
@@ -475,6 +652,139 @@ __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
   }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// W kernel specialised for 3x3 / stride 1 / pad 1 / width 32 (the residual convs): per chunk of 64 pixels
+// (2 image rows) the raw rows of 64 input channels (with halo) and of 64 dy channels are staged ONCE in LDS;
+// each wave owns a 32(k) x 32(c) output tile for all 9 taps (9 accumulators), so one A operand read feeds
+// 9 MFMAs and every input element is loaded from global memory once instead of 9 times.
+// -------------------------------------------------------------------------------------------
+#define W3_LDA 65                 // dy tile [64 m][64 px + 1]
+#define W3_ROWS 4                 // 2 pixel rows + top/bottom halo
+#define W3_CH 137                 // floats per channel in LDS: 4 rows x 34, padded to an odd stride (137 % 32 = 9)
+
+struct W3Params {
+  const float *DY, *X, *zero;
+  float *part;                   // [splits][9][M][C]
+  int N, M, C, H;
+  int nchunks, chunks_per_split; // chunk = (n, row pair)
+};
+
+__global__ __launch_bounds__(256, 2) void igemm_w3x3_kernel(W3Params p) {
+  __shared__ __attribute__((aligned(16))) float lds[64 * W3_LDA + 64 * W3_CH];
+  float *As = lds, *Bs = lds + 64 * W3_LDA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = blockIdx.x * 64, m0 = blockIdx.y * 64, split = blockIdx.z;
+  const int HW = p.H * 32, rows2 = p.H / 2;
+  const int ch_begin = split * p.chunks_per_split;
+  int ch_end = ch_begin + p.chunks_per_split;
+  if (ch_end > p.nchunks) ch_end = p.nchunks;
+
+  // halo columns (0 and 33 of each (channel,row) line) are always zero
+  for (int u = tid; u < 64 * W3_ROWS * 2; u += 256) {
+    const int line = u >> 1;
+    Bs[(line >> 2) * W3_CH + (line & 3) * 34 + (u & 1) * 33] = 0.f;
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  f32x4 areg[4], breg[8];
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const float *Ap = As + (wm * 32 + l31) * W3_LDA + half;
+  const float *Bp = Bs + (wn * 32 + l31) * W3_CH + half;
+
+  for (int ch = ch_begin - 1; ch < ch_end; ++ch) {
+    if (ch >= ch_begin) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int u = tid + 256 * i;
+        float *d = As + (u >> 4) * W3_LDA + (u & 15) * 4;
+        d[0] = areg[i][0];
+        d[1] = areg[i][1];
+        d[2] = areg[i][2];
+        d[3] = areg[i][3];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int u = tid + 256 * i;
+        const int line = u >> 3;
+        float *d = Bs + (line >> 2) * W3_CH + (line & 3) * 34 + 1 + (u & 7) * 4;
+        d[0] = breg[i][0];
+        d[1] = breg[i][1];
+        d[2] = breg[i][2];
+        d[3] = breg[i][3];
+      }
+      __syncthreads();
+    }
+    if (ch + 1 < ch_end) {
+      const int nc = ch + 1;
+      const int n = nc / rows2, y0 = (nc - n * rows2) * 2;
+      const float *dyb = p.DY + ((long)n * p.M + m0) * HW + y0 * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int u = tid + 256 * i;
+        areg[i] = *reinterpret_cast<const f32x4 *>(dyb + (long)(u >> 4) * HW + (u & 15) * 4);
+      }
+      const float *xb = p.X + ((long)n * p.C + c0) * HW;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int u = tid + 256 * i;
+        const int line = u >> 3;
+        const int img_row = y0 - 1 + (line & 3);
+        const bool ok = img_row >= 0 && img_row < p.H;
+        const float *src = ok ? (xb + (long)(line >> 2) * HW + img_row * 32 + (u & 7) * 4) : p.zero;
+        breg[i] = *reinterpret_cast<const f32x4 *>(src);
+      }
+    }
+    if (ch >= ch_begin) {
+#pragma unroll
+      for (int row = 0; row < 2; ++row) {
+        const float *Ar = Ap + row * 32, *Br = Bp + row * 34;
+#pragma unroll 2
+        for (int kq = 0; kq < 16; ++kq) {           // k-step: pixels (row, 2kq + half)
+          const float a = Ar[2 * kq];
+          float b[9];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) b[t] = Br[(t / 3) * 34 + 2 * kq + (t % 3)];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const int c = c0 + wn * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float *out = p.part + ((long)(split * 9 + t) * p.M) * p.C + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      out[(long)m * p.C] = acc[t][r];
+    }
+  }
+}
+
+// dW[(m*C + c)*9 + t] = sum_s part[s][t][m][c]
+__global__ __launch_bounds__(256) void reduce_w3x3_kernel(const float *__restrict__ part, float *__restrict__ dw, int M,
+                                                          int C, int splits) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;      // index into dW [m][c][t]
+  const long total = (long)M * C * 9;
+  if (i >= total) return;
+  const int t = (int)(i % 9);
+  const long mc = i / 9;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += part[((long)(k * 9 + t) * M) * C + mc];
+  dw[i] = s;
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *part, float *out, long n, int splits) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -547,7 +857,7 @@ static size_t class_bytes(int REDp, int Mp) {
 
 static int launch_pack(const float *W, void *cls, int M, int Mp, int RED, int REDp, const TapList &l, long sm, long sc,
                        int HxWx, int Wx, hipStream_t st, const float **Wp_out, const int2 **gtab_out,
-                       const float **zero_out) {
+                       const float **zero_out, int cc = 0) {
   int2 *gtab = (int2 *)cls;
   float *Wp = (float *)((char *)cls + align_up((size_t)REDp * sizeof(int2), 256));
   *Wp_out = Wp;
@@ -559,6 +869,7 @@ static int launch_pack(const float *W, void *cls, int M, int Mp, int RED, int RE
   pp.Wp = Wp;
   pp.gtab = gtab;
   pp.HxWx = HxWx;
+  pp.cc = cc;
   for (int i = 0; i < LSPS_MAXT; ++i) pp.toff[i] = i < l.T ? l.dh[i] * Wx + l.dw[i] : 0;
   pp.M = M;
   pp.Mp = Mp;
@@ -595,12 +906,59 @@ static size_t packed_bytes(int Cin, int taps_total, int classes, int M) {
   return class_bytes(Cin * taps_total + 32 * classes, Mp) + (size_t)classes * 1024;
 }
 
+
+static bool f3x3_ok(int Cin, int H, int W, int R, int S, int st_, int pad) {
+  return R == 3 && S == 3 && st_ == 1 && pad == 1 && W == 32 && (H % 4) == 0 && (Cin % F3_CC) == 0;
+}
+
+// in [N][Cin][H][32] -> out [N][M][H][32]; tapidx maps kernel tap t=(dh+1)*3+(dw+1) to the weight's r*3+s
+static int run_f3x3(const float *in, const float *W, const float *bias, float *out, int N, int Cin, int H, int M,
+                    long sm, long sc, bool flip, int act, float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+  TapList l;
+  l.T = 9;
+  for (int t = 0; t < 9; ++t) {
+    l.dh[t] = t / 3 - 1;
+    l.dw[t] = t % 3 - 1;
+    l.idx[t] = flip ? 8 - t : t;
+  }
+  const int RED = Cin * 9, REDp = RED;     // Cin % 8 == 0 -> RED % 72 == 0
+  const int Mp = (int)align_up(M, 128);
+  const size_t need = class_bytes(REDp, Mp);
+  if (need > ws_bytes) {
+    set_error("conv workspace too small: need %zu, have %zu", need, ws_bytes);
+    return LSPS_E_WS;
+  }
+  F3Params p;
+  memset(&p, 0, sizeof(p));
+  const int2 *gtab_unused;
+  int rc = launch_pack(W, ws, M, Mp, RED, REDp, l, sm, sc, H * 32, 32, st, &p.Wp, &gtab_unused, &p.zero, F3_CC);
+  if (rc) return rc;
+  p.X = in;
+  p.bias = bias;
+  p.Y = out;
+  p.Cx = Cin;
+  p.H = H;
+  p.M = M;
+  p.Mp = Mp;
+  p.tiles_per_img = H / 4;
+  p.NT = N * p.tiles_per_img;
+  p.act = act;
+  p.slope = slope;
+  hipLaunchKernelGGL(igemm_f3x3_kernel, dim3(p.NT, Mp / 128), dim3(256), 0, st, p);
+  LSPS_CHECK_LAUNCH("igemm_f3x3");
+  return 0;
+}
+
 // "forward direction": in = big image [N][Cb][Hb][Wb], out = small image [N][Cs][Hs][Ws]
 //   out[n][m][p][q] = sum_{c,r,s} W(m,c,r,s) * in[n][c][p*st-pad+r][q*st-pad+s]
 //   weight element address: W[m*sm + c*sc + r*S + s]
 static int run_forward_dir(const float *in, const float *W, const float *bias, float *out, int N, int Cb, int Hb, int Wb,
                            int Cs, int Hs, int Ws, int R, int S, int st_, int pad, long sm, long sc, int act,
                            float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+#ifndef LSPS_NO_F3X3
+  if (f3x3_ok(Cb, Hb, Wb, R, S, st_, pad) && Cs >= 128)
+    return run_f3x3(in, W, bias, out, N, Cb, Hb, Cs, sm, sc, false, act, slope, ws, ws_bytes, st);
+#endif
   TapList l;
   l.T = R * S;
   for (int r = 0; r < R; ++r)
@@ -654,6 +1012,11 @@ static int run_forward_dir(const float *in, const float *W, const float *bias, f
 static int run_transposed_dir(const float *in, const float *W, const float *bias, float *out, int N, int Cb, int Hb,
                               int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad, long sm, long sc, int act,
                               float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+#ifndef LSPS_NO_F3X3
+  // stride-1 transposed conv == forward 3x3 conv with flipped taps (dh = pad - r)
+  if (f3x3_ok(Cs, Hs, Ws, R, S, st_, pad) && Hb == Hs && Wb == Ws && Cb >= 128)
+    return run_f3x3(in, W, bias, out, N, Cs, Hs, Cb, sm, sc, true, act, slope, ws, ws_bytes, st);
+#endif
   const int M = Cb;
   const int Mp = (int)align_up(M, 128);
   size_t used = 0;
@@ -732,9 +1095,64 @@ static int wgrad_splits(int M, int J, int nchunks) {
   return (int)s;
 }
 
+
+static bool w3x3_ok(int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad) {
+  return R == 3 && S == 3 && st_ == 1 && pad == 1 && Wb == 32 && Ws == 32 && Hb == Hs && (Hb % 2) == 0 &&
+         (Cb % 64) == 0 && (Cs % 64) == 0;
+}
+
+static int w3x3_splits(int M, int C, int nchunks) {
+  const int tiles = (M / 64) * (C / 64);
+  int s = 512 / tiles;                    // 2 workgroups per CU x 256 CUs, one round
+  if (s > nchunks) s = nchunks;
+  if (s < 1) s = 1;
+  return s;
+}
+
+static size_t w3x3_ws_bytes(int N, int M, int C, int H) {
+  return 256 + (size_t)w3x3_splits(M, C, N * H / 2) * 9 * M * C * sizeof(float);
+}
+
+static int run_w3x3(const float *dy, const float *x, float *dW, int N, int C, int H, int M, void *ws, size_t ws_bytes,
+                    hipStream_t st) {
+  W3Params p;
+  memset(&p, 0, sizeof(p));
+  p.DY = dy;
+  p.X = x;
+  p.N = N;
+  p.M = M;
+  p.C = C;
+  p.H = H;
+  p.nchunks = N * H / 2;
+  const int splits = w3x3_splits(M, C, p.nchunks);
+  p.chunks_per_split = ceil_div(p.nchunks, splits);
+  if (w3x3_ws_bytes(N, M, C, H) > ws_bytes) {
+    set_error("wgrad workspace too small: need %zu, have %zu", w3x3_ws_bytes(N, M, C, H), ws_bytes);
+    return LSPS_E_WS;
+  }
+  float *zero = (float *)ws;
+  hipError_t e = hipMemsetAsync(zero, 0, 256, st);
+  if (e != hipSuccess) {
+    set_error("hipMemsetAsync: %s", hipGetErrorString(e));
+    return LSPS_E_HIP;
+  }
+  p.zero = zero;
+  p.part = (float *)((char *)ws + 256);
+  hipLaunchKernelGGL(igemm_w3x3_kernel, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
+  LSPS_CHECK_LAUNCH("igemm_w3x3");
+  const long total = (long)M * C * 9;
+  hipLaunchKernelGGL(reduce_w3x3_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float *)p.part, dW, M, C,
+                     splits);
+  LSPS_CHECK_LAUNCH("reduce_w3x3");
+  return 0;
+}
+
 // dW[m][(c,t)] = sum_{n,p,q} small[n][m][p][q] * big[n][c][p*st-pad+r][q*st-pad+s]
 static int run_wgrad(const float *small, const float *big, float *dW, int N, int Cb, int Hb, int Wb, int Cs, int Hs,
                      int Ws, int R, int S, int st_, int pad, void *ws, size_t ws_bytes, hipStream_t st) {
+#ifndef LSPS_NO_W3X3
+  if (w3x3_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad)) return run_w3x3(small, big, dW, N, Cb, Hb, Cs, ws, ws_bytes, st);
+#endif
   WParams p;
   memset(&p, 0, sizeof(p));
   TapList l;
@@ -824,6 +1242,10 @@ static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int W
                     (splits > 1 ? (size_t)splits * Cs * J * sizeof(float) : 0);
   size_t m = fwd > tr ? fwd : tr;
   if (wg > m) m = wg;
+  if (w3x3_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, R == 3 ? 1 : -1)) {
+    const size_t w3 = w3x3_ws_bytes(N, Cs, Cb, Hb);
+    if (w3 > m) m = w3;
+  }
   return BIAS_WS_BYTES + m + 1024;
 }
 

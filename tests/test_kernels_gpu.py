@@ -45,6 +45,11 @@ CONV_CASES = [
     (5, 3, 17, 13, 37, 3, 1, 1),        # ragged everything
     (3, 5, 19, 23, 70, 5, 2, 2),        # 5x5 stride 2, ragged
     (2, 33, 9, 9, 129, 3, 3, 0),        # stride 3
+    (2, 8, 32, 32, 130, 3, 1, 1),       # specialised 3x3/width-32 kernel: one channel chunk, ragged M
+    (5, 16, 8, 32, 128, 3, 1, 1),       # specialised kernel: H=8 (two row tiles), N not a power of two
+    (1, 24, 4, 32, 200, 3, 1, 1),       # specialised kernel: a single row tile (both halos out of range)
+    (3, 64, 8, 32, 128, 3, 1, 1),       # specialised wgrad kernel (C, K multiples of 64), few chunks
+    (7, 128, 2, 32, 64, 3, 1, 1),       # specialised wgrad: one row pair per image, odd N
 ]
 
 
