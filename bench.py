@@ -157,10 +157,11 @@ def main():
                                                    'tflops': 7.76 * args.batch / 128.0 / t_fwd}}
 
     if rank == 0:
-        dom = prof.get('igemm_f<128x128>', None)
+        dom_name = max(prof, key=lambda k: prof[k]['total_ms']) if prof else None
+        dom = prof.get(dom_name)
         roofline = None
         if dom:
-            roofline = {'bound': 'mfma', 'kernel': 'igemm_f_kernel<2,2,2,2> (implicit-GEMM conv, f32 MFMA 32x32x2)',
+            roofline = {'bound': 'mfma', 'kernel': dom_name + ' (implicit-GEMM conv on v_mfma_f32_32x32x2_f32)',
                         'achieved': dom['tflops'], 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': dom['tflops'] / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
                         'launches': dom['launches'], 'avg_launch_ms': dom['avg_ms'],

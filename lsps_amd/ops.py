@@ -45,8 +45,17 @@ class Profiler(object):
         self.records = []
 
     @staticmethod
-    def f_kernel(M):
-        return 'igemm_f<128x128>' if M >= 128 else ('igemm_f<64x256>' if M >= 64 else 'igemm_f<32x256>')
+    def f_kernel(M, cin=0, h=0, w=0, r=0, stride=0, pad=0):
+        """Name of the kernel the C library dispatches to (mirrors igemm.hip: f3x3_ok / choose_cfg)."""
+        if r == 3 and stride == 1 and pad == 1 and w == 32 and h % 4 == 0 and cin % 8 == 0 and M >= 128:
+            return 'igemm_f3x3_kernel'
+        return 'igemm_f_kernel<2,2,2,2>' if M >= 128 else ('igemm_f_kernel<2,2,1,4>' if M >= 64 else 'igemm_f_kernel<1,2,1,4>')
+
+    @staticmethod
+    def w_kernel(cb, hb, wb, cs, r, stride, pad):
+        if r == 3 and stride == 1 and pad == 1 and wb == 32 and hb % 2 == 0 and cb % 64 == 0 and cs % 64 == 0:
+            return 'igemm_w3x3_kernel'
+        return 'igemm_w_kernel'
 
     def span(self, key, flops, launches):
         return _Span(self, key, flops, launches)
@@ -96,7 +105,7 @@ class _Conv2dFn(torch.autograd.Function):
         P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
         y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
         ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, R, S, stride, pad), x.device)
-        with profiler.span(Profiler.f_kernel(K), 2.0 * N * K * P * Q * C * R * S, 1):
+        with profiler.span(Profiler.f_kernel(K, C, H, W, R if R == S else 0, stride, pad), 2.0 * N * K * P * Q * C * R * S, 1):
             _lib.check(L.lsps_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, C, H, W, K, R, S,
                                          stride, pad, act, slope, ws, wsb, _lib.stream()), 'conv2d_fwd')
         ctx.geom = (N, C, H, W, K, R, S, stride, pad, act, slope)
@@ -120,14 +129,15 @@ class _Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            with profiler.span(Profiler.f_kernel(C), flops, stride * stride):
+            with profiler.span(Profiler.f_kernel(C, K, dy.shape[2], dy.shape[3], R if R == S else 0, stride, pad), flops,
+                               stride * stride):
                 _lib.check(L.lsps_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, C, H, W, K, R, S, stride,
                                                pad, ws, wsb, st), 'conv2d_dgrad')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = torch.empty(K, dtype=torch.float32, device=x.device)
-            with profiler.span('igemm_w<128x128x64>', flops, 1):
+            with profiler.span(Profiler.w_kernel(C, H, W, K, R if R == S else 0, stride, pad), flops, 1):
                 _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), N, C, H, W, K, R,
                                                S, stride, pad, ws, wsb, st), 'conv2d_wgrad')
         return dx, dw, db, None, None, None, None
@@ -184,7 +194,7 @@ class _ConvT2dFn(torch.autograd.Function):
             dw = torch.empty_like(w)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = torch.empty(Co, dtype=torch.float32, device=x.device)
-            with profiler.span('igemm_w<128x128x64>', flops, 1):
+            with profiler.span('igemm_w_kernel', flops, 1):
                 _lib.check(L.lsps_convT2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), N, Ci, H, W, Co,
                                                 R, S, stride, pad, outpad, ws, wsb, st), 'convT2d_wgrad')
         return dx, dw, db, None, None, None, None, None

