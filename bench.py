@@ -92,9 +92,10 @@ def main():
         raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one process per GPU)" % args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get('LSPS_FORCE_DP') == '1':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_PORT', '29517')
+        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
 
     import lsps_amd.trainers as trainers
     from lsps_amd import ops, synth
@@ -182,9 +183,14 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(hp)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
-        print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its banner through C stdio; flush it first so that the JSON is the LAST line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

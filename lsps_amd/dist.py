@@ -23,6 +23,15 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def active():
+    """True when gradients must be exchanged.  LSPS_FORCE_DP=1 also runs the exchange in a 1-rank process
+    group (used to smoke-test the RCCL call pattern on a single-GPU box)."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('LSPS_FORCE_DP') == '1'
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -51,7 +60,8 @@ class GradReducer(object):
         self._works = []
         self._launched = None
         self.expected = None        # indices expected to receive a gradient this backward (None: unknown)
-        if self.world > 1:
+        self.active = active()
+        if self.active:
             arena.on_grad_ready = self._on_grad_ready
 
     # ---- per-backward protocol -------------------------------------------------------------
@@ -61,7 +71,7 @@ class GradReducer(object):
         been accumulated (overlap with the rest of backward); without it, everything goes at finish()."""
         self._works = []
         self._launched = [False] * len(self.buckets)
-        if expected is None or self.world == 1:
+        if expected is None or not self.active:
             self._pending = None
             return
         self._pending = [0] * len(self.buckets)
@@ -84,7 +94,7 @@ class GradReducer(object):
 
     def finish(self):
         """Call after backward, before the optimizer step: launches what is left, waits for all."""
-        if self.world == 1:
+        if not self.active:
             return
         touched = self.arena.touched
         for b, (i0, i1) in enumerate(self.buckets):
@@ -99,7 +109,7 @@ class GradReducer(object):
 
 def all_reduce_mean_scalars(values, device):
     """Logging parity: average a small list of python floats over ranks (one tiny all-reduce)."""
-    if world() == 1:
+    if not active():
         return values
     t = torch.tensor(values, dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -82,7 +82,7 @@ class LSPSTrainer(nn.Module):
     def _step(self, key, opt, loss, expected_net=None):
         red = self._reducers[key]
         expected = None
-        if lsps_dist.world() > 1 and expected_net is not None:
+        if lsps_dist.active() and expected_net is not None:
             ids = set(id(p) for p in expected_net)
             expected = [i for i, p in enumerate(red.arena.params) if id(p) in ids]
         red.begin(expected)
@@ -93,7 +93,7 @@ class LSPSTrainer(nn.Module):
     def _publish(self, names, tensors, extra=None):
         """One device->host copy for all per-step scalars; stored as numpy values like the reference."""
         vals = torch.stack([t.detach().reshape(()).float() for t in tensors]).cpu().numpy()
-        if lsps_dist.world() > 1:
+        if lsps_dist.active():
             vals = np.asarray(lsps_dist.all_reduce_mean_scalars([float(v) for v in vals], 'cuda'), dtype=np.float32)
         out = dict(zip(names, vals))
         for k, v in out.items():
@@ -241,7 +241,7 @@ class LSPSTrainer(nn.Module):
             terms_reg.append(regression(self.dis.regress_b, images_b, labels_b, noise.get('vae_b')))
         else:
             first_a, first_b = images_a[0:4], images_b[0:4]                       # :238 — only the first 4 samples
-            if lsps_dist.world() > 1:
+            if lsps_dist.active():
                 # exact global-batch parity: every rank evaluates the SAME (global first-4) feature term
                 first_a, first_b = first_a.clone(), first_b.clone()
                 torch.distributed.broadcast(first_a, 0)
