@@ -161,10 +161,20 @@ def main():
         dom_name = max(prof, key=lambda k: prof[k]['total_ms']) if prof else None
         dom = prof.get(dom_name)
         roofline = None
+        traffic = None
+        try:        # PMC traffic is collected offline (rocprofv3 --pmc cannot run inside the timed bench)
+            with open(os.path.join(REPO, 'profiles', 'r1_traffic.json')) as f:
+                tj = json.load(f).get(dom_name)
+            if tj:   # scaled from the profiled launch shape to this run's average launch by algorithmic work
+                traffic = tj['hbm_bytes_per_launch'] * dom['gflop_per_launch'] / tj['gflop_per_launch']
+        except (OSError, ValueError, TypeError):
+            traffic = None
         if dom:
             roofline = {'bound': 'mfma', 'kernel': dom_name + ' (implicit-GEMM conv on v_mfma_f32_32x32x2_f32)',
                         'achieved': dom['tflops'], 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': dom['tflops'] / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                        'frac': dom['tflops'] / F32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                        'traffic_note': 'HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE KB, calibrated), '
+                                        'profiles/r1_traffic.json; scaled to this run\'s mean launch size',
                         'launches': dom['launches'], 'avg_launch_ms': dom['avg_ms'],
                         'algorithmic_gflop_per_launch': dom['gflop_per_launch'],
                         'share_of_step_time': dom['total_ms'] / (1e3 * elapsed),

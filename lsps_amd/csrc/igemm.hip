@@ -152,7 +152,7 @@ template <int WM, int WN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
   constexpr int BM = WM * 32 * WAVES_M, BN = WN * 32 * WAVES_N, BK = BK_F;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-  static_assert(BN == 128 || BN == 256, "pixel tile");
+  static_assert(BN == 64 || BN == 128 || BN == 256, "pixel tile");
   constexpr int PIXW = BN / 64;        // waves side by side along the pixel tile
   constexpr int RGROUPS = 4 / PIXW;    // wave groups stacked along the reduction rows
   constexpr int NB = BK / RGROUPS;     // B gathers per thread per chunk: rows rbase*NB .. rbase*NB+NB-1
@@ -278,43 +278,6 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
         tabv = p.gtab[nk + rbase * NB + (lane & (NB - 1))];
       }
     }
-#ifdef LSPS_OPERAND_DB   // measured SLOWER (103 -> 79 TFLOP/s on the 3x3 256->256 layer): kept for reference
-    if (ch >= 0) {
-      // MFMA chain with the operands of k-step kk+1 read from LDS BEFORE the MFMAs of k-step kk are issued
-      // (explicit register double buffer): a wave's own ds_read latency hides behind its own 4 MFMAs.
-      const float *Ap = As + half * BM + wm * WM * 32 + l31;
-      const float *Bp = Bs + half * BN + wn * WN * 32 + l31;
-      float a[2][WM], b[2][WN];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) a[0][i] = Ap[i * 32];
-#pragma unroll
-      for (int j = 0; j < WN; ++j) b[0][j] = Bp[j * 32];
-#pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        const int cur = kk & 1, nxt = cur ^ 1;
-        if (kk + 1 < BK / 2) {
-#pragma unroll
-          for (int i = 0; i < WM; ++i) a[nxt][i] = Ap[(2 * kk + 2) * BM + i * 32];
-#pragma unroll
-          for (int j = 0; j < WN; ++j) b[nxt][j] = Bp[(2 * kk + 2) * BN + j * 32];
-        }
-        // Order fence: the LDS reads above may not sink below this point ("memory"), and the MFMAs below
-        // may not hoist above it (their operands pass through it).  hipcc otherwise sinks the reads under
-        // the MFMAs to reuse the operand registers, exposing the LDS latency on every k-step.
-#pragma unroll
-        for (int i = 0; i < WM; ++i) asm volatile("" : "+v"(a[cur][i])::"memory");
-#pragma unroll
-        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(b[cur][j])::"memory");
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int j = 0; j < WN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-      }
-    }
-  }
-
-#else
     if (ch >= 0) {
 #pragma unroll 8
       for (int kk = 0; kk < BK / 2; ++kk) {
@@ -333,7 +296,6 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
     }
   }
 
-#endif
   // ---- epilogue: lane holds pixel column l31 of each 32x32 tile, rows (r&3)+8*(r>>2)+4*half
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
@@ -508,10 +470,13 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
 }
 
 // -------------------------------------------------------------------------------------------
-// W kernel (weight gradient): tile 128 (m) x 128 (c,t) x 64 pixels, split over pixel chunks
+// W kernel (weight gradient): tile (64*TW) m x (64*TW) (c,t) columns x 64 pixels, split over pixel chunks.
+// TW = 2: 128x128 tile, each wave 2x2 MFMA tiles.  TW = 1: 64x64 tile (one MFMA tile per wave) for the
+// layers with <= 64 rows / columns (7x7 stem: 64 x 49; 1x1 head), where a 128x128 tile is >= 75 % padding.
 // -------------------------------------------------------------------------------------------
+template <int TW>
 __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
-  constexpr int BM = 128, BN = 128, BK = BK_W;
+  constexpr int BM = 64 * TW, BN = 64 * TW, BK = BK_W, RW = 16 * TW;   // RW rows / columns loaded per wave
   __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDW];
   float *As = lds, *Bs = lds + BM * LDW;
 
@@ -524,27 +489,27 @@ __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
   if (ch_end > p.nchunks) ch_end = p.nchunks;
   const int T = p.taps.T;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TW][TW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TW; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float areg[32], breg[32];
+  float areg[RW], breg[RW];
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
-  // this wave's 32 column-table rows (fixed for the whole kernel): lane i holds row i, broadcast by v_readlane
-  const int2 tabv = p.jtab[j0 + wave * 32 + (lane & 31)];
+  // this wave's RW column-table rows (fixed for the whole kernel): lane i holds row i, broadcast by v_readlane
+  const int2 tabv = p.jtab[j0 + wave * RW + (lane & (RW - 1))];
 
   for (int ch = ch_begin - 1; ch < ch_end; ++ch) {
     if (ch >= ch_begin) {
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        As[(wave * 32 + i) * LDW + lane] = areg[i];
-        Bs[(wave * 32 + i) * LDW + lane] = breg[i];
+      for (int i = 0; i < RW; ++i) {
+        As[(wave * RW + i) * LDW + lane] = areg[i];
+        Bs[(wave * RW + i) * LDW + lane] = breg[i];
       }
       __syncthreads();
     }
@@ -567,14 +532,14 @@ __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
       const float *sb = p.Small + (long)n * p.M * p.P + pp;
       const float *xb = p.Big + ((long)n * p.Cx * p.Hx + ih0) * p.Wx + iw0;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const int m = m0 + wave * 32 + i;           // wave-uniform row
+      for (int i = 0; i < RW; ++i) {
+        const int m = m0 + wave * RW + i;           // wave-uniform row
         const bool ok = pv && m < p.M;
         const float *src = ok ? (sb + (long)m * p.P) : p.zero;   // masked lanes read the zero slot: no select
         areg[i] = *src;
       }
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
+      for (int i = 0; i < RW; ++i) {
         const int off = __builtin_amdgcn_readlane(tabv.x, i);
         const int t = __builtin_amdgcn_readlane(tabv.y, i);
         const bool ok = (mask >> t) & 1ull;
@@ -582,76 +547,38 @@ __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
         breg[i] = *src;
       }
     }
-#ifdef LSPS_OPERAND_DB
-    if (ch >= ch_begin) {
-      // same operand double buffering + order fence as the F kernel
-      const float *Ap = As + (wm * 64 + l31) * LDW + half;
-      const float *Bp = Bs + (wn * 64 + l31) * LDW + half;
-      float a[2][2], b[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[0][i] = Ap[i * 32 * LDW];
-        b[0][i] = Bp[i * 32 * LDW];
-      }
-#pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        const int cur = kk & 1, nxt = cur ^ 1;
-        if (kk + 1 < BK / 2) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            a[nxt][i] = Ap[i * 32 * LDW + 2 * kk + 2];
-            b[nxt][i] = Bp[i * 32 * LDW + 2 * kk + 2];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          asm volatile("" : "+v"(a[cur][i])::"memory");
-          asm volatile("" : "+v"(b[cur][i])::"memory");
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-      }
-    }
-  }
-
-#else
     if (ch >= ch_begin) {
 #pragma unroll 8
       for (int kk = 0; kk < BK / 2; ++kk) {
-        float a[2], b[2];
+        float a[TW], b[TW];
         const int col = 2 * kk + half;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = As[((wm * 2 + i) * 32 + l31) * LDW + col];
+        for (int i = 0; i < TW; ++i) a[i] = As[((wm * TW + i) * 32 + l31) * LDW + col];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = Bs[((wn * 2 + j) * 32 + l31) * LDW + col];
+        for (int j = 0; j < TW; ++j) b[j] = Bs[((wn * TW + j) * 32 + l31) * LDW + col];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TW; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < TW; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
   }
 
-#endif
   float *out = p.part + (long)split * p.M * p.J;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int jj = j0 + (wn * 2 + j) * 32 + l31;
+  for (int j = 0; j < TW; ++j) {
+    const int jj = j0 + (wn * TW + j) * 32 + l31;
     if (jj >= p.J) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = m0 + (wm * TW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (m < p.M) out[(long)m * p.J + jj] = acc[i][j][r];
       }
   }
 }
-
 
 // -------------------------------------------------------------------------------------------
 // W kernel specialised for 3x3 / stride 1 / pad 1 / width 32 (the residual convs): per chunk of 64 pixels
@@ -793,6 +720,63 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *part,
   out[i] = s;
 }
 
+
+// -------------------------------------------------------------------------------------------
+// Pointwise head: 1x1 (transposed) conv with ONE output channel (generator output, lsps_nets.py:226-229).
+// 1.05 MMAC per sample against 4 MB of input: HBM-bound, so no MFMA — one float4 of pixels per thread,
+// channel loop with the weight in SGPRs, fused bias + tanh.  y[n][pix] = act(b + sum_c w[c] x[n][c][pix]).
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pw1_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                      const float *__restrict__ b, float *__restrict__ y, int N, int C,
+                                                      int HW4, int act, float slope) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // (n, pixel quad)
+  if (idx >= (long)N * HW4) return;
+  const int n = (int)(idx / HW4), q = (int)(idx - (long)n * HW4);
+  const f32x4 *xp = reinterpret_cast<const f32x4 *>(x) + (long)n * C * HW4 + q;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int c = 0; c < C; ++c) acc += w[c] * xp[(long)c * HW4];
+  const float bb = b ? b[0] : 0.f;
+  f32x4 r;
+  r[0] = apply_act(acc[0] + bb, act, slope);
+  r[1] = apply_act(acc[1] + bb, act, slope);
+  r[2] = apply_act(acc[2] + bb, act, slope);
+  r[3] = apply_act(acc[3] + bb, act, slope);
+  reinterpret_cast<f32x4 *>(y)[idx] = r;
+}
+
+// dx[n][c][pix] = w[c] * dy[n][pix]
+__global__ __launch_bounds__(256) void pw1_dgrad_kernel(const float *__restrict__ dy, const float *__restrict__ w,
+                                                        float *__restrict__ dx, int N, int C, int HW4) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)N * HW4) return;
+  const int n = (int)(idx / HW4), q = (int)(idx - (long)n * HW4);
+  const f32x4 g = reinterpret_cast<const f32x4 *>(dy)[idx];
+  f32x4 *xp = reinterpret_cast<f32x4 *>(dx) + (long)n * C * HW4 + q;
+#pragma unroll 8
+  for (int c = 0; c < C; ++c) xp[(long)c * HW4] = w[c] * g;
+}
+
+// part[s][c] = sum over slice s of (n,pix) of x[n][c][pix] * dy[n][pix]   (grid: C x S)
+__global__ __launch_bounds__(256) void pw1_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                        float *__restrict__ part, int N, int C, int HW4, long slice4) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, sidx = blockIdx.y;
+  const long total4 = (long)N * HW4;
+  const long e0 = (long)sidx * slice4;
+  long e1 = e0 + slice4;
+  if (e1 > total4) e1 = total4;
+  float s = 0.f;
+  for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+    const long n = e / HW4, q = e - n * HW4;
+    const f32x4 a = reinterpret_cast<const f32x4 *>(x)[(n * C + c) * HW4 + q];
+    const f32x4 g = reinterpret_cast<const f32x4 *>(dy)[e];
+    s += (a[0] * g[0] + a[1] * g[1]) + (a[2] * g[2] + a[3] * g[3]);
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) part[(long)sidx * C + c] = s;
+}
+
 // db[c] = sum_{n,p} t[n][c][p].  Stage 1: grid (C, S): block (c,s) sums slice s of the N*HW elements of
 // channel c into part[c*S+s]; stage 2 (reduce_partials_kernel with n=C... see run_bias_grad) adds the S slices.
 __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float *__restrict__ t, float *__restrict__ part,
@@ -827,9 +811,19 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float *__r
 // -------------------------------------------------------------------------------------------
 static unsigned magic_for(int T) { return T <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)T + 1ull); }
 
-static int choose_cfg(int M) { return M >= 128 ? 0 : (M >= 64 ? 1 : 2); }
-static int cfg_bm(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
-static int cfg_bn(int cfg) { return cfg == 0 ? 128 : 256; }
+// tile configs: 0: 128x128, 1: 64x256, 2: 32x256, 3: 128x64, 4: 64x64 (the last two for small pixel counts:
+// the late discriminator layers have N*4..N*64 pixels, and a 128x128 tiling leaves half of the CUs idle)
+static int cfg_bm(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : (cfg == 2 ? 32 : (cfg == 3 ? 128 : 64))); }
+static int cfg_bn(int cfg) { return cfg == 0 ? 128 : (cfg == 1 || cfg == 2 ? 256 : 64); }
+static int choose_cfg(int M, long NPIX) {
+  if (M < 64) return 2;
+  if (M < 128) return 1;
+  const long g0 = (long)ceil_div(NPIX, 128) * ceil_div(M, 128);
+  if (g0 >= 512) return 0;
+  const long g3 = (long)ceil_div(NPIX, 64) * ceil_div(M, 128);
+  if (g3 >= 512) return 3;
+  return 4;
+}
 
 struct TapList {
   int T;
@@ -894,8 +888,12 @@ static int launch_f(const FParams &p, int cfg, hipStream_t st) {
     hipLaunchKernelGGL((igemm_f_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
   else if (cfg == 1)
     hipLaunchKernelGGL((igemm_f_kernel<2, 2, 1, 4>), grid, dim3(256), 0, st, p);
-  else
+  else if (cfg == 2)
     hipLaunchKernelGGL((igemm_f_kernel<1, 2, 1, 4>), grid, dim3(256), 0, st, p);
+  else if (cfg == 3)
+    hipLaunchKernelGGL((igemm_f_kernel<1, 2, 4, 1>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((igemm_f_kernel<1, 1, 2, 2>), grid, dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_f");
   return 0;
 }
@@ -1004,7 +1002,7 @@ static int run_forward_dir(const float *in, const float *W, const float *bias, f
   p.act = act;
   p.slope = slope;
   fill_taps(p.taps, l, Wb);
-  return launch_f(p, choose_cfg(M), st);
+  return launch_f(p, choose_cfg(M, p.NPIX), st);
 }
 
 // "transposed direction": in = small image [N][Cs][Hs][Ws], out = big image [N][Cb][Hb][Wb]
@@ -1076,17 +1074,20 @@ static int run_transposed_dir(const float *in, const float *W, const float *bias
       p.act = act;
       p.slope = slope;
       fill_taps(p.taps, l, Ws);
-      rc = launch_f(p, choose_cfg(M), st);
+      rc = launch_f(p, choose_cfg(M, p.NPIX), st);
       if (rc) return rc;
     }
   return 0;
 }
 
+static int wgrad_tile(int M, int J) { return (M <= 64 && J <= 64) ? 64 : 128; }
+
 static int wgrad_splits(int M, int J, int nchunks) {
   // The W kernel runs 2 workgroups per CU (LDS-bound): aim at just under two full rounds of 256 CUs x 2.
   // Few-tile problems (7x7 stem: 64x49 outputs; 1x1 head) get up to 1024 pixel splits so that the whole chip
   // streams the activations; the partial buffer is capped at 256 MiB.
-  const long tiles = (long)ceil_div(M, 128) * ceil_div(J, 128);
+  const int tile = wgrad_tile(M, J);
+  const long tiles = (long)ceil_div(M, tile) * ceil_div(J, tile);
   long s = 1024 / tiles;
   const long cap = ((long)256 << 20) / ((long)M * J * 4);
   if (s > cap) s = cap;
@@ -1197,8 +1198,12 @@ static int run_wgrad(const float *small, const float *big, float *dW, int N, int
   p.jtab = jtab;
   p.zero = zero;
   p.part = splits > 1 ? (float *)((char *)ws + head) : dW;
-  dim3 grid(ceil_div(p.J, 128), ceil_div(p.M, 128), splits);
-  hipLaunchKernelGGL(igemm_w_kernel, grid, dim3(256), 0, st, p);
+  const int tile = wgrad_tile(p.M, p.J);
+  dim3 grid(ceil_div(p.J, tile), ceil_div(p.M, tile), splits);
+  if (tile == 64)
+    hipLaunchKernelGGL(igemm_w_kernel<1>, grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(igemm_w_kernel<2>, grid, dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_w");
   if (splits > 1) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(nW, 256)), dim3(256), 0, st, (const float *)p.part, dW, nW,
@@ -1246,12 +1251,18 @@ static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int W
     const size_t w3 = w3x3_ws_bytes(N, Cs, Cb, Hb);
     if (w3 > m) m = w3;
   }
-  return BIAS_WS_BYTES + m + 1024;
+  return 2 * BIAS_WS_BYTES + m + 1024;
 }
 
 static bool conv_args_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
   return N > 0 && C > 0 && H > 0 && W > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0 &&
          R * S <= LSPS_MAXT && stride <= 4;
+}
+
+
+static bool pw1_ok(int Co, int R, int S, int stride, int pad, int outpad, long HW, const void *p0, const void *p1) {
+  return Co == 1 && R == 1 && S == 1 && stride == 1 && pad == 0 && outpad == 0 && (HW % 4) == 0 &&
+         (((uintptr_t)p0 | (uintptr_t)p1) & 15) == 0;
 }
 
 }  // namespace lsps
@@ -1328,6 +1339,13 @@ int lsps_convT2d_fwd(const float *x, const float *w, const float *bias, float *y
                  "convT2d_fwd: unsupported geometry");
   const int Ho = (H - 1) * stride - 2 * pad + R + outpad, Wo = (W - 1) * stride - 2 * pad + S + outpad;
   LSPS_CHECK_ARG(Ho > 0 && Wo > 0, "convT2d_fwd: empty output");
+  if (pw1_ok(Co, R, S, stride, pad, outpad, (long)H * W, x, y)) {
+    const int HW4 = H * W / 4;
+    hipLaunchKernelGGL(pw1_fwd_kernel, dim3(ceil_div((long)N * HW4, 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                       y, N, Ci, HW4, act, slope);
+    LSPS_CHECK_LAUNCH("pw1_fwd");
+    return 0;
+  }
   // out channel m = co: W[ci][co][r][s] -> sm = R*S ; reduction channel ci -> sc = Co*R*S
   return run_transposed_dir(x, w, bias, y, N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad, (long)R * S, (long)Co * R * S,
                             act, slope, ws, ws_bytes, (hipStream_t)stream);
@@ -1339,6 +1357,13 @@ int lsps_convT2d_dgrad(const float *dy, const float *w, float *dx, int N, int Ci
   LSPS_CHECK_ARG(dy && w && dx && ws, "convT2d_dgrad: null pointer");
   LSPS_CHECK_ARG(conv_args_ok(N, Ci, H, W, Co, R, S, stride, pad), "convT2d_dgrad: unsupported geometry");
   const int Ho = (H - 1) * stride - 2 * pad + R + outpad, Wo = (W - 1) * stride - 2 * pad + S + outpad;
+  if (pw1_ok(Co, R, S, stride, pad, outpad, (long)H * W, dy, dx)) {
+    const int HW4 = H * W / 4;
+    hipLaunchKernelGGL(pw1_dgrad_kernel, dim3(ceil_div((long)N * HW4, 256)), dim3(256), 0, (hipStream_t)stream, dy, w, dx,
+                       N, Ci, HW4);
+    LSPS_CHECK_LAUNCH("pw1_dgrad");
+    return 0;
+  }
   // dx[n][ci][h][w] = sum_{co,r,s} W[ci][co][r][s] dy[n][co][h*st-pad+r][w*st-pad+s]
   return run_forward_dir(dy, w, nullptr, dx, N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad, (long)Co * R * S, (long)R * S,
                          LSPS_ACT_NONE, 1.f, ws, ws_bytes, (hipStream_t)stream);
@@ -1350,9 +1375,26 @@ int lsps_convT2d_wgrad(const float *x, const float *dy, float *dw, float *db, in
   LSPS_CHECK_ARG(x && dy && dw && ws, "convT2d_wgrad: null pointer");
   LSPS_CHECK_ARG(conv_args_ok(N, Ci, H, W, Co, R, S, stride, pad), "convT2d_wgrad: unsupported geometry");
   const int Ho = (H - 1) * stride - 2 * pad + R + outpad, Wo = (W - 1) * stride - 2 * pad + S + outpad;
-  LSPS_CHECK_ARG(ws_bytes >= BIAS_WS_BYTES, "convT2d_wgrad: workspace too small");
-  int rc = run_wgrad(x, dy, dw, N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad, (char *)ws + BIAS_WS_BYTES,
-                     ws_bytes - BIAS_WS_BYTES, (hipStream_t)stream);
+  LSPS_CHECK_ARG(ws_bytes >= 2 * BIAS_WS_BYTES, "convT2d_wgrad: workspace too small");
+  int rc;
+  if (pw1_ok(Co, R, S, stride, pad, outpad, (long)H * W, x, dy) && Ci <= 4096) {
+    const int HW4 = H * W / 4;
+    const long total4 = (long)N * HW4;
+    long Sp = (total4 + 16383) / 16384;
+    if (Sp > 64) Sp = 64;
+    const long slice4 = (total4 + Sp - 1) / Sp;
+    float *part = (float *)((char *)ws + BIAS_WS_BYTES);      // [Sp][Ci] <= 1 MiB
+    hipLaunchKernelGGL(pw1_wgrad_kernel, dim3(Ci, (int)Sp), dim3(256), 0, (hipStream_t)stream, x, dy, part, N, Ci, HW4,
+                       slice4);
+    LSPS_CHECK_LAUNCH("pw1_wgrad");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(Ci, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)part, dw, (long)Ci, (int)Sp);
+    LSPS_CHECK_LAUNCH("pw1_wgrad_reduce");
+    rc = 0;
+  } else {
+    rc = run_wgrad(x, dy, dw, N, Co, Ho, Wo, Ci, H, W, R, S, stride, pad, (char *)ws + BIAS_WS_BYTES,
+                   ws_bytes - BIAS_WS_BYTES, (hipStream_t)stream);
+  }
   if (rc) return rc;
   if (db) return run_bias_grad(dy, db, N, Co, Ho * Wo, ws, ws_bytes, (hipStream_t)stream);
   return 0;
