@@ -10,7 +10,7 @@ import sys
 def kernel_stats(db):
     c = sqlite3.connect(db)
     rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    out = ["%-78s %7s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct")]
+    out = ["%-78s %7s %14s %12s %7s" % ("kernel", "calls", "total_ms", "avg_ms", "pct")]
     for name, calls, total, avg, pct in rows:
         out.append("%-78s %7d %14.1f %12.2f %7.2f" % (name[:78], calls, total / 1e3, avg / 1e3, pct))
     return "\n".join(out)
