@@ -1,17 +1,29 @@
-"""Weight initialisers (reference: src/trainers/init.py:8-17)."""
-import numpy as np
-import torch.nn.init as init
+"""Weight initialisers of the depth path.
+
+`gaussian_weights_init` is applied with `module.apply(...)` by every block and by the trainer
+(reference behaviour: src/trainers/init.py:8-12): modules whose CLASS NAME begins with "Conv" — here the
+`Conv2d` / `ConvTranspose2d` parameter holders of common_net.py — get N(0, 0.02) weights; everything else
+(Linear, placeholders, containers) is left alone.  `xavier_weights_init` exists for API parity
+(src/trainers/init.py:14-17); no shipped config uses it.
+"""
+import math
+
+from torch.nn import init as _init
+
+GAUSSIAN_STD = 0.02
+
+
+def _is_conv_holder(module, anywhere=False):
+    name = type(module).__name__
+    return ('Conv' in name) if anywhere else name.startswith('Conv')
 
 
 def gaussian_weights_init(m):
-    """N(0, 0.02) on every module whose class name STARTS with 'Conv' (init.py:8-12) — i.e. the
-    Conv2d / ConvTranspose2d parameter holders of common_net.py, never Linear."""
-    if m.__class__.__name__.find('Conv') == 0:
-        m.weight.data.normal_(0.0, 0.02)
+    if _is_conv_holder(m):
+        m.weight.data.normal_(mean=0.0, std=GAUSSIAN_STD)
 
 
 def xavier_weights_init(m):
-    """Unused by the shipped configs (init.py:14-17)."""
-    if m.__class__.__name__.find('Conv') != -1:
-        init.xavier_uniform_(m.weight, gain=np.sqrt(2))
-        init.constant_(m.bias, 0.1)
+    if _is_conv_holder(m, anywhere=True):
+        _init.xavier_uniform_(m.weight, gain=math.sqrt(2.0))
+        _init.constant_(m.bias, 0.1)
