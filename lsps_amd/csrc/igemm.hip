@@ -63,6 +63,10 @@ struct FParams {
   int M, HyWy, Wy, h0, hs, w0, ws;   // D[m][pix] -> Y[n][m][h0+hs*ph][w0+ws*pw]
   int act;
   float slope;
+  // split over the reduction (few-workgroup problems, e.g. the Post head: 20 x n outputs, 8192-long reduction):
+  // blockIdx.z handles chunks [z*chunks_per_split, ...) and writes raw partial sums to part[z][m][pix]
+  int ksplit, chunks_per_split;
+  float *part;
   Taps taps;
 };
 
@@ -216,10 +220,13 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
   // Software pipeline, one copy of each phase: iteration `ch` first moves the registers prefetched for
   // chunk ch into LDS, then issues the global loads of chunk ch+1 (in flight during the MFMA chain), then
   // runs the MFMA chain of chunk ch.
+  const int ch_first = p.ksplit > 1 ? blockIdx.z * p.chunks_per_split : 0;
+  int ch_last = p.ksplit > 1 ? ch_first + p.chunks_per_split : nchunks;
+  if (ch_last > nchunks) ch_last = nchunks;
   int2 tabv = make_int2(0, 63);
-  if (nchunks > 0) tabv = p.gtab[rbase * NB + (lane & (NB - 1))];
-  for (int ch = -1; ch < nchunks; ++ch) {
-    if (ch >= 0) {
+  if (ch_first < ch_last) tabv = p.gtab[ch_first * BK + rbase * NB + (lane & (NB - 1))];
+  for (int ch = ch_first - 1; ch < ch_last; ++ch) {
+    if (ch >= ch_first) {
 #ifndef LSPS_ABL_NOBAR
       __syncthreads();
 #endif
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
 #endif
     }
 #ifdef LSPS_ABL_NOLOAD
-    if (ch + 1 < nchunks) {
+    if (ch + 1 < ch_last) {
 #pragma unroll
       for (int i = 0; i < A4; ++i) areg[i] = (f32x4){1.f, 2.f, 3.f, (float)ch};
 #pragma unroll
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
     }
     if (false) {
 #else
-    if (ch + 1 < nchunks) {
+    if (ch + 1 < ch_last) {
 #endif
       const int k0 = (ch + 1) * BK;
 #pragma unroll
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
         tabv = p.gtab[nk + rbase * NB + (lane & (NB - 1))];
       }
     }
-    if (ch >= 0) {
+    if (ch >= ch_first) {
 #pragma unroll 8
       for (int kk = 0; kk < BK / 2; ++kk) {
         float a[WM], b[WN];
@@ -297,6 +304,22 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
   }
 
   // ---- epilogue: lane holds pixel column l31 of each 32x32 tile, rows (r&3)+8*(r>>2)+4*half
+  if (p.ksplit > 1) {                       // raw partial sums; bias / activation are applied by the reducer
+    float *part = p.part + (long)blockIdx.z * p.M * p.NPIX;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const long Jo = (long)blockIdx.x * BN + (wn * WN + j) * 32 + l31;
+      if (Jo >= p.NPIX) continue;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (m < p.M) part[(long)m * p.NPIX + Jo] = acc[i][j][r];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const long Jo = (long)blockIdx.x * BN + (wn * WN + j) * 32 + l31;
@@ -321,6 +344,22 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
 }
 
 
+
+// y[n][m][p] = act(bias[m] + sum_z part[z][m][n*P + p])   (forward direction only: contiguous output lattice)
+__global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias,
+                                                            float *__restrict__ y, int M, int P, long NPIX, int ksplit,
+                                                            int act, float slope) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // over [M][NPIX]
+  if (idx >= (long)M * NPIX) return;
+  const int m = (int)(idx / NPIX);
+  const long pix = idx - (long)m * NPIX;
+  float s = 0.f;
+  for (int z = 0; z < ksplit; ++z) s += part[(long)z * M * NPIX + idx];
+  if (bias) s += bias[m];
+  const long n = pix / P, pp = pix - n * P;
+  y[(n * M + m) * P + pp] = apply_act(s, act, slope);
+}
+
 // -------------------------------------------------------------------------------------------
 // F kernel specialised for the dominant layer class: 3x3 taps, stride 1, pad 1, image width 32
 // (the 28 residual convs = 88 % of the generator's MACs, forward and dgrad).
@@ -330,69 +369,73 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
 // offsets.  Tile: 128 output channels x 128 pixels (4 full image rows), chunk = CC*9 reduction rows.
 // -------------------------------------------------------------------------------------------
 #define F3_CC 8
-#define F3_ROWS 6                 // 4 output rows + top/bottom halo
 #define F3_LDW 34                 // 32 pixels + left/right halo column (always zero: W == 32, pad == 1)
-#define F3_CH (F3_ROWS * F3_LDW)  // 204 floats per channel
 
 struct F3Params {
   const float *X, *Wp, *bias, *zero;
   float *Y;
-  int Cx, H, M, Mp, NT;          // NT = N * (H/4) pixel tiles
-  int tiles_per_img;             // H / 4
+  int Cx, H, M, Mp, NT;          // NT = N * (H/TR) pixel tiles
+  int tiles_per_img;             // H / TR
   int act;
   float slope;
 };
 
+// TR = output rows per tile: 4 (tile 128 ch x 128 px, waves 2x2, each 64 ch x 64 px) or, when that grid would
+// leave CUs idle (estimate modes run the generator on 8 samples), 2 (128 ch x 64 px, waves 4x1, each 32 ch x 64 px).
+template <int TR>
 __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
   constexpr int BM = 128, RC = F3_CC * 9;            // 72 reduction rows per chunk
   constexpr int A4 = RC * BM / 4 / 256;              // 9 float4 of weights per thread per chunk
-  __shared__ __attribute__((aligned(16))) float lds[RC * BM + F3_CC * F3_CH];
+  constexpr int ROWS = TR + 2, CH = ROWS * F3_LDW;   // staged rows incl. halo; floats per channel
+  constexpr int B4 = (F3_CC * ROWS * 8 + 255) / 256; // float4 of input per thread per chunk (2 or 1)
+  constexpr int WM = TR == 4 ? 2 : 1;                // MFMA row tiles per wave
+  __shared__ __attribute__((aligned(16))) float lds[RC * BM + F3_CC * CH];
   float *As = lds, *Bs = lds + RC * BM;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.y * BM;
   const int n = blockIdx.x / p.tiles_per_img;
-  const int row0 = (blockIdx.x - n * p.tiles_per_img) * 4;       // first output row of the tile
+  const int row0 = (blockIdx.x - n * p.tiles_per_img) * TR;      // first output row of the tile
   const int HW = p.H * 32;
   const float *xn = p.X + (long)n * p.Cx * HW;
 
   // zero the halo columns once (never overwritten): cols 0 and 33 of every (channel,row)
-  if (tid < F3_CC * F3_ROWS * 2) {
+  if (tid < F3_CC * ROWS * 2) {
     const int rr = tid >> 1;
     Bs[rr * F3_LDW + (tid & 1) * 33] = 0.f;
   }
 
-  // B staging assignment: 48 (channel,row) lines of 32 pixels = 384 float4; thread handles u = tid, tid+256
-  int b_lds[2];
-  long b_off[2];
-  bool b_use[2], b_ok[2];
+  // B staging assignment: F3_CC*ROWS (channel,row) lines of 32 pixels = 8 float4 each
+  int b_lds[B4];
+  long b_off[B4];
+  bool b_use[B4], b_ok[B4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < B4; ++i) {
     const int u = tid + 256 * i;
-    b_use[i] = u < F3_CC * F3_ROWS * 8;
+    b_use[i] = u < F3_CC * ROWS * 8;
     const int line = u >> 3, c4 = u & 7;
-    const int ch = line / F3_ROWS, r = line - ch * F3_ROWS;
+    const int ch = line / ROWS, r = line - ch * ROWS;
     const int img_row = row0 - 1 + r;
     b_ok[i] = b_use[i] && img_row >= 0 && img_row < p.H;
-    b_lds[i] = ch * F3_CH + r * F3_LDW + 1 + c4 * 4;
+    b_lds[i] = ch * CH + r * F3_LDW + 1 + c4 * 4;
     b_off[i] = (long)ch * HW + (long)img_row * 32 + c4 * 4;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[WM][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 areg[A4], breg[2];
+  f32x4 areg[A4], breg[B4];
   const int nchunks = p.Cx / F3_CC;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = TR == 4 ? (wave >> 1) : wave, wn = TR == 4 ? (wave & 1) : 0;
   const int l31 = lane & 31, half = lane >> 5;
-  const float *Ap = As + half * BM + wm * 64 + l31;
-  const float *Bp = Bs + half * F3_CH + wn * 2 * F3_LDW + l31;
+  const float *Ap = As + half * BM + wm * WM * 32 + l31;
+  const float *Bp = Bs + half * CH + wn * 2 * F3_LDW + l31;
 
   for (int ch = -1; ch < nchunks; ++ch) {
     if (ch >= 0) {
@@ -403,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
         *reinterpret_cast<f32x4 *>(As + u * 4) = areg[i];          // tile rows are contiguous: [72][128]
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < B4; ++i)
         if (b_use[i]) {
           float *d = Bs + b_lds[i];
           d[0] = breg[i][0];
@@ -423,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
       }
       const float *xc = xn + (long)(ch + 1) * F3_CC * HW;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < B4; ++i) {
         const float *src = b_ok[i] ? (xc + b_off[i]) : p.zero;     // masked rows read the zero slot
         breg[i] = *reinterpret_cast<const f32x4 *>(src);
       }
@@ -435,13 +478,13 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
 #pragma unroll
         for (int cp = 0; cp < F3_CC / 2; ++cp) {                   // channel pair (2cp, 2cp+1): k = half
           const int kk = t * (F3_CC / 2) + cp;                     // k-step: reduction rows 2kk, 2kk+1
-          float a[2], b[2];
+          float a[WM], b[2];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) a[i] = Ap[2 * kk * BM + i * 32];
+          for (int i = 0; i < WM; ++i) a[i] = Ap[2 * kk * BM + i * 32];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) b[j] = Bp[2 * cp * F3_CH + (j + tr) * F3_LDW + ts];
+          for (int j = 0; j < 2; ++j) b[j] = Bp[2 * cp * CH + (j + tr) * F3_LDW + ts];
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
@@ -455,10 +498,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
   for (int j = 0; j < 2; ++j) {
     float *yb = p.Y + (long)n * p.M * HW + (long)(row0 + wn * 2 + j) * 32 + l31;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (m < p.M) {
           float v = acc[i][j][r];
           if (p.bias) v += p.bias[m];
@@ -882,7 +925,7 @@ static int launch_pack(const float *W, void *cls, int M, int Mp, int RED, int RE
 
 static int launch_f(const FParams &p, int cfg, hipStream_t st) {
   const int BM = cfg_bm(cfg), BN = cfg_bn(cfg);
-  dim3 grid(ceil_div(p.NPIX, BN), ceil_div(p.M, BM));
+  dim3 grid(ceil_div(p.NPIX, BN), ceil_div(p.M, BM), p.ksplit > 1 ? p.ksplit : 1);
   if (grid.x == 0 || grid.y == 0) return 0;
   if (cfg == 0)
     hipLaunchKernelGGL((igemm_f_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
@@ -938,11 +981,15 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   p.H = H;
   p.M = M;
   p.Mp = Mp;
-  p.tiles_per_img = H / 4;
+  const int tr = ((long)N * (H / 4) * (Mp / 128) >= 512) ? 4 : 2;   // small batches: 2-row tiles, twice the workgroups
+  p.tiles_per_img = H / tr;
   p.NT = N * p.tiles_per_img;
   p.act = act;
   p.slope = slope;
-  hipLaunchKernelGGL(igemm_f3x3_kernel, dim3(p.NT, Mp / 128), dim3(256), 0, st, p);
+  if (tr == 4)
+    hipLaunchKernelGGL(igemm_f3x3_kernel<4>, dim3(p.NT, Mp / 128), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(igemm_f3x3_kernel<2>, dim3(p.NT, Mp / 128), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_f3x3");
   return 0;
 }
@@ -1002,7 +1049,27 @@ static int run_forward_dir(const float *in, const float *W, const float *bias, f
   p.act = act;
   p.slope = slope;
   fill_taps(p.taps, l, Wb);
-  return launch_f(p, choose_cfg(M, p.NPIX), st);
+  const int cfg = choose_cfg(M, p.NPIX);
+  const long wgs = (long)ceil_div(p.NPIX, cfg_bn(cfg)) * ceil_div(M, cfg_bm(cfg));
+  const int nchunks = REDp / BK_F;
+  if (wgs <= 64 && nchunks >= 32) {          // a handful of workgroups with a long reduction: split it
+    int ks = (int)(256 / wgs);
+    if (ks > nchunks / 4) ks = nchunks / 4;
+    const size_t part_bytes = (size_t)ks * M * p.NPIX * sizeof(float);
+    if (ks > 1 && need + part_bytes <= ws_bytes) {
+      p.ksplit = ks;
+      p.chunks_per_split = ceil_div(nchunks, ks);
+      p.part = (float *)((char *)ws + need);
+      rc = launch_f(p, cfg, st);
+      if (rc) return rc;
+      const long total = (long)M * p.NPIX;
+      hipLaunchKernelGGL(ksplit_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float *)p.part, bias,
+                         out, M, p.P, (long)p.NPIX, ks, act, slope);
+      LSPS_CHECK_LAUNCH("ksplit_reduce");
+      return 0;
+    }
+  }
+  return launch_f(p, cfg, st);
 }
 
 // "transposed direction": in = small image [N][Cs][Hs][Ws], out = big image [N][Cb][Hb][Wb]
@@ -1251,7 +1318,7 @@ static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int W
     const size_t w3 = w3x3_ws_bytes(N, Cs, Cb, Hb);
     if (w3 > m) m = w3;
   }
-  return 2 * BIAS_WS_BYTES + m + 1024;
+  return 2 * BIAS_WS_BYTES + m + ((size_t)8 << 20) + 1024;   // + 8 MiB: reduction-split partials of tiny forward problems
 }
 
 static bool conv_args_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
