@@ -152,3 +152,142 @@ class LeakyReLULinear(nn.Module):
 
     def forward(self, x):
         return self.model[0](x)
+
+
+# ---------------------------------------------------------------------------------------------
+# Variants that no shipped config instantiates (reference: common_net.py:42-135,183-379).  The ones that
+# can be expressed with the kernels of the hot path are thin compositions of them; BatchNorm- / ReLU- /
+# cv2-based ones keep their names in the namespace (the drop-in contract) but refuse
+# construction: there is no HIP kernel behind them and no silent torch fallback.
+# ---------------------------------------------------------------------------------------------
+class Conv2dGrouped(nn.Module):
+    """Grouped 3x3 conv of the ResNeXt block (common_net.py:116): weight (n_out, n_in/groups, k, k).
+    Runs one lsps_conv2d launch per group on a contiguous channel slice (copy = glue; variant is unused)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride=1, padding=0, groups=1, bias=True):
+        super(Conv2dGrouped, self).__init__()
+        assert n_in % groups == 0 and n_out % groups == 0
+        self.stride, self.padding, self.groups = stride, padding, groups
+        self.weight = nn.Parameter(torch.empty(n_out, n_in // groups, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(n_out)) if bias else None
+        _default_reset(self.weight, self.bias, (n_in // groups) * kernel_size * kernel_size)
+
+    def forward(self, x, use_bias=True):
+        g = self.groups
+        cin, cout = x.size(1) // g, self.weight.size(0) // g
+        outs = []
+        for i in range(g):
+            b = self.bias[i * cout:(i + 1) * cout] if (use_bias and self.bias is not None) else None
+            outs.append(ops.conv2d(x[:, i * cin:(i + 1) * cin].contiguous(), self.weight[i * cout:(i + 1) * cout], b,
+                                   self.stride, self.padding))
+        return torch.cat(outs, 1)
+
+
+class LeakyINSResNeXtBlock(nn.Module):
+    """x + IN(conv1x1(LReLU(IN(gconv3x3(LReLU(IN(conv1x1(x)))))))) (common_net.py:111-132)."""
+
+    def __init__(self, inplanes, planes, k=2, cardinality=8, dropout=0.0):
+        super(LeakyINSResNeXtBlock, self).__init__()
+        if dropout > 0:
+            raise NotImplementedError("res_dropout_ratio > 0 is not used by the shipped configs")
+        self.model = nn.Sequential(
+            Conv2d(inplanes, k * inplanes, 1, 1, 0), _Fused('InstanceNorm2d'), _Fused('LeakyReLU'),
+            Conv2dGrouped(k * inplanes, k * inplanes, 3, 1, 1, groups=cardinality), _Fused('InstanceNorm2d'),
+            _Fused('LeakyReLU'), Conv2d(k * inplanes, planes, 1, 1, 0), _Fused('InstanceNorm2d + residual add'))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        c1, c2, c3 = self.model[0], self.model[3], self.model[6]
+        h = ops.instance_norm_(ops.conv2d(x, c1.weight, None, 1, 0), None, LRELU_SLOPE)   # biases cancel under IN
+        h = ops.instance_norm_(c2(h, use_bias=False), None, LRELU_SLOPE)
+        return ops.instance_norm_(ops.conv2d(h, c3.weight, None, 1, 0), x, -1.0)
+
+
+class LeakyReLUINSConv2d(nn.Module):
+    """LReLU(IN(conv(x))) (common_net.py:324-335)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0):
+        super(LeakyReLUINSConv2d, self).__init__()
+        self.model = nn.Sequential(Conv2d(n_in, n_out, kernel_size, stride, padding), _Fused('InstanceNorm2d'),
+                                   _Fused('LeakyReLU'))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        c = self.model[0]
+        return ops.instance_norm_(ops.conv2d(x, c.weight, None, c.stride, c.padding), None, LRELU_SLOPE)
+
+
+class LeakyReLUINSConvTranspose2d(nn.Module):
+    """LReLU(IN(conv_transpose(x))) (common_net.py:337-349)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding, output_padding):
+        super(LeakyReLUINSConvTranspose2d, self).__init__()
+        self.model = nn.Sequential(ConvTranspose2d(n_in, n_out, kernel_size, stride, padding, output_padding),
+                                   _Fused('InstanceNorm2d'), _Fused('LeakyReLU'))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        c = self.model[0]
+        y = ops.conv_transpose2d(x, c.weight, None, c.stride, c.padding, c.output_padding)
+        return ops.instance_norm_(y, None, LRELU_SLOPE)
+
+
+class LeakyReLUResBlock(nn.Module):
+    """x + conv(LReLU(conv(x))) (common_net.py:201-215; both convs map n_in -> n_out as in the reference)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0):
+        super(LeakyReLUResBlock, self).__init__()
+        self.model = nn.Sequential(Conv2d(n_in, n_out, kernel_size, stride, padding, act=ACT_LRELU), _Fused('LeakyReLU'),
+                                   Conv2d(n_in, n_out, kernel_size, stride, padding))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        return ops.axpy(self.model[2](self.model[0](x)), x, 1.0)
+
+
+class Bias2d(nn.Module):
+    """Per-channel bias (common_net.py:92-103)."""
+
+    def __init__(self, channels):
+        super(Bias2d, self).__init__()
+        self.bias = nn.Parameter(torch.empty(channels).normal_(0, 0.002))
+
+    def forward(self, x):
+        return x + self.bias.view(1, -1, 1, 1)
+
+
+class GaussianVAE(nn.Module):
+    """mu / softplus(sd) heads (common_net.py:42-65)."""
+
+    def __init__(self, n_in, n_out):
+        super(GaussianVAE, self).__init__()
+        self.en_mu, self.en_sigma = Linear(n_in, n_out), Linear(n_in, n_out, act=ops.ACT_SOFTPLUS)
+        for m in (self.en_mu, self.en_sigma):
+            m.weight.data.normal_(0, 0.002)
+            m.bias.data.normal_(0, 0.002)
+
+    def forward(self, x):
+        return self.en_mu(x), self.en_sigma(x)
+
+    def sample(self, x, noise=None):
+        mu, sd = self.forward(x)
+        if noise is None:
+            noise = torch.randn(mu.size(), device=mu.device, dtype=mu.dtype)
+        return mu + sd * noise, mu, sd
+
+
+def _unbuilt(name, why):
+    def __init__(self, *a, **k):
+        raise NotImplementedError("%s is not instantiated by any shipped LSPS config and has no HIP kernel here (%s)"
+                                  % (name, why))
+    return type(name, (nn.Module,), {'__init__': __init__, '__doc__': 'Placeholder for the reference class %s.' % name})
+
+
+for _n, _why in (('GaussianSmoother', 'needs cv2'), ('GaussianVAE2D', 'conv + Softplus epilogue'),
+                 ('INSResBlock', 'ReLU after InstanceNorm'), ('ReLUINSConv2d', 'ReLU after InstanceNorm'),
+                 ('ReLUINSConvTranspose2d', 'ReLU after InstanceNorm'), ('LeakyReLUBNNSResBlock', 'BatchNorm'),
+                 ('LeakyReLUBNLinear', 'BatchNorm'), ('LeakyReLUBNConv2d', 'BatchNorm'),
+                 ('LeakyReLUBNConvTranspose2d', 'BatchNorm'), ('LeakyReLUBNNSConv2d', 'BatchNorm'),
+                 ('LeakyReLUBNNSConvTranspose2d', 'BatchNorm')):
+    globals()[_n] = _unbuilt(_n, _why)
+del _n, _why

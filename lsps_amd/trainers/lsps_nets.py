@@ -9,7 +9,8 @@ import torch.nn as nn
 
 from .common_net import *  # noqa: F401,F403
 from .common_net import (ACT_LRELU, ACT_NONE, ACT_TANH, Conv2d, ConvTranspose2d, GaussianNoiseLayer,
-                         LeakyINSResBlock, LeakyReLUConv2d, LeakyReLUConvTranspose2d, LeakyReLULinear, Linear, _Fused)
+                         LeakyINSResBlock, LeakyINSResNeXtBlock, LeakyReLUConv2d, LeakyReLUConvTranspose2d,
+                         LeakyReLULinear, Linear, _Fused)
 from .. import ops
 from ..ops import ACT_SOFTPLUS
 
@@ -162,11 +163,15 @@ class SharedResGen(_Net):
     block + Gaussian noise -> shared latent -> shared residual block -> per-domain decoders
     (residual blocks, 3x3 stride-2 transposed convs, 1x1 transposed conv + tanh) (lsps_nets.py:164-272)."""
 
+    def _res_block(self, tch, params):
+        return LeakyINSResBlock(tch, tch)
+
     def __init__(self, params):
         super(SharedResGen, self).__init__()
         ch = params['ch']
         if params.get('res_dropout_ratio', 0):
             raise NotImplementedError("res_dropout_ratio > 0 is not used by the shipped configs")
+        res_block = lambda tch: self._res_block(tch, params)   # noqa: E731
 
         def encoder(input_dim):
             layers = [LeakyReLUConv2d(input_dim, ch, kernel_size=7, stride=1, padding=3)]
@@ -174,11 +179,11 @@ class SharedResGen(_Net):
             for _ in range(1, params['n_enc_front_blk']):
                 layers.append(LeakyReLUConv2d(tch, tch * 2, kernel_size=3, stride=2, padding=1))
                 tch *= 2
-            layers += [LeakyINSResBlock(tch, tch) for _ in range(params['n_enc_res_blk'])]
+            layers += [res_block(tch) for _ in range(params['n_enc_res_blk'])]
             return nn.Sequential(*layers), tch
 
         def decoder(tch, output_dim):
-            layers = [LeakyINSResBlock(tch, tch) for _ in range(params['n_gen_res_blk'])]
+            layers = [res_block(tch) for _ in range(params['n_gen_res_blk'])]
             for _ in range(1, params['n_gen_front_blk']):
                 layers.append(LeakyReLUConvTranspose2d(tch, tch // 2, kernel_size=3, stride=2, padding=1,
                                                        output_padding=1))
@@ -189,9 +194,9 @@ class SharedResGen(_Net):
 
         self.encode_A, tch = encoder(params['input_dim_a'])
         self.encode_B, tch = encoder(params['input_dim_b'])
-        self.enc_shared = nn.Sequential(*([LeakyINSResBlock(tch, tch) for _ in range(params['n_enc_shared_blk'])]
+        self.enc_shared = nn.Sequential(*([res_block(tch) for _ in range(params['n_enc_shared_blk'])]
                                           + [GaussianNoiseLayer()]))
-        self.dec_shared = nn.Sequential(*[LeakyINSResBlock(tch, tch) for _ in range(params['n_gen_shared_blk'])])
+        self.dec_shared = nn.Sequential(*[res_block(tch) for _ in range(params['n_gen_shared_blk'])])
         self.decode_A = decoder(tch, params['input_dim_a'])
         self.decode_B = decoder(tch, params['input_dim_b'])
 
@@ -223,3 +228,13 @@ class SharedResGen(_Net):
     def forward_b2a(self, x_B, noise=None):
         shared = self._enc_shared(self.encode_B(x_B), noise)
         return self.decode_A(self.dec_shared(shared)), shared
+
+
+class SharedResXGen(SharedResGen):
+    """SharedResGen with ResNeXt residual blocks (1x1 expand, grouped 3x3, 1x1 project; lsps_nets.py:277-387).
+    Same topology, methods and state-dict keys as the reference class; not used by the shipped configs."""
+
+    def _res_block(self, tch, params):
+        k = params['n_resnext_k'] if 'n_resnext_k' in params.keys() else 1
+        c = params['n_resnext_c'] if 'n_resnext_c' in params.keys() else 4
+        return LeakyINSResNeXtBlock(tch, tch, k=k, cardinality=c)

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from .lsps_nets import *  # noqa: F401,F403
-from .lsps_nets import Mapping, SharedDis, SharedResGen, poseVAE
+from .lsps_nets import Mapping, SharedDis, SharedResGen, SharedResXGen, poseVAE
 from .helpers import get_model_list, _compute_fake_acc, _compute_true_acc  # noqa: F401
 from .init import *  # noqa: F401,F403
 from .init import gaussian_weights_init
@@ -28,7 +28,8 @@ from .. import dist as lsps_dist
 from .. import ops
 from ..optim import FlatAdam
 
-_NETS = {'Mapping': Mapping, 'poseVAE': poseVAE, 'SharedDis': SharedDis, 'SharedResGen': SharedResGen}
+_NETS = {'Mapping': Mapping, 'poseVAE': poseVAE, 'SharedDis': SharedDis, 'SharedResGen': SharedResGen,
+         'SharedResXGen': SharedResXGen}
 
 
 def _net(spec):

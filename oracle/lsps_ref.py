@@ -60,8 +60,22 @@ class ParamTable(object):
             v.grad = None
 
 
+def _res_block_shapes(s, prefix, t, cfg):
+    """Residual block parameters: LeakyINSResBlock (common_net.py:160-175) or, for SharedResXGen,
+    LeakyINSResNeXtBlock (common_net.py:111-126: 1x1 expand, grouped 3x3, 1x1 project)."""
+    if cfg.get('name') == 'SharedResXGen':
+        k, g = cfg.get('n_resnext_k', 1), cfg.get('n_resnext_c', 4)
+        s[prefix + '.model.0.weight'], s[prefix + '.model.0.bias'] = (k * t, t, 1, 1), (k * t,)
+        s[prefix + '.model.3.weight'], s[prefix + '.model.3.bias'] = (k * t, k * t // g, 3, 3), (k * t,)
+        s[prefix + '.model.6.weight'], s[prefix + '.model.6.bias'] = (t, k * t, 1, 1), (t,)
+    else:
+        for m in (0, 3):
+            s['%s.model.%d.weight' % (prefix, m)] = (t, t, 3, 3)
+            s['%s.model.%d.bias' % (prefix, m)] = (t,)
+
+
 def gen_shapes(cfg):
-    """Key/shape list of SharedResGen (lsps_nets.py:164-237)."""
+    """Key/shape list of SharedResGen / SharedResXGen (lsps_nets.py:164-237, 277-355)."""
     ch = cfg['ch']
     s = OrderedDict()
     for d, cin in (('A', cfg['input_dim_a']), ('B', cfg['input_dim_b'])):
@@ -75,22 +89,16 @@ def gen_shapes(cfg):
             t *= 2
         i = cfg['n_enc_front_blk']
         for j in range(cfg['n_enc_res_blk']):                                # :194-196
-            for m in (0, 3):
-                s['encode_%s.%d.model.%d.weight' % (d, i + j, m)] = (t, t, 3, 3)
-                s['encode_%s.%d.model.%d.bias' % (d, i + j, m)] = (t,)
+            _res_block_shapes(s, 'encode_%s.%d' % (d, i + j), t, cfg)
     tch = t
     for grp, n in (('enc_shared', cfg['n_enc_shared_blk']), ('dec_shared', cfg['n_gen_shared_blk'])):
         for j in range(n):                                                   # :203-209
-            for m in (0, 3):
-                s['%s.%d.model.%d.weight' % (grp, j, m)] = (tch, tch, 3, 3)
-                s['%s.%d.model.%d.bias' % (grp, j, m)] = (tch,)
+            _res_block_shapes(s, '%s.%d' % (grp, j), tch, cfg)
     for d, cout in (('A', cfg['input_dim_a']), ('B', cfg['input_dim_b'])):
         t = tch
         i = 0
         for j in range(cfg['n_gen_res_blk']):                                # :218-220
-            for m in (0, 3):
-                s['decode_%s.%d.model.%d.weight' % (d, i, m)] = (t, t, 3, 3)
-                s['decode_%s.%d.model.%d.bias' % (d, i, m)] = (t,)
+            _res_block_shapes(s, 'decode_%s.%d' % (d, i), t, cfg)
             i += 1
         for j in range(1, cfg['n_gen_front_blk']):                           # :222-225 (ConvTranspose: C_in,C_out,R,S)
             s['decode_%s.%d.model.0.weight' % (d, i)] = (t, t // 2, 3, 3)
@@ -190,6 +198,16 @@ def leaky_ins_res_block(x, p, key):
     return x + instance_norm(h)
 
 
+def leaky_ins_resnext_block(x, p, key, groups):
+    """LeakyINSResNeXtBlock (common_net.py:111-132)."""
+    h = F.conv2d(x, p[key + '.model.0.weight'], p[key + '.model.0.bias'])
+    h = F.leaky_relu(instance_norm(h), LRELU_SLOPE)
+    h = F.conv2d(h, p[key + '.model.3.weight'], p[key + '.model.3.bias'], padding=1, groups=groups)
+    h = F.leaky_relu(instance_norm(h), LRELU_SLOPE)
+    h = F.conv2d(h, p[key + '.model.6.weight'], p[key + '.model.6.bias'])
+    return x + instance_norm(h)
+
+
 # --------------------------------------------------------------------------------------
 # nets (lsps_nets.py)
 # --------------------------------------------------------------------------------------
@@ -200,6 +218,11 @@ class RefGen(ParamTable):
         super(RefGen, self).__init__(gen_shapes(cfg))
         self.cfg = cfg
         self.training = True
+        if cfg.get('name') == 'SharedResXGen':                    # lsps_nets.py:277-387
+            g = cfg.get('n_resnext_c', 4)
+            self._block = lambda h, p, key: leaky_ins_resnext_block(h, p, key, g)
+        else:
+            self._block = leaky_ins_res_block
 
     def _enc_front(self, d, x):                                  # encode_A / encode_B
         c, p = self.cfg, self.p
@@ -207,26 +230,26 @@ class RefGen(ParamTable):
         for i in range(1, c['n_enc_front_blk']):
             h = lrelu_conv(h, p, 'encode_%s.%d.model.0' % (d, i), 2, 1)
         for j in range(c['n_enc_res_blk']):
-            h = leaky_ins_res_block(h, p, 'encode_%s.%d' % (d, c['n_enc_front_blk'] + j))
+            h = self._block(h, p, 'encode_%s.%d' % (d, c['n_enc_front_blk'] + j))
         return h
 
     def _enc_shared(self, h, noise):                             # enc_shared (+ GaussianNoiseLayer, common_net.py:32-40)
         for j in range(self.cfg['n_enc_shared_blk']):
-            h = leaky_ins_res_block(h, self.p, 'enc_shared.%d' % j)
+            h = self._block(h, self.p, 'enc_shared.%d' % j)
         if self.training:
             h = h + (torch.randn(h.shape) if noise is None else noise)
         return h
 
     def _dec_shared(self, h):
         for j in range(self.cfg['n_gen_shared_blk']):
-            h = leaky_ins_res_block(h, self.p, 'dec_shared.%d' % j)
+            h = self._block(h, self.p, 'dec_shared.%d' % j)
         return h
 
     def _dec_front(self, d, h):                                  # decode_A / decode_B
         c, p = self.cfg, self.p
         i = 0
         for j in range(c['n_gen_res_blk']):
-            h = leaky_ins_res_block(h, p, 'decode_%s.%d' % (d, i))
+            h = self._block(h, p, 'decode_%s.%d' % (d, i))
             i += 1
         for j in range(1, c['n_gen_front_blk']):
             h = lrelu_convT(h, p, 'decode_%s.%d.model.0' % (d, i), 2, 1, 1)

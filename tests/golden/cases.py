@@ -79,6 +79,7 @@ def dead_bias_keys(golden):
         if nme.endswith('.model.3.bias'):
             dead.add(nme)
             dead.add(nme[:-len('.model.3.bias')] + '.model.0.bias')
+            dead.add(nme[:-len('.model.3.bias')] + '.model.6.bias')      # ResNeXt block: third conv, also under IN
     return dead
 
 
@@ -287,6 +288,28 @@ def run_module_cases(A, config, shapes_mod, with_map=True):
     R['vae.decode'] = OrderedDict(pose=A.vae_decode(tr, zp))
     if with_map and config == 'tiny':
         R['map.forward'] = OrderedDict(out=A.map_forward(tr, zp))
+    return R
+
+
+def run_resx_cases(A, shapes_mod):
+    """SharedResXGen (ResNeXt generator, lsps_nets.py:277-387; unused by the shipped configs): forward in eval
+    and one pretrain iteration, tiny width, k=2, cardinality 4."""
+    hp = hp_for('tiny')
+    hp['gen'] = dict(hp['gen'], name='SharedResXGen', n_resnext_k=2, n_resnext_c=4)
+    sds = make_weights(hp, shapes_mod)
+    tr = A.make_trainer(hp, sds)
+    n = 2
+    b = make_inputs(n)
+    R = OrderedDict()
+    A.set_train(tr, False)
+    R['resx.forward.eval'] = OrderedDict(zip(('x_aa', 'x_ba', 'x_ab', 'x_bb', 'shared'),
+                                             A.gen_forward(tr, b['xa'], b['xb'], None)))
+    A.set_train(tr, True)
+    lat2, lat1 = latent_shape(hp, 2 * n), latent_shape(hp, n)
+    A.dis_update(tr, b, hp, noise(lat2, 1100))
+    A.gen_update(tr, b, hp, (noise(lat2, 1200), noise(lat1, 1300), noise(lat1, 1400)))
+    R['resx.pretrain.scalars'] = A.scalars(tr)
+    _grad_digest(R, 'resx.pretrain.gen_update.grads', A, tr, 'gen')
     return R
 
 

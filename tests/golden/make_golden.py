@@ -183,6 +183,8 @@ def main(which):
         R = OrderedDict()
         R.update(cases.run_module_cases(A, config, shapes))
         R.update(cases.run_step_cases(A, config, shapes))
+        if config == 'tiny':
+            R.update(cases.run_resx_cases(A, shapes))
         flat = cases.flatten(R)
         path = os.path.join(HERE, 'golden_%s.npz' % config)
         np.savez_compressed(path, **flat)

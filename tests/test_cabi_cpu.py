@@ -45,10 +45,17 @@ def test_argument_validation_without_gpu():
 
 def test_namespace_matches_reference_package():
     import lsps_amd.trainers as t
-    for name in ('LSPSTrainer', 'SharedResGen', 'SharedDis', 'poseVAE', 'Mapping', 'LeakyINSResBlock',
-                 'LeakyReLUConv2d', 'LeakyReLUConvTranspose2d', 'LeakyReLULinear', 'GaussianNoiseLayer',
+    # every public name of the reference's `from trainers import *` (probed list)
+    for name in ('LSPSTrainer', 'SharedResGen', 'SharedResXGen', 'SharedDis', 'poseVAE', 'Mapping', 'Bias2d',
+                 'GaussianNoiseLayer', 'GaussianSmoother', 'GaussianVAE', 'GaussianVAE2D', 'INSResBlock',
+                 'LeakyINSResBlock', 'LeakyINSResNeXtBlock', 'LeakyReLUBNConv2d', 'LeakyReLUBNConvTranspose2d',
+                 'LeakyReLUBNLinear', 'LeakyReLUBNNSConv2d', 'LeakyReLUBNNSConvTranspose2d', 'LeakyReLUBNNSResBlock',
+                 'LeakyReLUConv2d', 'LeakyReLUConvTranspose2d', 'LeakyReLUINSConv2d', 'LeakyReLUINSConvTranspose2d',
+                 'LeakyReLULinear', 'LeakyReLUResBlock', 'ReLUINSConv2d', 'ReLUINSConvTranspose2d',
                  'gaussian_weights_init', 'xavier_weights_init', 'get_model_list', 'Variable', 'torch', 'nn', 'os', 'np'):
         assert hasattr(t, name), name
+    with pytest.raises(NotImplementedError):      # BatchNorm / ReLU variants: named, but no silent torch fallback
+        t.LeakyReLUBNConv2d(1, 2, 3, 1)
 
 
 @pytest.mark.parametrize("cfg", ["nnyu", "nicvl"])

@@ -35,6 +35,17 @@ def test_oracle_steps_match_reference(config, golden):
     assert not bad, "worst=%g first failures: %s" % (worst, bad[:5])
 
 
+def test_oracle_resnext_generator_matches_reference(golden):
+    torch.set_num_threads(8)
+    A = cases.NativeAdapter(lsps_ref, 'cpu')
+    R = cases.run_resx_cases(A, lsps_ref)
+    g = {k: v for k, v in golden('tiny').items() if k.split('/')[0] in R}
+    assert g, "no golden entries"
+    # three LeakyReLU/InstanceNorm stages per block at 8-64 channels: gradients are even more kink-sensitive
+    bad, worst = cases.compare(R, g, 1e-3, grad_rtol=5e-2)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:5])
+
+
 def test_shape_tables_match_reference_keys(golden):
     """State-dict key sets / shapes equal the reference's (80/20/10/8 tensors)."""
     hp = cases.hp_for('full')

@@ -42,6 +42,14 @@ def test_steps_match_reference_golden(config, golden):
     assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
 
 
+def test_resnext_generator_matches_reference_golden(golden):
+    A = _adapter()
+    R = cases.run_resx_cases(A, lsps_ref)
+    g = {k: v for k, v in golden('tiny').items() if k.split('/')[0] in R}
+    bad, worst = cases.compare(R, g, RTOL, grad_rtol=5e-2)
+    assert g and not bad, "worst=%g first failures: %s" % (worst, bad[:8])
+
+
 def test_joint_readout_matches_oracle():
     """A12: regress_b -> vae.decode -> mm joints; worst-joint argmax and <=40 mm decisions identical,
     joint coordinates within 1e-3 (depth_train.py:200-253, handpose_evaluation.py:97,130-136,203)."""
