@@ -48,6 +48,8 @@ CONV_CASES = [
     (2, 8, 32, 32, 130, 3, 1, 1),       # specialised 3x3/width-32 kernel: one channel chunk, ragged M
     (5, 16, 8, 32, 128, 3, 1, 1),       # specialised kernel: H=8 (two row tiles), N not a power of two
     (1, 24, 4, 32, 200, 3, 1, 1),       # specialised kernel: a single row tile (both halos out of range)
+    (3, 1, 128, 128, 24, 7, 2, 3),      # direct 1-channel-input dgrad (discriminator stem), K not a multiple of 16
+    (2, 1, 64, 128, 16, 7, 2, 3),       # same, non-square image
     (3, 64, 8, 32, 128, 3, 1, 1),       # specialised wgrad kernel (C, K multiples of 64), few chunks
     (7, 128, 2, 32, 64, 3, 1, 1),       # specialised wgrad: one row pair per image, odd N
 ]
