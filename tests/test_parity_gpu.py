@@ -98,3 +98,52 @@ def test_full_batch_properties():
         post_big = tr.dis.regress_b(xb)[1]
         post_small = tr.dis.regress_b(xb[40:44].contiguous())[1]
         assert float((post_big[40:44] - post_small).abs().max()) <= 1e-4 * float(post_big.abs().max())
+
+
+def test_update_steps_are_bitwise_deterministic():
+    """No atomics anywhere on the path (split reductions are two-stage): the same step from the same state
+    gives bit-identical losses and weights."""
+    A = _adapter()
+    hp = cases.hp_for('tiny')
+    sds = cases.make_weights(hp, lsps_ref)
+    b = cases.make_inputs(4)
+    lat2, lat1 = cases.latent_shape(hp, 8), cases.latent_shape(hp, 4)
+    outs = []
+    for _ in range(2):
+        tr = A.make_trainer(hp, sds)
+        A.set_train(tr, True)
+        A.dis_update(tr, b, hp, cases.noise(lat2, 1))
+        A.gen_update(tr, b, hp, (cases.noise(lat2, 2), cases.noise(lat1, 3), cases.noise(lat1, 4)))
+        outs.append((A.scalars(tr), A.params(tr, 'gen'), A.params(tr, 'dis')))
+    assert outs[0][0] == outs[1][0]
+    for net in (1, 2):
+        for k in outs[0][net]:
+            assert np.array_equal(outs[0][net][k], outs[1][net][k]), k
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_ragged_batches_against_oracle(n):
+    """Edge cases the reference's code paths have: batch smaller than the [0:4] slice of post_update
+    (lsps_trainer.py:238), n == 1 (.squeeze() drops the batch axis, lsps_nets.py:139), odd batches."""
+    A = _adapter()
+    O = cases.NativeAdapter(lsps_ref, 'cpu', trainer_kwargs=dict(literal=False))
+    hp = cases.hp_for('tiny')
+    sds = cases.make_weights(hp, lsps_ref)
+    b = cases.make_inputs(n)
+    k = min(n, 4)
+    latp = cases.latent_shape(hp, 2 * k)
+    zd = hp['vae']['z_dim']
+    res = []
+    for Ad in (O, A):
+        tr = Ad.make_trainer(hp, sds)
+        Ad.set_train(tr, True)
+        mode = 3 if n != 1 else 0          # n == 1: dis.feats' split-by-4 needs >= 1 sample per domain pair
+        Ad.post_update(tr, b, mode, hp, cases.noise(latp, 5), cases.noise((n, zd), 6, 0.05), cases.noise((n, zd), 7, 0.05))
+        Ad.set_train(tr, False)
+        post = Ad.dis_regress(tr, 'b', b['xb'])[1]
+        res.append((Ad.scalars(tr), post, Ad.vae_decode(tr, post)))
+    for k_ in res[0][0]:
+        assert abs(res[0][0][k_] - res[1][0][k_]) <= 1e-3 * max(1e-6, abs(res[0][0][k_])), k_
+    assert res[0][1].shape == res[1][1].shape                     # [20] at n == 1, [n, 20] otherwise
+    assert np.abs(res[0][1] - res[1][1]).max() <= 1e-3 * np.abs(res[0][1]).max()
+    assert np.abs(res[0][2] - res[1][2]).max() <= 1e-3 * np.abs(res[0][2]).max()
