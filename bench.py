@@ -22,6 +22,7 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, 'tests', 'golden'))
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 
 
 def load_hp():
@@ -79,6 +80,8 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=128, help='samples per domain per GPU')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="'bf16': bf16 MFMA operands (f32 accumulate) in the 3x3 residual-conv kernels (BASELINE config 5)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary workloads (estimate3, fwd-only)')
     args = ap.parse_args()
@@ -109,6 +112,7 @@ def main():
         net.load_state_dict({k: torch.as_tensor(v) for k, v in synth.make_state_dict(shapes, seed).items()})
     tr.gen.train()
     tr.dis.train()
+    ops.set_math_mode(args.dtype)
     b = make_device_batch(args.batch, dev, seed_offset=rank)
 
     def pretrain_step():
@@ -152,12 +156,23 @@ def main():
         with torch.no_grad():
             t_fwd = timed(lambda: tr.gen(b['xa'], b['xb']), 3)
         tr.gen.train()
+        t_bf16 = None
+        if args.dtype == 'f32':         # BASELINE config 5 (bf16 MFMA conv path) on the same workload, for reference
+            ops.set_math_mode('bf16')
+            t_bf16 = timed(pretrain_step, 2)
+            ops.set_math_mode('f32')
         extra = {'estimate3_step_bs%d' % args.batch: {'steps_per_s': 1.0 / t_est, 'ms_per_step': 1e3 * t_est,
                                                        'algorithmic_tflop_per_step': 0.579 * args.batch / 128.0},
                  'gen_forward_bs%d' % args.batch: {'calls_per_s': 1.0 / t_fwd, 'ms_per_call': 1e3 * t_fwd,
                                                    'tflops': 7.76 * args.batch / 128.0 / t_fwd}}
+        if t_bf16:
+            extra['pretrain_step_bf16_mfma_bs%d' % args.batch] = {
+                'steps_per_s': 1.0 / t_bf16, 'ms_per_step': 1e3 * t_bf16,
+                'note': 'residual 3x3 convs on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 in registers, f32 '
+                        'accumulate, f32 tensors/statistics/Adam); NOT the headline value'}
 
     if rank == 0:
+        peak = F32_MFMA_PEAK_TFLOPS if args.dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
         dom_name = max(prof, key=lambda k: prof[k]['total_ms']) if prof else None
         dom = prof.get(dom_name)
         roofline = None
@@ -171,8 +186,8 @@ def main():
             traffic = None
         if dom:
             roofline = {'bound': 'mfma', 'kernel': dom_name + ' (implicit-GEMM conv on v_mfma_f32_32x32x2_f32)',
-                        'achieved': dom['tflops'], 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': dom['tflops'] / F32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                        'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
+                        'frac': dom['tflops'] / peak, 'traffic': traffic,
                         'traffic_note': 'HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE KB, calibrated), '
                                         'profiles/r1_traffic.json; scaled to this run\'s mean launch size',
                         'launches': dom['launches'], 'avg_launch_ms': dom['avg_ms'],
@@ -182,7 +197,7 @@ def main():
         out = {
             'metric': 'depth_train steps/sec (128x128x1, bs=128)', 'value': args.steps / elapsed, 'unit': 'steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'pretrain step = LSPSTrainer.dis_update + gen_update (enc+dec+disc+KL), exps/nnyu.yaml nets '
                                    '(gen.ch=64, dis.ch=64), synthetic NYU-shape 128x128x1 depth crops',
                        'batch_per_domain_per_gpu': args.batch, 'global_batch_per_domain': args.batch * world,

@@ -38,6 +38,13 @@ int         lsps_version(void);
 const char *lsps_last_error(void);
 /* number of compute units of the current device (used by callers to size split counts) */
 int         lsps_device_cus(void);
+/* Math mode of the 3x3 / stride-1 residual-conv kernels (process-wide): 0 = exact f32 MFMA (default);
+ * 1 = operands rounded to bf16 in registers, v_mfma_f32_32x32x16_bf16 with f32 accumulation (BASELINE config 5:
+ * "bf16 with MFMA conv path").  Tensors stay f32 in HBM in both modes.                                  */
+#define LSPS_MATH_F32  0
+#define LSPS_MATH_BF16 1
+int         lsps_set_math_mode(int mode);
+int         lsps_get_math_mode(void);
 
 /* ---- Conv2d: replaces nn.Conv2d forward + autograd's convolution_backward -----------------
  * call sites: common_net.py:250 (LeakyReLUConv2d), :162-163 (LeakyINSResBlock.conv3x3),

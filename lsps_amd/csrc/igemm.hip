@@ -38,6 +38,12 @@ void set_error(const char *fmt, ...) {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 struct defeats SROA (scratch)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Math mode of the 3x3 residual kernels: 0 = exact f32 MFMA (default), 1 = operands rounded to bf16 in registers
+// (v_cvt_pk_bf16_f32, RNE) and v_mfma_f32_32x32x16_bf16 with f32 accumulation (BASELINE config 5).  HBM and LDS
+// tensors stay f32 in both modes.
+static int g_math_mode = 0;
 
 #define LSPS_MAXT 49
 #define BK_F 32   // reduction chunk of the F kernel
@@ -382,7 +388,7 @@ struct F3Params {
 
 // TR = output rows per tile: 4 (tile 128 ch x 128 px, waves 2x2, each 64 ch x 64 px) or, when that grid would
 // leave CUs idle (estimate modes run the generator on 8 samples), 2 (128 ch x 64 px, waves 4x1, each 32 ch x 64 px).
-template <int TR>
+template <int TR, bool BF16>
 __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
   constexpr int BM = 128, RC = F3_CC * 9;            // 72 reduction rows per chunk
   constexpr int A4 = RC * BM / 4 / 256;              // 9 float4 of weights per thread per chunk
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
         breg[i] = *reinterpret_cast<const f32x4 *>(src);
       }
     }
-    if (ch >= 0) {
+    if (ch >= 0 && !BF16) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int tr = t / 3, ts = t - tr * 3;
@@ -489,6 +495,35 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
             for (int j = 0; j < 2; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+      }
+    }
+    if (ch >= 0 && BF16) {
+      // bf16 mode: one MFMA covers K = 16 = (2 taps) x (8 channels): lanes 0-31 carry tap 2g, lanes 32-63 tap
+      // 2g+1; each lane gathers its 8 channels from the SAME f32 LDS tiles and rounds them to bf16 in registers.
+      const float *A0 = As + wm * WM * 32 + l31, *B0 = Bs + wn * 2 * F3_LDW + l31;
+#pragma unroll
+      for (int g = 0; g < 5; ++g) {
+        const int t0 = 2 * g, t1 = (2 * g + 1 <= 8) ? 2 * g + 1 : 8;    // last group: upper half re-reads tap 8, B zeroed
+        const int arow = (half ? t1 : t0) * F3_CC;
+        const int boff = half ? (t1 / 3) * F3_LDW + (t1 % 3) : (t0 / 3) * F3_LDW + (t0 % 3);
+        const bool dead = (2 * g + 1 > 8) && half;
+        bf16x8 af[WM], bf[2];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)A0[(arow + e) * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = B0[e * CH + j * F3_LDW + boff];
+            bf[j][e] = (__bf16)(dead ? 0.f : v);
+          }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
     }
   }
@@ -640,6 +675,7 @@ struct W3Params {
   int nchunks, chunks_per_split; // chunk = (n, row pair)
 };
 
+template <bool BF16>
 __global__ __launch_bounds__(256, 2) void igemm_w3x3_kernel(W3Params p) {
   __shared__ __attribute__((aligned(16))) float lds[64 * W3_LDA + 64 * W3_CH];
   float *As = lds, *Bs = lds + 64 * W3_LDA;
@@ -713,7 +749,7 @@ __global__ __launch_bounds__(256, 2) void igemm_w3x3_kernel(W3Params p) {
         breg[i] = *reinterpret_cast<const f32x4 *>(src);
       }
     }
-    if (ch >= ch_begin) {
+    if (ch >= ch_begin && !BF16) {
 #pragma unroll
       for (int row = 0; row < 2; ++row) {
         const float *Ar = Ap + row * 32, *Br = Bp + row * 34;
@@ -725,6 +761,25 @@ __global__ __launch_bounds__(256, 2) void igemm_w3x3_kernel(W3Params p) {
           for (int t = 0; t < 9; ++t) b[t] = Br[(t / 3) * 34 + 2 * kq + (t % 3)];
 #pragma unroll
           for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+        }
+      }
+    }
+    if (ch >= ch_begin && BF16) {
+      // bf16 mode: K = 16 consecutive pixels of one image row per MFMA (lanes 0-31: pixels 0..7, lanes 32-63: 8..15)
+      const float *A0 = As + (wm * 32 + l31) * W3_LDA + 8 * half;
+      const float *B0 = Bs + (wn * 32 + l31) * W3_CH + 8 * half;
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {                 // 64-pixel chunk = 4 groups of 16 pixels (2 rows x 2 halves)
+        const int row = q >> 1, col = (q & 1) * 16;
+        bf16x8 af;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) af[e] = (__bf16)A0[row * 32 + col + e];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          bf16x8 bf;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bf[e] = (__bf16)B0[(row + t / 3) * 34 + col + (t % 3) + e];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
         }
       }
     }
@@ -1077,10 +1132,18 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   p.NT = N * p.tiles_per_img;
   p.act = act;
   p.slope = slope;
-  if (tr == 4)
-    hipLaunchKernelGGL(igemm_f3x3_kernel<4>, dim3(p.NT, Mp / 128), dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL(igemm_f3x3_kernel<2>, dim3(p.NT, Mp / 128), dim3(256), 0, st, p);
+  const dim3 grid(p.NT, Mp / 128);
+  if (g_math_mode == 1) {
+    if (tr == 4)
+      hipLaunchKernelGGL((igemm_f3x3_kernel<4, true>), grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((igemm_f3x3_kernel<2, true>), grid, dim3(256), 0, st, p);
+  } else {
+    if (tr == 4)
+      hipLaunchKernelGGL((igemm_f3x3_kernel<4, false>), grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((igemm_f3x3_kernel<2, false>), grid, dim3(256), 0, st, p);
+  }
   LSPS_CHECK_LAUNCH("igemm_f3x3");
   return 0;
 }
@@ -1297,7 +1360,10 @@ static int run_w3x3(const float *dy, const float *x, float *dW, int N, int C, in
   }
   p.zero = zero;
   p.part = (float *)((char *)ws + 256);
-  hipLaunchKernelGGL(igemm_w3x3_kernel, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
+  if (g_math_mode == 1)
+    hipLaunchKernelGGL(igemm_w3x3_kernel<true>, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(igemm_w3x3_kernel<false>, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_w3x3");
   const long total = (long)M * C * 9;
   hipLaunchKernelGGL(reduce_w3x3_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float *)p.part, dW, M, C,
@@ -1444,6 +1510,17 @@ extern "C" {
 
 int lsps_version(void) { return LSPS_ABI_VERSION; }
 const char *lsps_last_error(void) { return lsps::g_err; }
+
+int lsps_set_math_mode(int mode) {
+  if (mode != 0 && mode != 1) {
+    set_error("set_math_mode: mode must be 0 (f32) or 1 (bf16 MFMA operands)");
+    return LSPS_E_ARG;
+  }
+  lsps::g_math_mode = mode;
+  return 0;
+}
+
+int lsps_get_math_mode(void) { return lsps::g_math_mode; }
 
 int lsps_device_cus(void) {
   int dev = 0, cus = 0;

@@ -258,3 +258,31 @@ def test_ops_reject_cpu_tensors():
     from lsps_amd import ops, _lib
     with pytest.raises(Exception):
         ops.conv2d(torch.zeros(1, 1, 4, 4), torch.zeros(1, 1, 3, 3), None, 1, 1)
+
+
+@pytest.mark.parametrize("case", [(3, 256, 32, 32, 256, 3, 1, 1), (2, 8, 32, 32, 130, 3, 1, 1), (5, 16, 8, 32, 128, 3, 1, 1),
+                                  (3, 64, 8, 32, 128, 3, 1, 1), (7, 128, 2, 32, 64, 3, 1, 1)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv3x3_bf16_math_mode(case):
+    """BASELINE config 5: the 3x3 residual-conv kernels with bf16 MFMA operands (f32 accumulate, f32 tensors).
+    Tolerance 1e-2 of the abs-max: operands carry 8 mantissa bits (2^-9 relative rounding each)."""
+    _need_gpu()
+    from lsps_amd import ops
+    N, C, H, W, K, R, st, pad = case
+    x = _rand(N, C, H, W, seed=1).requires_grad_(True)
+    w = _rand(K, C, R, R, seed=2, scale=0.1).requires_grad_(True)
+    y_ref = F.conv2d(x, w, None, stride=st, padding=pad)
+    gy = _rand(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+    xd, wd = (t.detach().cuda().requires_grad_(True) for t in (x, w))
+    assert ops.get_math_mode() == 'f32'
+    ops.set_math_mode('bf16')
+    try:
+        y = ops.conv2d(xd, wd, None, st, pad)
+        y.backward(gy.cuda())
+        torch.cuda.synchronize()
+    finally:
+        ops.set_math_mode('f32')
+    errs = dict(y=_rel(y, y_ref), dx=_rel(xd.grad, x.grad), dw=_rel(wd.grad, w.grad))
+    assert all(e < 1e-2 for e in errs.values()), errs
+    assert max(errs.values()) > 1e-5, "bf16 mode did not engage (result is f32-exact)"

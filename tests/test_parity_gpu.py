@@ -147,3 +147,69 @@ def test_ragged_batches_against_oracle(n):
     assert res[0][1].shape == res[1][1].shape                     # [20] at n == 1, [n, 20] otherwise
     assert np.abs(res[0][1] - res[1][1]).max() <= 1e-3 * np.abs(res[0][1]).max()
     assert np.abs(res[0][2] - res[1][2]).max() <= 1e-3 * np.abs(res[0][2]).max()
+
+
+def test_bf16_math_mode_end_to_end(golden):
+    """BASELINE config 5 (bf16 MFMA conv path): full-width nets with the residual convs on bf16 MFMA operands
+    (f32 accumulation, f32 InstanceNorm statistics, f32 master weights / Adam) against the SAME f32 golden
+    vectors of the reference.  bf16 carries 8 mantissa bits: forward tensors within 3e-2 of their abs-max,
+    loss scalars within 5 %."""
+    A = _adapter()
+    from lsps_amd import ops
+    ops.set_math_mode('bf16')
+    try:
+        R = cases.run_module_cases(A, 'full', lsps_ref)
+        hp = cases.hp_for('full')
+        sds = cases.make_weights(hp, lsps_ref)
+        tr = A.make_trainer(hp, sds)
+        A.set_train(tr, True)
+        b = cases.make_inputs(2)
+        lat2, lat1 = cases.latent_shape(hp, 4), cases.latent_shape(hp, 2)
+        A.dis_update(tr, b, hp, cases.noise(lat2, 1000))
+        A.gen_update(tr, b, hp, (cases.noise(lat2, 2000), cases.noise(lat1, 3000), cases.noise(lat1, 4000)))
+        scal = A.scalars(tr)
+    finally:
+        ops.set_math_mode('f32')
+    g = golden('full')
+    gm = {k: v for k, v in g.items() if k.split('/')[0] in R}
+    bad, worst = cases.compare(R, gm, 3e-2)
+    print("bf16 worst forward rel err", worst)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:6])
+    assert worst > 1e-5, "bf16 mode did not engage"
+    for k, v in scal.items():
+        ref = float(g['pretrain.it0.gen_update.scalars/%s/full' % k])
+        assert abs(v - ref) <= 5e-2 * max(abs(ref), 1e-3), (k, v, ref)
+
+
+def test_icvl_config_bf16_against_oracle():
+    """BASELINE config 5 itself: exps/nicvl.yaml (vae.input_dim = 48), bf16 MFMA conv path, against the f32 CPU
+    oracle on the same seeded inputs (no golden vectors exist for ICVL: the oracle is the checker here)."""
+    A = _adapter()
+    from lsps_amd import ops
+    hp = cases.load_hp('nicvl')
+    assert hp['vae']['input_dim'] == 48
+    sds = cases.make_weights(hp, lsps_ref)
+    n = 2
+    b = cases.make_inputs(n, label_dim=48)
+    lat2, lat1 = cases.latent_shape(hp, 2 * n), cases.latent_shape(hp, n)
+    nz = (cases.noise(lat2, 21), cases.noise(lat2, 22), cases.noise(lat1, 23), cases.noise(lat1, 24))
+    zd = hp['vae']['z_dim']
+    res = []
+    for Ad, mode in ((cases.NativeAdapter(lsps_ref, 'cpu', trainer_kwargs=dict(literal=False)), None), (A, 'bf16')):
+        if mode:
+            ops.set_math_mode(mode)
+        try:
+            tr = Ad.make_trainer(hp, sds)
+            Ad.set_train(tr, True)
+            Ad.dis_update(tr, b, hp, nz[0])
+            outs = Ad.gen_update(tr, b, hp, nz[1:])
+            Ad.post_update(tr, b, 3, hp, cases.noise(cases.latent_shape(hp, 4), 25), cases.noise((n, zd), 26, 0.05),
+                           cases.noise((n, zd), 27, 0.05))
+            res.append((Ad.scalars(tr), outs[0], outs[4]))
+        finally:
+            if mode:
+                ops.set_math_mode('f32')
+    (s_ref, xaa_ref, xaba_ref), (s_hip, xaa, xaba) = res
+    for k in s_ref:
+        assert abs(s_ref[k] - s_hip[k]) <= 5e-2 * max(abs(s_ref[k]), 1e-3), (k, s_ref[k], s_hip[k])
+    assert np.abs(xaa - xaa_ref).max() <= 3e-2 and np.abs(xaba - xaba_ref).max() <= 3e-2

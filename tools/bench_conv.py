@@ -46,8 +46,10 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--only', default='')
     ap.add_argument('--ops', default='fwd,dgrad,wgrad')
+    ap.add_argument('--math', default='f32')
     a = ap.parse_args()
     L = _lib.lib()
+    L.lsps_set_math_mode(1 if a.math == 'bf16' else 0)
     dev = torch.device('cuda')
     st = _lib.stream()
     for name, (C, H, W, K, R, s, p) in LAYERS:
