@@ -38,7 +38,7 @@ int         lsps_version(void);
 const char *lsps_last_error(void);
 /* number of compute units of the current device (used by callers to size split counts) */
 int         lsps_device_cus(void);
-/* Math mode of the 3x3 / stride-1 residual-conv kernels (process-wide): 0 = exact f32 MFMA (default);
+/* Math mode of the MFMA conv kernels (process-wide; direct HBM-bound kernels are f32 always): 0 = exact f32 MFMA (default);
  * 1 = operands rounded to bf16 in registers, v_mfma_f32_32x32x16_bf16 with f32 accumulation (BASELINE config 5:
  * "bf16 with MFMA conv path").  Tensors stay f32 in HBM in both modes.                                  */
 #define LSPS_MATH_F32  0

@@ -40,7 +40,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 struct defeats SROA (scratch)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// Math mode of the 3x3 residual kernels: 0 = exact f32 MFMA (default), 1 = operands rounded to bf16 in registers
+// Math mode of the MFMA conv kernels: 0 = exact f32 MFMA (default), 1 = operands rounded to bf16 in registers
 // (v_cvt_pk_bf16_f32, RNE) and v_mfma_f32_32x32x16_bf16 with f32 accumulation (BASELINE config 5).  HBM and LDS
 // tensors stay f32 in both modes.
 static int g_math_mode = 0;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void build_jtab_kernel(int2 *jtab, float *zero
 // -------------------------------------------------------------------------------------------
 // F kernel
 // -------------------------------------------------------------------------------------------
-template <int WM, int WN, int WAVES_M, int WAVES_N>
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
   constexpr int BM = WM * 32 * WAVES_M, BN = WN * 32 * WAVES_N, BK = BK_F;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
         tabv = p.gtab[nk + rbase * NB + (lane & (NB - 1))];
       }
     }
-    if (ch >= ch_first) {
+    if (ch >= ch_first && !BF16) {
 #pragma unroll 8
       for (int kk = 0; kk < BK / 2; ++kk) {
         float a[WM], b[WN];
@@ -305,6 +305,26 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
 #pragma unroll
           for (int j = 0; j < WN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (ch >= ch_first && BF16) {               // bf16 mode: K = 16 reduction rows per MFMA, rounded in registers
+#pragma unroll
+      for (int k16 = 0; k16 < BK / 16; ++k16) {
+        const int row0 = k16 * 16 + 8 * half;
+        bf16x8 af[WM], bf[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)As[(row0 + e) * BM + (wm * WM + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bf[j][e] = (__bf16)Bs[(row0 + e) * BN + (wn * WN + j) * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
     }
   }
@@ -552,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
 // TW = 2: 128x128 tile, each wave 2x2 MFMA tiles.  TW = 1: 64x64 tile (one MFMA tile per wave) for the
 // layers with <= 64 rows / columns (7x7 stem: 64 x 49; 1x1 head), where a 128x128 tile is >= 75 % padding.
 // -------------------------------------------------------------------------------------------
-template <int TW>
+template <int TW, bool BF16 = false>
 __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
   constexpr int BM = 64 * TW, BN = 64 * TW, BK = BK_W, RW = 16 * TW;   // RW rows / columns loaded per wave
   __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDW];
@@ -625,7 +645,7 @@ __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
         breg[i] = *src;
       }
     }
-    if (ch >= ch_begin) {
+    if (ch >= ch_begin && !BF16) {
 #pragma unroll 8
       for (int kk = 0; kk < BK / 2; ++kk) {
         float a[TW], b[TW];
@@ -639,6 +659,26 @@ __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
 #pragma unroll
           for (int j = 0; j < TW; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (ch >= ch_begin && BF16) {               // bf16 mode: K = 16 consecutive pixels per MFMA
+#pragma unroll
+      for (int k16 = 0; k16 < BK / 16; ++k16) {
+        const int col0 = k16 * 16 + 8 * half;
+        bf16x8 af[TW], bf[TW];
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)As[((wm * TW + i) * 32 + l31) * LDW + col0 + e];
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bf[j][e] = (__bf16)Bs[((wn * TW + j) * 32 + l31) * LDW + col0 + e];
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+#pragma unroll
+          for (int j = 0; j < TW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
     }
   }
@@ -1073,16 +1113,25 @@ static int launch_f(const FParams &p, int cfg, hipStream_t st) {
   const int BM = cfg_bm(cfg), BN = cfg_bn(cfg);
   dim3 grid(ceil_div(p.NPIX, BN), ceil_div(p.M, BM), p.ksplit > 1 ? p.ksplit : 1);
   if (grid.x == 0 || grid.y == 0) return 0;
+  const bool bf = g_math_mode == 1;
+#define LSPS_LAUNCH_F(...)                                                                  \
+  do {                                                                                      \
+    if (bf)                                                                                 \
+      hipLaunchKernelGGL((igemm_f_kernel<__VA_ARGS__, true>), grid, dim3(256), 0, st, p);   \
+    else                                                                                    \
+      hipLaunchKernelGGL((igemm_f_kernel<__VA_ARGS__, false>), grid, dim3(256), 0, st, p);  \
+  } while (0)
   if (cfg == 0)
-    hipLaunchKernelGGL((igemm_f_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+    LSPS_LAUNCH_F(2, 2, 2, 2);
   else if (cfg == 1)
-    hipLaunchKernelGGL((igemm_f_kernel<2, 2, 1, 4>), grid, dim3(256), 0, st, p);
+    LSPS_LAUNCH_F(2, 2, 1, 4);
   else if (cfg == 2)
-    hipLaunchKernelGGL((igemm_f_kernel<1, 2, 1, 4>), grid, dim3(256), 0, st, p);
+    LSPS_LAUNCH_F(1, 2, 1, 4);
   else if (cfg == 3)
-    hipLaunchKernelGGL((igemm_f_kernel<1, 2, 4, 1>), grid, dim3(256), 0, st, p);
+    LSPS_LAUNCH_F(1, 2, 4, 1);
   else
-    hipLaunchKernelGGL((igemm_f_kernel<1, 1, 2, 2>), grid, dim3(256), 0, st, p);
+    LSPS_LAUNCH_F(1, 1, 2, 2);
+#undef LSPS_LAUNCH_F
   LSPS_CHECK_LAUNCH("igemm_f");
   return 0;
 }
@@ -1424,10 +1473,17 @@ static int run_wgrad(const float *small, const float *big, float *dW, int N, int
   p.part = splits > 1 ? (float *)((char *)ws + head) : dW;
   const int tile = wgrad_tile(p.M, p.J);
   dim3 grid(ceil_div(p.J, tile), ceil_div(p.M, tile), splits);
-  if (tile == 64)
-    hipLaunchKernelGGL(igemm_w_kernel<1>, grid, dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL(igemm_w_kernel<2>, grid, dim3(256), 0, st, p);
+  if (g_math_mode == 1) {
+    if (tile == 64)
+      hipLaunchKernelGGL((igemm_w_kernel<1, true>), grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((igemm_w_kernel<2, true>), grid, dim3(256), 0, st, p);
+  } else {
+    if (tile == 64)
+      hipLaunchKernelGGL((igemm_w_kernel<1, false>), grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((igemm_w_kernel<2, false>), grid, dim3(256), 0, st, p);
+  }
   LSPS_CHECK_LAUNCH("igemm_w");
   if (splits > 1) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(nW, 256)), dim3(256), 0, st, (const float *)p.part, dW, nW,
