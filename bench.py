@@ -156,10 +156,12 @@ def main():
         with torch.no_grad():
             t_fwd = timed(lambda: tr.gen(b['xa'], b['xb']), 3)
         tr.gen.train()
-        t_bf16 = None
+        t_bf16 = t_split = None
         if args.dtype == 'f32':         # BASELINE config 5 (bf16 MFMA conv path) on the same workload, for reference
             ops.set_math_mode('bf16')
             t_bf16 = timed(pretrain_step, 2)
+            ops.set_math_mode('f32_split')
+            t_split = timed(pretrain_step, 2)
             ops.set_math_mode('f32')
         extra = {'estimate3_step_bs%d' % args.batch: {'steps_per_s': 1.0 / t_est, 'ms_per_step': 1e3 * t_est,
                                                        'algorithmic_tflop_per_step': 0.579 * args.batch / 128.0},
@@ -170,6 +172,10 @@ def main():
                 'steps_per_s': 1.0 / t_bf16, 'ms_per_step': 1e3 * t_bf16,
                 'note': 'residual 3x3 convs on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 in registers, f32 '
                         'accumulate, f32 tensors/statistics/Adam); NOT the headline value'}
+            extra['pretrain_step_f32_split_bs%d' % args.batch] = {
+                'steps_per_s': 1.0 / t_split, 'ms_per_step': 1e3 * t_split,
+                'note': 'experimental: 3x3 residual convs with f32-accurate products from 3 bf16 limbs per operand and 6 '
+                        'bf16 MFMAs (error vs fp64 <= exact-f32 MFMA); NOT the headline value'}
 
     if rank == 0:
         peak = F32_MFMA_PEAK_TFLOPS if args.dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS

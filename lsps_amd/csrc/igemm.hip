@@ -45,6 +45,32 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // tensors stay f32 in both modes.
 static int g_math_mode = 0;
 
+// x = hi + mid + lo with three bf16 values (8+8+8 significand bits: exact for f32).  Used by math mode 2.
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)x[e];
+    const float r1 = x[e] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    hi[e] = h;
+    mid[e] = m;
+    lo[e] = (__bf16)r2;
+  }
+}
+
+// acc += a*b to ~f32 accuracy from six bf16 MFMAs (dropped terms mid*lo, lo*mid, lo*lo are < 2^-24 relative)
+__device__ __forceinline__ f32x16 mfma_split6(const bf16x8 &ah, const bf16x8 &am, const bf16x8 &al, const bf16x8 &bh,
+                                              const bf16x8 &bm, const bf16x8 &bl, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  return acc;
+}
+
 #define LSPS_MAXT 49
 #define BK_F 32   // reduction chunk of the F kernel
 #define BK_W 64   // reduction (pixel) chunk of the W kernel
@@ -408,8 +434,9 @@ struct F3Params {
 
 // TR = output rows per tile: 4 (tile 128 ch x 128 px, waves 2x2, each 64 ch x 64 px) or, when that grid would
 // leave CUs idle (estimate modes run the generator on 8 samples), 2 (128 ch x 64 px, waves 4x1, each 32 ch x 64 px).
-template <int TR, bool BF16>
+template <int TR, int MODE>
 __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
+  constexpr bool BF16 = MODE == 1, SPLIT = MODE == 2;
   constexpr int BM = 128, RC = F3_CC * 9;            // 72 reduction rows per chunk
   constexpr int A4 = RC * BM / 4 / 256;              // 9 float4 of weights per thread per chunk
   constexpr int ROWS = TR + 2, CH = ROWS * F3_LDW;   // staged rows incl. halo; floats per channel
@@ -497,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
         breg[i] = *reinterpret_cast<const f32x4 *>(src);
       }
     }
-    if (ch >= 0 && !BF16) {
+    if (ch >= 0 && MODE == 0) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int tr = t / 3, ts = t - tr * 3;
@@ -517,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
         }
       }
     }
-    if (ch >= 0 && BF16) {
+    if (ch >= 0 && (BF16 || SPLIT)) {
       // bf16 mode: one MFMA covers K = 16 = (2 taps) x (8 channels): lanes 0-31 carry tap 2g, lanes 32-63 tap
       // 2g+1; each lane gathers its 8 channels from the SAME f32 LDS tiles and rounds them to bf16 in registers.
       const float *A0 = As + wm * WM * 32 + l31, *B0 = Bs + wn * 2 * F3_LDW + l31;
@@ -527,23 +554,44 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
         const int arow = (half ? t1 : t0) * F3_CC;
         const int boff = half ? (t1 / 3) * F3_LDW + (t1 % 3) : (t0 / 3) * F3_LDW + (t0 % 3);
         const bool dead = (2 * g + 1 > 8) && half;
-        bf16x8 af[WM], bf[2];
+        float av[WM][8], bv[2][8];
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)A0[(arow + e) * BM + i * 32];
+          for (int e = 0; e < 8; ++e) av[i][e] = A0[(arow + e) * BM + i * 32];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float v = B0[e * CH + j * F3_LDW + boff];
-            bf[j][e] = (__bf16)(dead ? 0.f : v);
+            bv[j][e] = dead ? 0.f : v;
           }
+        if (SPLIT) {                      // f32-accurate product from three bf16 limbs per operand, six MFMAs
+          bf16x8 ah[WM], am[WM], al[WM], bh[2], bm[2], bl[2];
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
+          for (int i = 0; i < WM; ++i) split3(av[i], ah[i], am[i], al[i]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) split3(bv[j], bh[j], bm[j], bl[j]);
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma_split6(ah[i], am[i], al[i], bh[j], bm[j], bl[j], acc[i][j]);
+        } else {
+          bf16x8 af[WM], bf[2];
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)av[i][e];
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bf[j][e] = (__bf16)bv[j][e];
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
       }
     }
   }
@@ -715,8 +763,9 @@ struct W3Params {
   int nchunks, chunks_per_split; // chunk = (n, row pair)
 };
 
-template <bool BF16>
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void igemm_w3x3_kernel(W3Params p) {
+  constexpr bool BF16 = MODE == 1, SPLIT = MODE == 2;
   __shared__ __attribute__((aligned(16))) float lds[64 * W3_LDA + 64 * W3_CH];
   float *As = lds, *Bs = lds + 64 * W3_LDA;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -789,7 +838,7 @@ __global__ __launch_bounds__(256, 2) void igemm_w3x3_kernel(W3Params p) {
         breg[i] = *reinterpret_cast<const f32x4 *>(src);
       }
     }
-    if (ch >= ch_begin && !BF16) {
+    if (ch >= ch_begin && MODE == 0) {
 #pragma unroll
       for (int row = 0; row < 2; ++row) {
         const float *Ar = Ap + row * 32, *Br = Bp + row * 34;
@@ -804,22 +853,38 @@ __global__ __launch_bounds__(256, 2) void igemm_w3x3_kernel(W3Params p) {
         }
       }
     }
-    if (ch >= ch_begin && BF16) {
-      // bf16 mode: K = 16 consecutive pixels of one image row per MFMA (lanes 0-31: pixels 0..7, lanes 32-63: 8..15)
+    if (ch >= ch_begin && (BF16 || SPLIT)) {
+      // bf16 / split modes: K = 16 consecutive pixels of one image row per MFMA (lanes 0-31: pixels 0..7, 32-63: 8..15)
       const float *A0 = As + (wm * 32 + l31) * W3_LDA + 8 * half;
       const float *B0 = Bs + (wn * 32 + l31) * W3_CH + 8 * half;
 #pragma unroll 1
       for (int q = 0; q < 4; ++q) {                 // 64-pixel chunk = 4 groups of 16 pixels (2 rows x 2 halves)
         const int row = q >> 1, col = (q & 1) * 16;
-        bf16x8 af;
+        float av[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) af[e] = (__bf16)A0[row * 32 + col + e];
+        for (int e = 0; e < 8; ++e) av[e] = A0[row * 32 + col + e];
+        bf16x8 ah, am, al;
+        if (SPLIT) {
+          split3(av, ah, am, al);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ah[e] = (__bf16)av[e];
+        }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          bf16x8 bf;
+          float bv[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) bf[e] = (__bf16)B0[(row + t / 3) * 34 + col + (t % 3) + e];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+          for (int e = 0; e < 8; ++e) bv[e] = B0[(row + t / 3) * 34 + col + (t % 3) + e];
+          if (SPLIT) {
+            bf16x8 bh, bm, bl;
+            split3(bv, bh, bm, bl);
+            acc[t] = mfma_split6(ah, am, al, bh, bm, bl, acc[t]);
+          } else {
+            bf16x8 bf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bf[e] = (__bf16)bv[e];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf, acc[t], 0, 0, 0);
+          }
         }
       }
     }
@@ -1184,14 +1249,19 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   const dim3 grid(p.NT, Mp / 128);
   if (g_math_mode == 1) {
     if (tr == 4)
-      hipLaunchKernelGGL((igemm_f3x3_kernel<4, true>), grid, dim3(256), 0, st, p);
+      hipLaunchKernelGGL((igemm_f3x3_kernel<4, 1>), grid, dim3(256), 0, st, p);
     else
-      hipLaunchKernelGGL((igemm_f3x3_kernel<2, true>), grid, dim3(256), 0, st, p);
+      hipLaunchKernelGGL((igemm_f3x3_kernel<2, 1>), grid, dim3(256), 0, st, p);
+  } else if (g_math_mode == 2) {
+    if (tr == 4)
+      hipLaunchKernelGGL((igemm_f3x3_kernel<4, 2>), grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((igemm_f3x3_kernel<2, 2>), grid, dim3(256), 0, st, p);
   } else {
     if (tr == 4)
-      hipLaunchKernelGGL((igemm_f3x3_kernel<4, false>), grid, dim3(256), 0, st, p);
+      hipLaunchKernelGGL((igemm_f3x3_kernel<4, 0>), grid, dim3(256), 0, st, p);
     else
-      hipLaunchKernelGGL((igemm_f3x3_kernel<2, false>), grid, dim3(256), 0, st, p);
+      hipLaunchKernelGGL((igemm_f3x3_kernel<2, 0>), grid, dim3(256), 0, st, p);
   }
   LSPS_CHECK_LAUNCH("igemm_f3x3");
   return 0;
@@ -1410,9 +1480,11 @@ static int run_w3x3(const float *dy, const float *x, float *dW, int N, int C, in
   p.zero = zero;
   p.part = (float *)((char *)ws + 256);
   if (g_math_mode == 1)
-    hipLaunchKernelGGL(igemm_w3x3_kernel<true>, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(igemm_w3x3_kernel<1>, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
+  else if (g_math_mode == 2)
+    hipLaunchKernelGGL(igemm_w3x3_kernel<2>, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL(igemm_w3x3_kernel<false>, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(igemm_w3x3_kernel<0>, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_w3x3");
   const long total = (long)M * C * 9;
   hipLaunchKernelGGL(reduce_w3x3_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float *)p.part, dW, M, C,
@@ -1568,8 +1640,8 @@ int lsps_version(void) { return LSPS_ABI_VERSION; }
 const char *lsps_last_error(void) { return lsps::g_err; }
 
 int lsps_set_math_mode(int mode) {
-  if (mode != 0 && mode != 1) {
-    set_error("set_math_mode: mode must be 0 (f32) or 1 (bf16 MFMA operands)");
+  if (mode < 0 || mode > 2) {
+    set_error("set_math_mode: mode must be 0 (f32), 1 (bf16 MFMA operands) or 2 (f32 via 3-limb bf16 split)");
     return LSPS_E_ARG;
   }
   lsps::g_math_mode = mode;

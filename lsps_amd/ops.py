@@ -84,12 +84,12 @@ profiler = Profiler()
 def set_math_mode(mode):
     """'f32' (default, exact f32 MFMA) or 'bf16' (bf16 MFMA operands, f32 accumulation, in the 3x3 residual-conv
     kernels: BASELINE config 5).  Process-wide."""
-    code = {'f32': 0, 'bf16': 1}[mode]
+    code = {'f32': 0, 'bf16': 1, 'f32_split': 2}[mode]
     _lib.check(_lib.lib().lsps_set_math_mode(code), 'set_math_mode')
 
 
 def get_math_mode():
-    return ('f32', 'bf16')[_lib.lib().lsps_get_math_mode()]
+    return ('f32', 'bf16', 'f32_split')[_lib.lib().lsps_get_math_mode()]
 
 
 def conv_out_size(h, r, stride, pad):

@@ -288,3 +288,28 @@ def test_conv3x3_bf16_math_mode(case):
     errs = dict(y=_rel(y, y_ref), dx=_rel(xd.grad, x.grad), dw=_rel(wd.grad, w.grad))
     assert all(e < 1e-2 for e in errs.values()), errs
     assert max(errs.values()) > 1e-5, "bf16 mode did not engage (result is f32-exact)"
+
+
+@pytest.mark.parametrize("case", [(3, 256, 32, 32, 256, 3, 1, 1), (2, 8, 32, 32, 130, 3, 1, 1), (3, 64, 8, 32, 128, 3, 1, 1)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv3x3_f32_split_math_mode(case):
+    """Experimental mode 2: f32 products from three bf16 limbs per operand (x = hi + mid + lo exactly) and six
+    bf16 MFMAs (dropped cross terms < 2^-24 relative).  Same tolerance as the exact-f32 kernels."""
+    _need_gpu()
+    from lsps_amd import ops
+    N, C, H, W, K, R, st, pad = case
+    x = _rand(N, C, H, W, seed=1).requires_grad_(True)
+    w = _rand(K, C, R, R, seed=2, scale=0.1).requires_grad_(True)
+    y_ref = F.conv2d(x, w, None, stride=st, padding=pad)
+    gy = _rand(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+    xd, wd = (t.detach().cuda().requires_grad_(True) for t in (x, w))
+    ops.set_math_mode('f32_split')
+    try:
+        y = ops.conv2d(xd, wd, None, st, pad)
+        y.backward(gy.cuda())
+        torch.cuda.synchronize()
+    finally:
+        ops.set_math_mode('f32')
+    errs = dict(y=_rel(y, y_ref), dx=_rel(xd.grad, x.grad), dw=_rel(wd.grad, w.grad))
+    assert errs['y'] < 1e-4 and errs['dx'] < 1e-4 and errs['dw'] < 2e-4, errs

@@ -49,7 +49,7 @@ def main():
     ap.add_argument('--math', default='f32')
     a = ap.parse_args()
     L = _lib.lib()
-    L.lsps_set_math_mode(1 if a.math == 'bf16' else 0)
+    L.lsps_set_math_mode({'f32': 0, 'bf16': 1, 'f32_split': 2}[a.math])
     dev = torch.device('cuda')
     st = _lib.stream()
     for name, (C, H, W, K, R, s, p) in LAYERS:
