@@ -59,7 +59,6 @@ class GradReducer(object):
         self._pending = None
         self._works = []
         self._launched = None
-        self.expected = None        # indices expected to receive a gradient this backward (None: unknown)
         self.active = active()
         if self.active:
             arena.on_grad_ready = self._on_grad_ready

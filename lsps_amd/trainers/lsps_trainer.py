@@ -91,16 +91,13 @@ class LSPSTrainer(nn.Module):
         red.finish()
         opt.step()
 
-    def _publish(self, names, tensors, extra=None):
+    def _publish(self, names, tensors):
         """One device->host copy for all per-step scalars; stored as numpy values like the reference."""
         vals = torch.stack([t.detach().reshape(()).float() for t in tensors]).cpu().numpy()
         if lsps_dist.active():
             vals = np.asarray(lsps_dist.all_reduce_mean_scalars([float(v) for v in vals], 'cuda'), dtype=np.float32)
-        out = dict(zip(names, vals))
-        for k, v in out.items():
-            if extra is None or k not in extra:
-                setattr(self, k, np.asarray(v, dtype=np.float32))
-        return out
+        for k, v in zip(names, vals):
+            setattr(self, k, np.asarray(v, dtype=np.float32))
 
     # ------------------------------------------------------------------ loss helpers (:42-60)
     def _compute_ll_loss(self, a, b):
