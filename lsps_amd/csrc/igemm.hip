@@ -615,6 +615,202 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
   }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// Split-precision variant of the 3x3 / stride-1 / width-32 kernel (math mode 2, experimental): every f32 operand
+// is split ONCE into three bf16 limbs (hi, mid, lo: 8+8+8 significand bits, exact) — the weights by the pack
+// kernel, the input rows when they are staged into LDS — and stored K-contiguous ([..][8 channels] bf16), so that
+// an MFMA operand fragment is ONE ds_read_b128 per limb.  A product is six v_mfma_f32_32x32x16_bf16 (32 cycles
+// each, K = 16 = 2 taps x 8 channels) against eight v_mfma_f32_32x32x2_f32 (64 cycles each) for the same 16
+// reduction elements: 192 vs 512 matrix-pipe cycles at f32-class accuracy (dropped limb products < 2^-24).
+// -------------------------------------------------------------------------------------------
+#define FS_TAPS 10                                   // 9 taps + one all-zero tap so that taps pair up
+#define FS_APLANE (FS_TAPS * 128 * 8)                // bf16 elements per limb plane of the weight tile
+#define FS_ACHUNK (3 * FS_APLANE)                    // bf16 elements per (m-tile, channel chunk)
+
+struct FSPack {
+  const float *W;
+  unsigned short *Wq;            // [Mp/128][C/8][3 limbs][10 taps][128 m][8 c] bf16
+  int M, C;
+  long sm, sc;
+  int tapidx[9];
+};
+
+__device__ __forceinline__ void split3_scalar(float x, unsigned short &h, unsigned short &m, unsigned short &l) {
+  const __bf16 bh = (__bf16)x;
+  const float r1 = x - (float)bh;
+  const __bf16 bm = (__bf16)r1;
+  const float r2 = r1 - (float)bm;
+  const __bf16 bl = (__bf16)r2;
+  h = __builtin_bit_cast(unsigned short, bh);
+  m = __builtin_bit_cast(unsigned short, bm);
+  l = __builtin_bit_cast(unsigned short, bl);
+}
+
+__global__ __launch_bounds__(256) void pack_split_kernel(FSPack p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // over [mtile][chunk][tap][m_local][c]
+  const int chunks = p.C / 8, mtiles = (p.M + 127) / 128;
+  const long total = (long)mtiles * chunks * FS_TAPS * 128 * 8;
+  if (idx >= total) return;
+  const int c = (int)(idx & 7);
+  const int ml = (int)((idx >> 3) & 127);
+  long rest = idx >> 10;
+  const int t = (int)(rest % FS_TAPS);
+  rest /= FS_TAPS;
+  const int chunk = (int)(rest % chunks), mt = (int)(rest / chunks);
+  const int m = mt * 128 + ml;
+  float v = 0.f;
+  if (t < 9 && m < p.M) v = p.W[(long)m * p.sm + (long)(chunk * 8 + c) * p.sc + p.tapidx[t]];
+  unsigned short h, mm, l;
+  split3_scalar(v, h, mm, l);
+  unsigned short *base = p.Wq + ((long)mt * chunks + chunk) * FS_ACHUNK + ((long)t * 128 + ml) * 8 + c;
+  base[0] = h;
+  base[FS_APLANE] = mm;
+  base[2 * FS_APLANE] = l;
+}
+
+struct FSParams {
+  const float *X, *bias, *zero;
+  const unsigned short *Wq;
+  float *Y;
+  int Cx, H, M, tiles_per_img;
+  int act;
+  float slope;
+};
+
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+template <int TR>
+__global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
+  constexpr int ROWS = TR + 2, BPL = ROWS * F3_LDW * 8;      // bf16 elements per limb plane of the input tile
+  constexpr int A16 = FS_ACHUNK / 8 / 256;                   // 16-byte units of weights per thread per chunk (15)
+  constexpr int WM = TR == 4 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) unsigned short lds[FS_ACHUNK + 3 * BPL];
+  unsigned short *Aq = lds, *Bq = lds + FS_ACHUNK;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.y * 128;
+  const int n = blockIdx.x / p.tiles_per_img;
+  const int row0 = (blockIdx.x - n * p.tiles_per_img) * TR;
+  const int HW = p.H * 32;
+  const float *xn = p.X + (long)n * p.Cx * HW;
+  const int nchunks = p.Cx / 8;
+
+  // halo columns (0 and 33) of every row, all 8 channels, all 3 limb planes: zero once
+  for (int u = tid; u < 3 * ROWS * 2 * 8; u += 256) {
+    const int c = u & 7, side = (u >> 3) & 1, r = (u >> 4) % ROWS, pl = (u >> 4) / ROWS;
+    Bq[pl * BPL + (r * F3_LDW + side * 33) * 8 + c] = 0;
+  }
+
+  // B staging: thread (r, col) owns ONE pixel of the staged rows and gathers its 8 channels (8 coalesced dword
+  // loads: lanes = consecutive pixels), so that after the split each limb is ONE 16-byte LDS store
+  const bool b_use = tid < ROWS * 32;
+  const int b_r = tid >> 5, b_col = tid & 31;
+  const int b_img_row = row0 - 1 + b_r;
+  const bool b_ok = b_use && b_img_row >= 0 && b_img_row < p.H;
+  const int b_lds = (b_r * F3_LDW + 1 + b_col) * 8;
+  const long b_off = (long)b_img_row * 32 + b_col;
+
+  f32x16 acc[WM][2];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 areg[A16];
+  float breg[8];
+  const int wm = TR == 4 ? (wave >> 1) : wave, wn = TR == 4 ? (wave & 1) : 0;
+  const int l31 = lane & 31, half = lane >> 5;
+  const unsigned short *wq = p.Wq + (long)blockIdx.y * nchunks * FS_ACHUNK;
+
+  for (int ch = -1; ch < nchunks; ++ch) {
+    if (ch >= 0) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < A16; ++i) *reinterpret_cast<f32x4 *>(Aq + (tid + 256 * i) * 8) = areg[i];
+      if (b_use) {
+        u16x8 h8, m8, l8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          unsigned short h, m, l;
+          split3_scalar(breg[e], h, m, l);
+          h8[e] = h;
+          m8[e] = m;
+          l8[e] = l;
+        }
+        *reinterpret_cast<u16x8 *>(Bq + b_lds) = h8;
+        *reinterpret_cast<u16x8 *>(Bq + BPL + b_lds) = m8;
+        *reinterpret_cast<u16x8 *>(Bq + 2 * BPL + b_lds) = l8;
+      }
+      __syncthreads();
+    }
+    if (ch + 1 < nchunks) {
+#ifdef LSPS_ABL_SPLIT_NOA
+      const unsigned short *src = wq;            // ablation: always the first chunk (L1/L2-resident)
+#else
+      const unsigned short *src = wq + (long)(ch + 1) * FS_ACHUNK;
+#endif
+#pragma unroll
+      for (int i = 0; i < A16; ++i) areg[i] = *reinterpret_cast<const f32x4 *>(src + (tid + 256 * i) * 8);
+      const float *xc = xn + (long)(ch + 1) * F3_CC * HW;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float *s2 = b_ok ? (xc + (long)e * HW + b_off) : p.zero;
+        breg[e] = *s2;
+      }
+    }
+    if (ch >= 0) {
+#pragma unroll
+      for (int g = 0; g < 5; ++g) {
+        const int t0 = 2 * g, t1 = 2 * g + 1;                // t1 == 9: the all-zero tap
+        const int tb1 = t1 <= 8 ? t1 : 8;
+        const int arow = (half ? t1 : t0) * 128 + wm * WM * 32 + l31;
+        const int boff = (half ? (tb1 / 3) * F3_LDW + (tb1 % 3) : (t0 / 3) * F3_LDW + (t0 % 3)) + wn * 2 * F3_LDW + l31;
+        bf16x8 af[3][WM], bf[3][2];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+            af[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8 *>(Aq + pl * FS_APLANE + (arow + i * 32) * 8));
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            bf[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8 *>(Bq + pl * BPL + (boff + j * F3_LDW) * 8));
+        }
+        // six limb products, smallest first; the tile loop is INSIDE so that consecutive MFMAs hit different
+        // accumulators (no dependent-accumulator stall)
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[term]][i], bf[TB[term]][j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float *yb = p.Y + (long)n * p.M * HW + (long)(row0 + wn * 2 + j) * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < p.M) {
+          float v = acc[i][j][r];
+          if (p.bias) v += p.bias[m];
+          yb[(long)m * HW] = apply_act(v, p.act, p.slope);
+        }
+      }
+    }
+  }
+}
+
 // -------------------------------------------------------------------------------------------
 // W kernel (weight gradient): tile (64*TW) m x (64*TW) (c,t) columns x 64 pixels, split over pixel chunks.
 // TW = 2: 128x128 tile, each wave 2x2 MFMA tiles.  TW = 1: 64x64 tile (one MFMA tile per wave) for the
@@ -1224,6 +1420,50 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   }
   const int RED = Cin * 9, REDp = RED;     // Cin % 8 == 0 -> RED % 72 == 0
   const int Mp = (int)align_up(M, 128);
+  if (g_math_mode == 2) {                  // split-precision variant: weights pre-split into bf16 limb planes
+    const size_t wq_bytes = (size_t)(Mp / 128) * (Cin / 8) * FS_ACHUNK * sizeof(unsigned short);
+    if (256 + wq_bytes > ws_bytes) {
+      set_error("conv workspace too small: need %zu, have %zu", 256 + wq_bytes, ws_bytes);
+      return LSPS_E_WS;
+    }
+    hipError_t e = hipMemsetAsync(ws, 0, 256, st);
+    if (e != hipSuccess) {
+      set_error("hipMemsetAsync: %s", hipGetErrorString(e));
+      return LSPS_E_HIP;
+    }
+    FSPack pk;
+    pk.W = W;
+    pk.Wq = (unsigned short *)((char *)ws + 256);
+    pk.M = M;
+    pk.C = Cin;
+    pk.sm = sm;
+    pk.sc = sc;
+    for (int t = 0; t < 9; ++t) pk.tapidx[t] = l.idx[t];
+    const long total = (long)(Mp / 128) * (Cin / 8) * FS_TAPS * 128 * 8;
+    hipLaunchKernelGGL(pack_split_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, pk);
+    LSPS_CHECK_LAUNCH("pack_split");
+    FSParams q;
+    memset(&q, 0, sizeof(q));
+    q.X = in;
+    q.bias = bias;
+    q.zero = (const float *)ws;
+    q.Wq = pk.Wq;
+    q.Y = out;
+    q.Cx = Cin;
+    q.H = H;
+    q.M = M;
+    const int tr2 = ((long)N * (H / 4) * (Mp / 128) >= 512) ? 4 : 2;
+    q.tiles_per_img = H / tr2;
+    q.act = act;
+    q.slope = slope;
+    const dim3 grid2(N * q.tiles_per_img, Mp / 128);
+    if (tr2 == 4)
+      hipLaunchKernelGGL(igemm_f3x3_split_kernel<4>, grid2, dim3(256), 0, st, q);
+    else
+      hipLaunchKernelGGL(igemm_f3x3_split_kernel<2>, grid2, dim3(256), 0, st, q);
+    LSPS_CHECK_LAUNCH("igemm_f3x3_split");
+    return 0;
+  }
   const size_t need = class_bytes(REDp, Mp);
   if (need > ws_bytes) {
     set_error("conv workspace too small: need %zu, have %zu", need, ws_bytes);
@@ -1599,6 +1839,11 @@ static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int W
                     (splits > 1 ? (size_t)splits * Cs * J * sizeof(float) : 0);
   size_t m = fwd > tr ? fwd : tr;
   if (wg > m) m = wg;
+  if (R == 3 && S == 3 && st_ == 1) {   // split-precision weight planes (math mode 2), either direction
+    const size_t cmax = Cb > Cs ? Cb : Cs;
+    const size_t sp = 256 + (align_up(cmax, 128) / 128) * (cmax / 8 + 1) * FS_ACHUNK * sizeof(unsigned short);
+    if (sp > m) m = sp;
+  }
   if (w3x3_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, R == 3 ? 1 : -1)) {
     const size_t w3 = w3x3_ws_bytes(N, Cs, Cb, Hb);
     if (w3 > m) m = w3;
