@@ -19,6 +19,12 @@
 // accumulator register => 128-byte coalesced NCHW stores without any LDS transpose.
 // Tiles are staged through LDS (register prefetch of the next chunk overlaps the MFMA chain).
 //
+// Build-time experiment hooks (never defined in the shipped build; see DESIGN.md §3.1 for what they measured):
+//   LSPS_ABL_NOLOAD / _NOSTORE / _NOBAR / _SAMEADDR  ablations of the generic F kernel's phases
+//   LSPS_ABL_SPLIT_NOA   cache-resident weight tile in the split-precision kernel
+//   LSPS_STAGGER_PRIO, LSPS_F_LDS_PAD=<floats>       priority stagger / occupancy cap experiments
+//   LSPS_NO_F3X3, LSPS_NO_W3X3                       force the generic kernels for the 3x3 layers
+//
 // Reference call sites replaced: every nn.Conv2d / nn.ConvTranspose2d on the path
 // (src/trainers/common_net.py:162-163,250,262; src/trainers/lsps_nets.py:17-23,123-124,226-227)
 // and their autograd backward (total_loss.backward(), src/trainers/lsps_trainer.py:71,130,212,257).
