@@ -155,3 +155,22 @@ class FlatAdam(torch.optim.Optimizer):
             self.arena.zero_grad()
         else:
             super(FlatAdam, self).zero_grad(set_to_none=set_to_none)
+
+    def load_state_dict(self, state_dict):
+        """Accepts a torch.optim.Adam / FlatAdam state dict (reference: lsps_trainer.py:288-295, load_opt=True).
+        With an arena attached, the loaded moments are copied INTO the flat buffers (the kernel only reads those)."""
+        super(FlatAdam, self).load_state_dict(state_dict)
+        if self.arena is None:
+            return                                   # attach() picks the loaded state up later
+        a = self.arena
+        for p, o in zip(self.param_groups[0]['params'], a.offsets):
+            st = self.state.get(p)
+            if not st:
+                continue
+            n = p.numel()
+            for key, flat in (('exp_avg', self.flat_m), ('exp_avg_sq', self.flat_v)):
+                view = flat[o:o + n].view(p.shape)
+                if key in st and st[key].data_ptr() != view.data_ptr():
+                    view.copy_(st[key])
+                st[key] = view
+            st['step'] = int(st['step'].item()) if torch.is_tensor(st.get('step')) else int(st.get('step', 0))

@@ -254,6 +254,39 @@ def test_flat_adam_matches_torch_adam():
         assert _rel(ph, pr) < 1e-5
 
 
+def test_flat_adam_state_dict_round_trip():
+    """Optimizer state saved by torch.optim.Adam loads into FlatAdam (resume(load_opt=True)) and continues identically."""
+    _need_gpu()
+    from lsps_amd.optim import FlatAdam
+    shapes = [(16, 3, 3, 3), (16,), (100,)]
+    ps_ref = [torch.nn.Parameter(_rand(*s, seed=40 + i, scale=0.05).cuda()) for i, s in enumerate(shapes)]
+    ps_hip = [torch.nn.Parameter(p.detach().clone()) for p in ps_ref]
+    ref = torch.optim.Adam(ps_ref, lr=1e-3, betas=(0.5, 0.999), weight_decay=1e-4)
+    hip = FlatAdam(ps_hip, lr=1e-3, betas=(0.5, 0.999), weight_decay=1e-4)
+    hip.attach()
+
+    def grads(step):
+        for pr, ph in zip(ps_ref, ps_hip):
+            g = _rand(*pr.shape, seed=200 + step, scale=0.01).cuda()
+            pr.grad = g.clone()
+            ph.grad.copy_(g)
+        hip.arena.touched = [True] * len(ps_hip)
+    for step in range(2):
+        grads(step)
+        ref.step()
+        if step == 0:
+            hip.step()
+    # hip is one step behind: load ref's state (after 2 steps) and parameters, then both take step 3
+    hip.load_state_dict(ref.state_dict())
+    for pr, ph in zip(ps_ref, ps_hip):
+        ph.data.copy_(pr.data)
+    grads(2)
+    ref.step()
+    hip.step()
+    for pr, ph in zip(ps_ref, ps_hip):
+        assert _rel(ph, pr) < 1e-6
+
+
 def test_ops_reject_cpu_tensors():
     from lsps_amd import ops, _lib
     with pytest.raises(Exception):
