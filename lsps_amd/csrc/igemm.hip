@@ -1129,92 +1129,32 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *part,
 
 
 // -------------------------------------------------------------------------------------------
-// dgrad of a conv whose INPUT has one channel (the 7x7 stride-2 discriminator stem, needed in gen_update where
-// the discriminator input is a generated image): dx[n][h][w] = sum_k sum_(r,s) W[k][r][s] dy[n][k][(h+pad-r)/st][..].
-// 0.2 GFLOP against 1 MB of dy per sample: a direct kernel (the MFMA tile would be 31/32 padding).
-// Workgroup = 8 output rows of one sample; a wave owns (row, column-parity) items so that all 64 lanes share the
-// tap list (uniform loops, scalar weight loads) and read consecutive dy columns from the LDS tile.
-// -------------------------------------------------------------------------------------------
-#define SD_RB 8      // output rows per workgroup
-#define SD_KC 16     // dy channels staged per pass
-#define SD_PR 10     // dy rows staged (>= (SD_RB-1 + R-1)/st + 2 for st = 2, R <= 7 ... and st = 1, R <= 3)
-#define SD_HQ 3      // column halo on each side of the staged dy rows
-
-struct SDParams {
-  const float *dy, *w;
-  float *dx;
-  int N, K, H, W, P, Q, R, S, st, pad;
-};
-
-template <int R, int S, int ST>
-__global__ __launch_bounds__(256) void stem_dgrad_kernel(SDParams p) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];      // [SD_KC][SD_PR][Q + 2*SD_HQ] + weights [SD_KC][R*S]
-  const int QC = p.Q + 2 * SD_HQ;
-  float *wl = tile + SD_KC * SD_PR * QC;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = blockIdx.y, h0 = blockIdx.x * SD_RB;
-  const int a0 = h0 + p.pad - (R - 1);                                // first staged dy row = floor(a0 / ST)
-  const int p_lo = a0 >= 0 ? a0 / ST : -((-a0 + ST - 1) / ST);
-  const int lchunks = (p.W / ST) / 64;                                // 64-lane column chunks per parity
-  const int items = SD_RB * ST * lchunks;                             // (row, parity, chunk) work items
-  const int per_wave = (items + 3) / 4;                               // <= 4 (checked on the host)
-  constexpr int NR = (R + ST - 1) / ST, NS = (S + ST - 1) / ST;       // taps per dimension for one parity
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-
-  for (int k0 = 0; k0 < p.K; k0 += SD_KC) {
-    __syncthreads();
-    for (int u = tid; u < SD_KC * SD_PR * QC; u += 256) {
-      const int k = u / (SD_PR * QC), rem = u - k * SD_PR * QC;
-      const int pr = rem / QC, qc = rem - pr * QC;
-      const int pp = p_lo + pr, qq = qc - SD_HQ;
-      float v = 0.f;
-      if (pp >= 0 && pp < p.P && qq >= 0 && qq < p.Q && k0 + k < p.K)
-        v = p.dy[(((long)n * p.K + k0 + k) * p.P + pp) * p.Q + qq];
-      tile[u] = v;
-    }
-    for (int u = tid; u < SD_KC * R * S; u += 256) wl[u] = (k0 + u / (R * S) < p.K) ? p.w[(long)k0 * R * S + u] : 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int item = wave * per_wave + it;
-      if (it >= per_wave || item >= items) continue;                  // wave-uniform
-      const int lc = item % lchunks, rem = item / lchunks;
-      const int pw = rem % ST, ro = rem / ST;
-      const int h = h0 + ro;
-      if (h >= p.H) continue;
-      const int r_first = (h + p.pad) % ST, s_first = (pw + p.pad) % ST;
-      const int pr0 = (h + p.pad - r_first) / ST - p_lo;              // staged row of the first tap (next taps: -1 each)
-      const int dq0 = (pw + p.pad - s_first) / ST;                    // column shift of the first tap (next: -1 each)
-      const float *t0 = tile + pr0 * QC + SD_HQ + lc * 64 + lane + dq0;
-      const float *w0 = wl + r_first * S + s_first;
-      float a = acc[it];
-#pragma unroll 4
-      for (int k = 0; k < SD_KC; ++k) {
-#pragma unroll
-        for (int rr = 0; rr < NR; ++rr) {
-          if (r_first + rr * ST < R) {
-#pragma unroll
-            for (int ss = 0; ss < NS; ++ss) {
-              if (s_first + ss * ST < S)
-                a = fmaf(w0[k * R * S + rr * ST * S + ss * ST], t0[k * SD_PR * QC - rr * QC - ss], a);
-            }
-          }
-        }
-      }
-      acc[it] = a;
+// col2im for the dgrad of a 1-input-channel conv computed as a GEMM over taps:
+//   Z[n][t][p][q] = sum_k W[k][t] dy[n][k][p][q]   (MFMA kernel, M = R*S rows)
+//   dx[n][h][w]   = sum_{t=(r,s) valid} Z[n][t][(h+pad-r)/st][(w+pad-s)/st]
+__global__ __launch_bounds__(256) void col2im_c1_kernel(const float *__restrict__ Z, float *__restrict__ dx, int N, int H,
+                                                        int W, int P, int Q, int R, int S, int st, int pad) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)N * H * W) return;
+  const int w = (int)(idx % W);
+  const long t1 = idx / W;
+  const int h = (int)(t1 % H), n = (int)(t1 / H);
+  const float *zn = Z + (long)n * R * S * P * Q;
+  float acc = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const int a = h + pad - r;
+    if (a < 0 || a % st != 0) continue;
+    const int pp = a / st;
+    if (pp >= P) continue;
+    for (int s2 = 0; s2 < S; ++s2) {
+      const int b = w + pad - s2;
+      if (b < 0 || b % st != 0) continue;
+      const int qq = b / st;
+      if (qq >= Q) continue;
+      acc += zn[((long)(r * S + s2) * P + pp) * Q + qq];
     }
   }
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int item = wave * per_wave + it;
-    if (it >= per_wave || item >= items) continue;
-    const int lc = item % lchunks, rem = item / lchunks;
-    const int pw = rem % ST, ro = rem / ST;
-    const int h = h0 + ro;
-    if (h >= p.H) continue;
-    p.dx[((long)n * p.H + h) * p.W + (lc * 64 + lane) * ST + pw] = acc[it];
-  }
+  dx[idx] = acc;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1864,18 +1804,6 @@ static bool conv_args_ok(int N, int C, int H, int W, int K, int R, int S, int st
 
 
 
-static bool stem_dgrad_ok(int C, int H, int W, int R, int S, int st_, int pad) {
-  if (C != 1 || R != 7 || S != 7 || st_ != 2 || (W % (64 * st_)) != 0) return false;   // instantiated: <7,7,2>
-  const int Q = (W + 2 * pad - S) / st_ + 1;
-  const int items = SD_RB * st_ * ((W / st_) / 64);                   // (row, parity, 64-column chunk) work items
-  const int dq_max = (st_ - 1 + pad) / st_;                           // column shifts of the staged dy rows
-  const int dq_min_abs = (S - 1 - pad + st_ - 1) / st_;
-  return items <= 16 &&                                               // 4 waves x 4 accumulators
-         (SD_RB - 1 + R - 1) / st_ + 2 <= SD_PR &&                    // staged dy rows
-         dq_max <= SD_HQ && (S - 1 - pad <= 0 || dq_min_abs <= SD_HQ) &&
-         W / st_ + dq_max <= Q + SD_HQ;
-}
-
 static bool pw1_ok(int Co, int R, int S, int stride, int pad, int outpad, long HW, const void *p0, const void *p1) {
   return Co == 1 && R == 1 && S == 1 && stride == 1 && pad == 0 && outpad == 0 && (HW % 4) == 0 &&
          (((uintptr_t)p0 | (uintptr_t)p1) & 15) == 0;
@@ -1911,7 +1839,9 @@ int lsps_device_cus(void) {
 size_t lsps_conv2d_workspace_bytes(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
   if (!conv_args_ok(N, C, H, W, K, R, S, stride, pad)) return 0;
   const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
-  return conv_ws_bytes(N, C, H, W, K, P, Q, R, S, stride);
+  size_t extra = 0;
+  if (C == 1 && R * S >= 9) extra = align_up((size_t)N * R * S * P * Q * sizeof(float), 256) + ((size_t)8 << 20);   // Z of the tap-GEMM dgrad
+  return conv_ws_bytes(N, C, H, W, K, P, Q, R, S, stride) + extra;
 }
 
 int lsps_conv2d_fwd(const float *x, const float *w, const float *bias, float *y, int N, int C, int H, int W, int K,
@@ -1931,26 +1861,21 @@ int lsps_conv2d_dgrad(const float *dy, const float *w, float *dx, int N, int C, 
   LSPS_CHECK_ARG(dy && w && dx && ws, "conv2d_dgrad: null pointer");
   LSPS_CHECK_ARG(conv_args_ok(N, C, H, W, K, R, S, stride, pad), "conv2d_dgrad: unsupported geometry");
   const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
-  if (stem_dgrad_ok(C, H, W, R, S, stride, pad)) {
-    SDParams sp;
-    sp.dy = dy;
-    sp.w = w;
-    sp.dx = dx;
-    sp.N = N;
-    sp.K = K;
-    sp.H = H;
-    sp.W = W;
-    sp.P = P;
-    sp.Q = Q;
-    sp.R = R;
-    sp.S = S;
-    sp.st = stride;
-    sp.pad = pad;
-    const size_t lds_bytes = ((size_t)SD_KC * SD_PR * (Q + 2 * SD_HQ) + SD_KC * R * S) * sizeof(float);
-    if (lds_bytes <= 64 * 1024) {
-      hipLaunchKernelGGL((stem_dgrad_kernel<7, 7, 2>), dim3(ceil_div(H, SD_RB), N), dim3(256), lds_bytes,
-                         (hipStream_t)stream, sp);
-      LSPS_CHECK_LAUNCH("stem_dgrad");
+  if (C == 1 && R * S >= 9) {
+    // one input channel (the 7x7 stems: the generator's is reached by the cycle passes, the discriminator's by
+    // gen_update): the direct MFMA tiling would be 31/32 padding, so compute Z[t] = W[:,t]^T dy as a 1x1 conv with
+    // R*S output rows (M = 49 -> 77 % of a 64-row tile), then gather-sum the taps (a hand-written direct VALU
+    // kernel measured 3x slower than this)
+    const size_t zbytes = (size_t)N * R * S * P * Q * sizeof(float);
+    if (zbytes + ((size_t)4 << 20) <= ws_bytes) {
+      float *Z = (float *)ws;
+      int rc = run_forward_dir(dy, w, nullptr, Z, N, K, P, Q, R * S, P, Q, 1, 1, 1, 0, 1L, (long)R * S, LSPS_ACT_NONE, 1.f,
+                               (char *)ws + align_up(zbytes, 256), ws_bytes - align_up(zbytes, 256), (hipStream_t)stream);
+      if (rc) return rc;
+      const long total = (long)N * H * W;
+      hipLaunchKernelGGL(col2im_c1_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float *)Z,
+                         dx, N, H, W, P, Q, R, S, stride, pad);
+      LSPS_CHECK_LAUNCH("col2im_c1");
       return 0;
     }
   }
