@@ -6,8 +6,9 @@ src/depth_train.py:152-160): `dis_update` then `gen_update` of LSPSTrainer on on
 NYU-shape batch of 128 depth crops per domain (enc + dec + discriminator + KL / L1 / GAN losses,
 forward + dgrad + wgrad + Adam), all through the HIP kernels.  With --gpus N (launched by
 torch.distributed.run, one process per GPU) every rank runs 128 samples per domain (weak
-scaling) and gradients are all-reduced over RCCL; value = global steps/s of the whole job
-(N ranks x 128 samples advance one global step of batch 128*N).
+scaling: global batch 128*N) and gradients are all-reduced over RCCL.  The unit of work is ONE
+bs=128 step; `value` = units all ranks processed / time = N * K / elapsed (whole-job aggregate,
+grows with N under weak scaling); `ms_per_step` = wall time of one global iteration.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for field definitions).
 """
@@ -201,7 +202,8 @@ def main():
                         'share_of_step_time': dom['total_ms'] / (1e3 * elapsed),
                         'per_kernel': prof}
         out = {
-            'metric': 'depth_train steps/sec (128x128x1, bs=128)', 'value': args.steps / elapsed, 'unit': 'steps/s',
+            'metric': 'depth_train steps/sec (128x128x1, bs=128)', 'value': world * args.steps / elapsed,
+            'unit': 'steps/s (bs=128 steps of work per second, summed over ranks)',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'pretrain step = LSPSTrainer.dis_update + gen_update (enc+dec+disc+KL), exps/nnyu.yaml nets '
@@ -209,6 +211,7 @@ def main():
                        'batch_per_domain_per_gpu': args.batch, 'global_batch_per_domain': args.batch * world,
                        'parallelism': 'dp%d' % world, 'algorithmic_tflop_per_step_per_gpu': 50.0 * args.batch / 128.0},
             'step_tflops_per_gpu': 50.0 * args.batch / 128.0 / (elapsed / args.steps),
+            'global_iterations_per_s': args.steps / elapsed,
             'roofline': roofline, 'other_workloads': extra,
         }
         if not args.no_cpu_baseline and world == 1:
