@@ -203,13 +203,14 @@ def main():
                         'per_kernel': prof}
         out = {
             'metric': 'depth_train steps/sec (128x128x1, bs=128)', 'value': world * args.steps / elapsed,
-            'unit': 'steps/s (bs=128 steps of work per second, summed over ranks)',
+            'unit': 'steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'pretrain step = LSPSTrainer.dis_update + gen_update (enc+dec+disc+KL), exps/nnyu.yaml nets '
                                    '(gen.ch=64, dis.ch=64), synthetic NYU-shape 128x128x1 depth crops',
                        'batch_per_domain_per_gpu': args.batch, 'global_batch_per_domain': args.batch * world,
-                       'parallelism': 'dp%d' % world, 'algorithmic_tflop_per_step_per_gpu': 50.0 * args.batch / 128.0},
+                       'parallelism': 'dp%d' % world,
+                       'unit_of_work': 'one bs=%d step; value = n_gpus * steps / time (aggregate over ranks)' % args.batch, 'algorithmic_tflop_per_step_per_gpu': 50.0 * args.batch / 128.0},
             'step_tflops_per_gpu': 50.0 * args.batch / 128.0 / (elapsed / args.steps),
             'global_iterations_per_s': args.steps / elapsed,
             'roofline': roofline, 'other_workloads': extra,
