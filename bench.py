@@ -192,7 +192,10 @@ def main():
         except (OSError, ValueError, TypeError):
             traffic = None
         if dom:
-            roofline = {'bound': 'mfma', 'kernel': dom_name + ' (implicit-GEMM conv on v_mfma_f32_32x32x2_f32)',
+            mfma = 'v_mfma_f32_32x32x2_f32' if args.dtype == 'f32' else 'v_mfma_f32_32x32x16_bf16'
+            if args.dtype != 'f32':
+                traffic = None          # the PMC passes in profiles/ were taken in the f32 mode
+            roofline = {'bound': 'mfma', 'kernel': dom_name + ' (implicit-GEMM conv on %s)' % mfma,
                         'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                         'frac': dom['tflops'] / peak, 'traffic': traffic,
                         'traffic_note': 'HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE KB, calibrated), '

@@ -636,8 +636,8 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
 
 struct FSPack {
   const float *W;
-  unsigned short *Wq;            // [Mp/128][C/8][3 limbs][10 taps][128 m][8 c] bf16
-  int M, C;
+  unsigned short *Wq;            // [Mp/128][C/8][np limbs][10 taps][128 m][8 c] bf16
+  int M, C, np;                  // np = 3 (f32 split: hi, mid, lo) or 1 (bf16 mode: hi only)
   long sm, sc;
   int tapidx[9];
 };
@@ -669,10 +669,12 @@ __global__ __launch_bounds__(256) void pack_split_kernel(FSPack p) {
   if (t < 9 && m < p.M) v = p.W[(long)m * p.sm + (long)(chunk * 8 + c) * p.sc + p.tapidx[t]];
   unsigned short h, mm, l;
   split3_scalar(v, h, mm, l);
-  unsigned short *base = p.Wq + ((long)mt * chunks + chunk) * FS_ACHUNK + ((long)t * 128 + ml) * 8 + c;
+  unsigned short *base = p.Wq + ((long)mt * chunks + chunk) * (p.np * FS_APLANE) + ((long)t * 128 + ml) * 8 + c;
   base[0] = h;
-  base[FS_APLANE] = mm;
-  base[2 * FS_APLANE] = l;
+  if (p.np == 3) {
+    base[FS_APLANE] = mm;
+    base[2 * FS_APLANE] = l;
+  }
 }
 
 struct FSParams {
@@ -686,13 +688,15 @@ struct FSParams {
 
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
-template <int TR>
+// NP = 3: f32 split (six MFMAs per tile pair); NP = 1: plain bf16 mode (operands rounded once at staging / packing)
+template <int TR, int NP>
 __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
   constexpr int ROWS = TR + 2, BPL = ROWS * F3_LDW * 8;      // bf16 elements per limb plane of the input tile
-  constexpr int A16 = FS_ACHUNK / 8 / 256;                   // 16-byte units of weights per thread per chunk (15)
+  constexpr int ACH = NP * FS_APLANE;                        // bf16 elements of weights per (m-tile, channel chunk)
+  constexpr int A16 = ACH / 8 / 256;                         // 16-byte units of weights per thread per chunk (5 per limb)
   constexpr int WM = TR == 4 ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) unsigned short lds[FS_ACHUNK + 3 * BPL];
-  unsigned short *Aq = lds, *Bq = lds + FS_ACHUNK;
+  __shared__ __attribute__((aligned(16))) unsigned short lds[ACH + NP * BPL];
+  unsigned short *Aq = lds, *Bq = lds + ACH;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
   const int nchunks = p.Cx / 8;
 
   // halo columns (0 and 33) of every row, all 8 channels, all 3 limb planes: zero once
-  for (int u = tid; u < 3 * ROWS * 2 * 8; u += 256) {
+  for (int u = tid; u < NP * ROWS * 2 * 8; u += 256) {
     const int c = u & 7, side = (u >> 3) & 1, r = (u >> 4) % ROWS, pl = (u >> 4) / ROWS;
     Bq[pl * BPL + (r * F3_LDW + side * 33) * 8 + c] = 0;
   }
@@ -730,7 +734,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
   float breg[8];
   const int wm = TR == 4 ? (wave >> 1) : wave, wn = TR == 4 ? (wave & 1) : 0;
   const int l31 = lane & 31, half = lane >> 5;
-  const unsigned short *wq = p.Wq + (long)blockIdx.y * nchunks * FS_ACHUNK;
+  const unsigned short *wq = p.Wq + (long)blockIdx.y * nchunks * ACH;
 
   for (int ch = -1; ch < nchunks; ++ch) {
     if (ch >= 0) {
@@ -748,8 +752,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
           l8[e] = l;
         }
         *reinterpret_cast<u16x8 *>(Bq + b_lds) = h8;
-        *reinterpret_cast<u16x8 *>(Bq + BPL + b_lds) = m8;
-        *reinterpret_cast<u16x8 *>(Bq + 2 * BPL + b_lds) = l8;
+        if (NP == 3) {
+          *reinterpret_cast<u16x8 *>(Bq + BPL + b_lds) = m8;
+          *reinterpret_cast<u16x8 *>(Bq + 2 * BPL + b_lds) = l8;
+        }
       }
       __syncthreads();
     }
@@ -757,7 +763,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
 #ifdef LSPS_ABL_SPLIT_NOA
       const unsigned short *src = wq;            // ablation: always the first chunk (L1/L2-resident)
 #else
-      const unsigned short *src = wq + (long)(ch + 1) * FS_ACHUNK;
+      const unsigned short *src = wq + (long)(ch + 1) * ACH;
 #endif
 #pragma unroll
       for (int i = 0; i < A16; ++i) areg[i] = *reinterpret_cast<const f32x4 *>(src + (tid + 256 * i) * 8);
@@ -775,9 +781,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
         const int tb1 = t1 <= 8 ? t1 : 8;
         const int arow = (half ? t1 : t0) * 128 + wm * WM * 32 + l31;
         const int boff = (half ? (tb1 / 3) * F3_LDW + (tb1 % 3) : (t0 / 3) * F3_LDW + (t0 % 3)) + wn * 2 * F3_LDW + l31;
-        bf16x8 af[3][WM], bf[3][2];
+        bf16x8 af[NP][WM], bf[NP][2];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
           for (int i = 0; i < WM; ++i)
             af[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8 *>(Aq + pl * FS_APLANE + (arow + i * 32) * 8));
@@ -787,9 +793,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
         }
         // six limb products, smallest first; the tile loop is INSIDE so that consecutive MFMAs hit different
         // accumulators (no dependent-accumulator stall)
-        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int NT = NP == 3 ? 6 : 1;
+        constexpr int TA[6] = {NP == 3 ? 2 : 0, 0, 1, 1, 0, 0}, TB[6] = {0, NP == 3 ? 2 : 0, 1, 0, 1, 0};
 #pragma unroll
-        for (int term = 0; term < 6; ++term)
+        for (int term = 0; term < NT; ++term)
 #pragma unroll
           for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1366,8 +1373,9 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   }
   const int RED = Cin * 9, REDp = RED;     // Cin % 8 == 0 -> RED % 72 == 0
   const int Mp = (int)align_up(M, 128);
-  if (g_math_mode == 2) {                  // split-precision variant: weights pre-split into bf16 limb planes
-    const size_t wq_bytes = (size_t)(Mp / 128) * (Cin / 8) * FS_ACHUNK * sizeof(unsigned short);
+  if (g_math_mode != 0) {                  // bf16 / split-precision variants: weights pre-converted to bf16 limb planes
+    const int np = g_math_mode == 2 ? 3 : 1;
+    const size_t wq_bytes = (size_t)(Mp / 128) * (Cin / 8) * np * FS_APLANE * sizeof(unsigned short);
     if (256 + wq_bytes > ws_bytes) {
       set_error("conv workspace too small: need %zu, have %zu", 256 + wq_bytes, ws_bytes);
       return LSPS_E_WS;
@@ -1382,6 +1390,7 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
     pk.Wq = (unsigned short *)((char *)ws + 256);
     pk.M = M;
     pk.C = Cin;
+    pk.np = np;
     pk.sm = sm;
     pk.sc = sc;
     for (int t = 0; t < 9; ++t) pk.tapidx[t] = l.idx[t];
@@ -1403,10 +1412,17 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
     q.act = act;
     q.slope = slope;
     const dim3 grid2(N * q.tiles_per_img, Mp / 128);
-    if (tr2 == 4)
-      hipLaunchKernelGGL(igemm_f3x3_split_kernel<4>, grid2, dim3(256), 0, st, q);
-    else
-      hipLaunchKernelGGL(igemm_f3x3_split_kernel<2>, grid2, dim3(256), 0, st, q);
+    if (np == 3) {
+      if (tr2 == 4)
+        hipLaunchKernelGGL((igemm_f3x3_split_kernel<4, 3>), grid2, dim3(256), 0, st, q);
+      else
+        hipLaunchKernelGGL((igemm_f3x3_split_kernel<2, 3>), grid2, dim3(256), 0, st, q);
+    } else {
+      if (tr2 == 4)
+        hipLaunchKernelGGL((igemm_f3x3_split_kernel<4, 1>), grid2, dim3(256), 0, st, q);
+      else
+        hipLaunchKernelGGL((igemm_f3x3_split_kernel<2, 1>), grid2, dim3(256), 0, st, q);
+    }
     LSPS_CHECK_LAUNCH("igemm_f3x3_split");
     return 0;
   }
