@@ -32,6 +32,13 @@ def make_batch(n, seed=YAML_SEED, label_dim=108, size=128):
     return imgs, labels, com
 
 
+def make_poses(n, seed=YAML_SEED, label_dim=108):
+    """Pose vectors only, [n, label_dim] float32 ~ N(0, 0.3) clipped to [-1, 1] (the stage-1 loaders run with
+    ``pose_only = True``, ``src/pose_train.py:106-107``)."""
+    rs = np.random.RandomState(seed)
+    return np.clip(rs.normal(0.0, 0.3, size=(n, label_dim)), -1.0, 1.0).astype(np.float32)
+
+
 def make_state_dict(shapes, seed):
     """Seeded weights for a ``key -> shape`` table, following the reference's init rules:
     conv / conv-transpose weights ~ N(0, 0.02) (``src/trainers/init.py:8-12``), biases and

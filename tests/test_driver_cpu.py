@@ -104,3 +104,40 @@ def test_evaluation_formulas():
     assert e.getNumFramesWithinMaxDist(40) == 2
     assert list(e.getWorstJoint()[:2]) == [1, 2]
     assert np.allclose(e.getMaxErrorOverSeq(), [5, 50, 0])
+
+
+def test_pose_train_cadence_cpu(tmp_path):
+    """Stage 1 (reference src/pose_train.py:122-185): both domains' poses concatenated when frac > 0, vae_sch
+    every 1000 its, reconstruction read-out every 10*image_save_iterations, save_vae name with 2+frac."""
+    from lsps_amd import pose_train
+    torch.set_num_threads(8)
+    saved = []
+
+    class _T(_OracleTrainer):
+        def __init__(self, hp):
+            super(_T, self).__init__(hp)
+            self.vae_sch = _CountingSched()
+            self.seen = []
+
+        def vae_update(self, y, hp):
+            self.seen.append(tuple(y.shape))
+            return super(_T, self).vae_update(y, hp)
+
+        def save_vae(self, prefix, iterations, frac):
+            saved.append('%s_vae_%.2f_%08d.pkl' % (prefix, frac, iterations + 1))
+
+    cfgp = _config(tmp_path, display=500, image_save_iterations=100, snapshot_save_iterations=250)
+    opts = pose_train.build_parser().parse_args(['--config', cfgp, '--iterations', '1000', '--frac', '1.0',
+                                                 '--log', str(tmp_path / 'log')])
+    lb = synth.make_poses(32, 77)
+    tb = [(torch.as_tensor(lb), np.tile(np.array([[0., 0., 600.]], np.float32), (32, 1)),
+           np.array([300., 300., 300.], np.float32))]
+    tr, hist, readouts = pose_train.run(opts, trainer_factory=_T, device='cpu', to_tensor=_t, test_batches=tb)
+    bs = yaml.safe_load(open(cfgp))['train']['hyperparameters']['batch_size_pose']
+    assert set(tr.seen) == {(2 * bs, 108)} and len(tr.seen) == 1000
+    assert tr.vae_sch.n == 1
+    assert [r[0] for r in readouts] == [1000]
+    assert saved == [str(tmp_path / 'out' / 'pre') + '_vae_3.00_00001000.pkl']
+    assert len(hist) == 2 and hist[-1]['vae_total_loss'] < hist[0]['vae_total_loss']
+    mean_err, max_err = readouts[0][1], readouts[0][2]
+    assert 0 < mean_err <= max_err < 300.0          # mm, poses are within the 300 mm cube

@@ -61,3 +61,31 @@ def test_pretrain_save_resume_and_estimate(tmp_path):
                                  test_batches=tb, evaluate_fn=ev)
     assert 'r' in seen and np.isfinite(seen['r'][0]) and 0.0 <= seen['r'][1] <= 100.0
     assert np.isfinite(float(tr3.dis_reg_loss)) and np.isfinite(float(tr3.dis_total_loss))
+
+
+def test_pose_train_stage1_save_load(tmp_path):
+    """Stage 1 on the HIP pose-MLP kernels: the loss falls, `save_vae` writes the reference's file name and
+    `load_vae` restores the weights into a fresh trainer (reference src/pose_train.py:122-185, lsps_trainer.py:321-332)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from lsps_amd import pose_train, trainers
+    cfgp = _config(tmp_path, display=100, image_save_iterations=30, snapshot_save_iterations=75)
+    opts = pose_train.build_parser().parse_args(['--config', cfgp, '--iterations', '300', '--frac', '0.5'])
+    dev = torch.device('cuda', 0)
+    lb = synth.make_poses(64, 77)
+    tb = [(torch.as_tensor(lb).to(dev), np.tile(np.array([[0., 0., 600.]], np.float32), (64, 1)),
+           np.array([300., 300., 300.], np.float32))]
+    tr, hist, readouts = pose_train.run(opts, test_batches=tb)
+    assert len(hist) == 3 and hist[-1]['vae_total_loss'] < hist[0]['vae_total_loss']
+    assert [r[0] for r in readouts] == [300] and 0 < readouts[0][1] <= readouts[0][2]
+    files = sorted(os.path.basename(f) for f in glob.glob(str(tmp_path / 'out' / '*.pkl')))
+    assert files == ['pre_vae_2.50_00000300.pkl']
+    hp = yaml.safe_load(open(cfgp))['train']['hyperparameters']
+    fresh = trainers.LSPSTrainer(hp)
+    fresh.cuda(0)
+    fresh.load_vae(str(tmp_path / 'out' / 'pre'), 2.5)
+    for k, v in tr.vae.state_dict().items():
+        assert torch.equal(v, fresh.vae.state_dict()[k]), k
+    # the read-out of the reloaded VAE is the same number
+    m2, x2 = pose_train.reconstruction_error(fresh, tb)
+    assert abs(m2 - readouts[0][1]) < 1e-4 and abs(x2 - readouts[0][2]) < 1e-3
