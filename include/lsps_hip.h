@@ -140,6 +140,23 @@ int lsps_adam_step(float *p, const float *g, float *m, float *v,
 /* elementwise helpers used by the trainer glue (GaussianNoiseLayer common_net.py:39-40 etc.) */
 int lsps_axpy(const float *x, const float *y, float alpha, float *out, long n, void *stream);  /* out = x + alpha*y */
 
+/* ---- data step either side of the path -------------------------------------------------
+ * lsps_crop_normalize: reference src/data/dataset_hand2.py:27-31 `normalize(img, com, cube)` for a batch:
+ *   out = (dpt == 0 ? com_z + half : dpt) - com_z) / half, with half = cube_z / 2.  dpt/out: [N][HW] device floats
+ *   (HW % 4 == 0), com_z/half: [N] device floats.  May run in place.
+ * lsps_crop_augment: the image part of src/data/dataset_hand2.py:34-119 `augmentCrop(...)` (normZeroOne=False) for
+ *   a batch of normalised crops x[N][H][W] -> out[N][H][W] (NOT in place): de-normalise, pre-max, nearest-
+ *   neighbour warp (cv2.warpPerspective for 'com'/'sc' via HandDetector.recropHand handdetector.py:786-805 with its
+ *   32000 / z-threshold fix-ups, cv2.warpAffine for 'rot' handdetector.py:733-739), then the premax / zero / clip /
+ *   re-normalise tail.  prm: [N][LSPS_AUG_STRIDE] device doubles, per sample:
+ *     [0] kind: 0 none, 1 perspective, 2 affine      [1] com_z in   [2] cube_z/2 in   [3] com_z out  [4] cube_z/2 out
+ *     [5] zstart  [6] zend (kind 1)                   [7..15] the INVERTED map, row-major (3x3, or 2x3 + padding)
+ *   The per-sample geometry that fills prm is host work: lsps_amd/data.py (mirror of HandDetector.moveCoM /
+ *   rotateHand / scaleHand / comToTransform). */
+#define LSPS_AUG_STRIDE 16
+int lsps_crop_normalize(const float *dpt, const float *com_z, const float *half, float *out, int N, int HW, void *stream);
+int lsps_crop_augment(const float *x, const double *prm, float *out, int N, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,8 @@ _SIGNATURES = {
     'lsps_linear_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P]),
     'lsps_adam_step': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int] + [c_float] * 6 + [_P]),
     'lsps_axpy': (c_int, [_P, _P, c_float, _P, c_long, _P]),
+    'lsps_crop_normalize': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    'lsps_crop_augment': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
 }
 EXPORTS = tuple(sorted(_SIGNATURES))
 
@@ -79,17 +81,18 @@ def check(rc, what):
 # ------------------------------------------------------------------------------------------
 # tensor plumbing (torch is used for device memory + streams only)
 # ------------------------------------------------------------------------------------------
-def ptr(t):
-    """Device pointer of a contiguous float32 HIP tensor (or None -> NULL)."""
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous HIP tensor of `dtype` (default float32), or None -> NULL."""
     if t is None:
         return None
     import torch
+    dtype = dtype or torch.float32
     if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise LspsHipError("lsps_amd ops need HIP device tensors (got %s); there is no CPU fallback"
                            % (t.device if hasattr(t, 'device') else type(t)))
-    if t.dtype != torch.float32 or not t.is_contiguous():
-        raise LspsHipError("lsps_amd ops need contiguous float32 tensors (dtype=%s contiguous=%s)"
-                           % (t.dtype, t.is_contiguous()))
+    if t.dtype != dtype or not t.is_contiguous():
+        raise LspsHipError("lsps_amd ops need contiguous %s tensors (dtype=%s contiguous=%s)"
+                           % (dtype, t.dtype, t.is_contiguous()))
     return t.data_ptr()
 
 
