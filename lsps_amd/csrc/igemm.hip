@@ -440,9 +440,8 @@ struct F3Params {
 
 // TR = output rows per tile: 4 (tile 128 ch x 128 px, waves 2x2, each 64 ch x 64 px) or, when that grid would
 // leave CUs idle (estimate modes run the generator on 8 samples), 2 (128 ch x 64 px, waves 4x1, each 32 ch x 64 px).
-template <int TR, int MODE>
+template <int TR>
 __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
-  constexpr bool BF16 = MODE == 1, SPLIT = MODE == 2;
   constexpr int BM = 128, RC = F3_CC * 9;            // 72 reduction rows per chunk
   constexpr int A4 = RC * BM / 4 / 256;              // 9 float4 of weights per thread per chunk
   constexpr int ROWS = TR + 2, CH = ROWS * F3_LDW;   // staged rows incl. halo; floats per channel
@@ -530,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
         breg[i] = *reinterpret_cast<const f32x4 *>(src);
       }
     }
-    if (ch >= 0 && MODE == 0) {
+    if (ch >= 0) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int tr = t / 3, ts = t - tr * 3;
@@ -547,56 +546,6 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
-    if (ch >= 0 && (BF16 || SPLIT)) {
-      // bf16 mode: one MFMA covers K = 16 = (2 taps) x (8 channels): lanes 0-31 carry tap 2g, lanes 32-63 tap
-      // 2g+1; each lane gathers its 8 channels from the SAME f32 LDS tiles and rounds them to bf16 in registers.
-      const float *A0 = As + wm * WM * 32 + l31, *B0 = Bs + wn * 2 * F3_LDW + l31;
-#pragma unroll
-      for (int g = 0; g < 5; ++g) {
-        const int t0 = 2 * g, t1 = (2 * g + 1 <= 8) ? 2 * g + 1 : 8;    // last group: upper half re-reads tap 8, B zeroed
-        const int arow = (half ? t1 : t0) * F3_CC;
-        const int boff = half ? (t1 / 3) * F3_LDW + (t1 % 3) : (t0 / 3) * F3_LDW + (t0 % 3);
-        const bool dead = (2 * g + 1 > 8) && half;
-        float av[WM][8], bv[2][8];
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) av[i][e] = A0[(arow + e) * BM + i * 32];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float v = B0[e * CH + j * F3_LDW + boff];
-            bv[j][e] = dead ? 0.f : v;
-          }
-        if (SPLIT) {                      // f32-accurate product from three bf16 limbs per operand, six MFMAs
-          bf16x8 ah[WM], am[WM], al[WM], bh[2], bm[2], bl[2];
-#pragma unroll
-          for (int i = 0; i < WM; ++i) split3(av[i], ah[i], am[i], al[i]);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) split3(bv[j], bh[j], bm[j], bl[j]);
-#pragma unroll
-          for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = mfma_split6(ah[i], am[i], al[i], bh[j], bm[j], bl[j], acc[i][j]);
-        } else {
-          bf16x8 af[WM], bf[2];
-#pragma unroll
-          for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)av[i][e];
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bf[j][e] = (__bf16)bv[j][e];
-#pragma unroll
-          for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
       }
     }
@@ -1111,18 +1060,181 @@ __global__ __launch_bounds__(256, 2) void igemm_w3x3_kernel(W3Params p) {
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// W kernel specialised for 3x3 / STRIDE 2 / pad 1 (the down-sampling convs and the up-sampling transposed convs:
+// "small" image [N][M][Hs][Ws], "big" image [N][C][2Hs][2Ws], Ws % 32 == 0):
+//   dW[m][c][r][s] = sum_{n,p,q} small[n][m][p][q] * big[n][c][2p + r - 1][2q + s - 1]
+// Chunk = one row segment of 32 small pixels.  The three big rows it touches are staged ONCE in LDS for 64 big
+// channels, DE-INTERLEAVED by column parity (odd columns with their left halo: O'[0..32], even columns: E[0..31]),
+// so that the stride-2 tap reads become unit-stride LDS reads: tap s=0 -> O'[q], s=1 -> E[q], s=2 -> O'[q+1].
+// A big element serves only ~9/4 taps here (9 in the stride-1 kernel), so the tile is 128 (m) x 64 (c) x 9 taps
+// on 512 threads (8 waves, 9 accumulators each) to keep ~70 flop per staged byte.
+// -------------------------------------------------------------------------------------------
+#define WS2_LDA 33                // small tile [128 m][32 px + 1]
+#define WS2_ROW 65                // one big row in LDS: O'[33] then E[32]
+#define WS2_CH (3 * WS2_ROW)      // 195 floats per big channel (195 % 32 = 3: conflict-free across 32 channels)
+#define WS2_LDS_BYTES ((128 * WS2_LDA + 64 * WS2_CH) * sizeof(float))
+
+struct WS2Params {
+  const float *Small, *Big, *zero;
+  float *part;                   // [splits][9][M][C]
+  int N, M, C, Hs, Ws;
+  int qblocks;                   // Ws / 32
+  int nchunks, chunks_per_split; // chunk = (n, small row, 32-column block)
+};
+
+__global__ __launch_bounds__(512, 2) void igemm_w3x3s2_kernel(WS2Params p) {
+  extern __shared__ __attribute__((aligned(16))) float ws2_lds[];
+  float *As = ws2_lds, *Bs = ws2_lds + 128 * WS2_LDA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = blockIdx.x * 64, m0 = blockIdx.y * 128, split = blockIdx.z;
+  const int HWs = p.Hs * p.Ws, Wb = 2 * p.Ws;
+  const long HWb = 4L * HWs;
+  const int ch_begin = split * p.chunks_per_split;
+  int ch_end = ch_begin + p.chunks_per_split;
+  if (ch_end > p.nchunks) ch_end = p.nchunks;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  f32x4 areg[2], breg[6];
+  float hreg = 0.f;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const float *Ap = As + (wm * 32 + l31) * WS2_LDA + half;
+  const float *Bp = Bs + (wn * 32 + l31) * WS2_CH + half;
+  const int per_img = p.Hs * p.qblocks;
+
+  for (int ch = ch_begin - 1; ch < ch_end; ++ch) {
+#ifdef LSPS_ABL_WS2_NOSTAGE
+    if (ch == ch_begin) {
+#else
+    if (ch >= ch_begin) {
+#endif
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int u = tid + 512 * i;
+        float *d = As + (u >> 3) * WS2_LDA + (u & 7) * 4;
+        d[0] = areg[i][0];
+        d[1] = areg[i][1];
+        d[2] = areg[i][2];
+        d[3] = areg[i][3];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int u = tid + 512 * i;
+        const int line = u >> 4, c4 = u & 15;            // line = channel * 3 + row
+        float *d = Bs + line * WS2_ROW + 2 * c4;         // (line * 65 == ch * 195 + row * 65)
+        d[33] = breg[i][0];                              // E[2 c4]
+        d[1] = breg[i][1];                               // O'[2 c4 + 1]
+        d[34] = breg[i][2];                              // E[2 c4 + 1]
+        d[2] = breg[i][3];                               // O'[2 c4 + 2]
+      }
+      if (tid < 192) Bs[tid * WS2_ROW] = hreg;           // O'[0]: the column left of the block (zero at the image edge)
+      __syncthreads();
+    }
+    if (ch + 1 < ch_end) {
+      const int nc = ch + 1;
+      const int n = nc / per_img;
+      const int rem = nc - n * per_img;
+      const int y = rem / p.qblocks, q0 = (rem - y * p.qblocks) * 32;
+      const float *sb = p.Small + ((long)n * p.M + m0) * HWs + y * p.Ws + q0;
+#ifdef LSPS_ABL_WS2_NOLOAD
+      if (ch < ch_begin) {
+#endif
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int u = tid + 512 * i;
+        areg[i] = *reinterpret_cast<const f32x4 *>(sb + (long)(u >> 3) * HWs + (u & 7) * 4);
+      }
+      const float *bb = p.Big + ((long)n * p.C + c0) * HWb + 2 * q0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int u = tid + 512 * i;
+        const int line = u >> 4, c4 = u & 15;
+        const int chn = line / 3, r = line - chn * 3;
+        const int rb = 2 * y - 1 + r;
+        const float *src = rb >= 0 ? (bb + (long)chn * HWb + (long)rb * Wb + c4 * 4) : p.zero;
+        breg[i] = *reinterpret_cast<const f32x4 *>(src);
+      }
+      if (tid < 192) {
+        const int chn = tid / 3, r = tid - chn * 3;
+        const int rb = 2 * y - 1 + r;
+        const float *src = (rb >= 0 && q0 > 0) ? (bb + (long)chn * HWb + (long)rb * Wb - 1) : p.zero;
+        hreg = *src;
+      }
+#ifdef LSPS_ABL_WS2_NOLOAD
+      }
+#endif
+    }
+    if (ch >= ch_begin) {
+      // k-step kq covers small pixels 2kq + half; the operands of step kq+1 are fetched from LDS before the nine
+      // MFMAs of step kq are issued (the compiler does not pipeline the reads across iterations by itself)
+      float a_nx = Ap[0], b_nx[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        b_nx[3 * r + 0] = Bp[r * WS2_ROW];
+        b_nx[3 * r + 1] = Bp[r * WS2_ROW + 33];
+        b_nx[3 * r + 2] = Bp[r * WS2_ROW + 1];
+      }
+#pragma unroll
+      for (int kq = 0; kq < 16; ++kq) {
+        const float a = a_nx;
+        float b[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) b[t] = b_nx[t];
+        if (kq + 1 < 16) {
+          a_nx = Ap[2 * kq + 2];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            b_nx[3 * r + 0] = Bp[r * WS2_ROW + 2 * kq + 2];
+            b_nx[3 * r + 1] = Bp[r * WS2_ROW + 33 + 2 * kq + 2];
+            b_nx[3 * r + 2] = Bp[r * WS2_ROW + 2 * kq + 3];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  const int c = c0 + wn * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float *out = p.part + ((long)(split * 9 + t) * p.M) * p.C + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      out[(long)m * p.C] = acc[t][r];
+    }
+  }
+}
+
 // dW[(m*C + c)*9 + t] = sum_s part[s][t][m][c]   (write-coalesced; the strided partial reads hit in L2 — the
 // read-coalesced / scattered-write variant measured 0.3 ms slower per layer)
 __global__ __launch_bounds__(256) void reduce_w3x3_kernel(const float *__restrict__ part, float *__restrict__ dw, int M,
                                                           int C, int splits) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;      // index into dW [m][c][t]
+  // 64 outputs per block, 4 threads per output (each sums every 4th split, fixed order -> deterministic)
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + o;                 // index into dW [m][c][t]
   const long total = (long)M * C * 9;
-  if (i >= total) return;
-  const int t = (int)(i % 9);
-  const long mc = i / 9;
   float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += part[((long)(k * 9 + t) * M) * C + mc];
-  dw[i] = s;
+  if (i < total) {
+    const int t = (int)(i % 9);
+    const long mc = i / 9;
+    const float *src = part + (long)t * M * C + mc;
+    const long stride = 9L * M * C;
+    for (int k = g; k < splits; k += 4) s += src[k * stride];
+  }
+  red[g][o] = s;
+  __syncthreads();
+  if (g == 0 && i < total) dw[i] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
 }
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *part, float *out, long n, int splits) {
@@ -1449,22 +1561,10 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   p.act = act;
   p.slope = slope;
   const dim3 grid(p.NT, Mp / 128);
-  if (g_math_mode == 1) {
-    if (tr == 4)
-      hipLaunchKernelGGL((igemm_f3x3_kernel<4, 1>), grid, dim3(256), 0, st, p);
-    else
-      hipLaunchKernelGGL((igemm_f3x3_kernel<2, 1>), grid, dim3(256), 0, st, p);
-  } else if (g_math_mode == 2) {
-    if (tr == 4)
-      hipLaunchKernelGGL((igemm_f3x3_kernel<4, 2>), grid, dim3(256), 0, st, p);
-    else
-      hipLaunchKernelGGL((igemm_f3x3_kernel<2, 2>), grid, dim3(256), 0, st, p);
-  } else {
-    if (tr == 4)
-      hipLaunchKernelGGL((igemm_f3x3_kernel<4, 0>), grid, dim3(256), 0, st, p);
-    else
-      hipLaunchKernelGGL((igemm_f3x3_kernel<2, 0>), grid, dim3(256), 0, st, p);
-  }
+  if (tr == 4)
+    hipLaunchKernelGGL(igemm_f3x3_kernel<4>, grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(igemm_f3x3_kernel<2>, grid, dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_f3x3");
   return 0;
 }
@@ -1689,7 +1789,71 @@ static int run_w3x3(const float *dy, const float *x, float *dW, int N, int C, in
     hipLaunchKernelGGL(igemm_w3x3_kernel<0>, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_w3x3");
   const long total = (long)M * C * 9;
-  hipLaunchKernelGGL(reduce_w3x3_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float *)p.part, dW, M, C,
+  hipLaunchKernelGGL(reduce_w3x3_kernel, dim3(ceil_div(total, 64)), dim3(256), 0, st, (const float *)p.part, dW, M, C,
+                     splits);
+  LSPS_CHECK_LAUNCH("reduce_w3x3");
+  return 0;
+}
+
+static bool w3x3s2_ok(int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad) {
+  return R == 3 && S == 3 && st_ == 2 && pad == 1 && Hb == 2 * Hs && Wb == 2 * Ws && (Ws % 32) == 0 && (Cb % 64) == 0 &&
+         (Cs % 128) == 0;
+}
+
+static int w3x3s2_splits(int M, int C, int nchunks) {
+  const int tiles = (M / 128) * (C / 64);
+  int s = 256 / tiles;                    // one 512-thread workgroup per CU x 256 CUs
+  if (s > nchunks) s = nchunks;
+  if (s < 1) s = 1;
+  return s;
+}
+
+static size_t w3x3s2_ws_bytes(int N, int M, int C, int Hs, int Ws) {
+  return 256 + (size_t)w3x3s2_splits(M, C, N * Hs * (Ws / 32)) * 9 * M * C * sizeof(float);
+}
+
+static int run_w3x3s2(const float *small, const float *big, float *dW, int N, int C, int M, int Hs, int Ws, void *ws,
+                      size_t ws_bytes, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {                        // 67 KB of LDS: above the 64 KB static limit, so dynamic + opt-in
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_w3x3s2_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS2_LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(igemm_w3x3s2): %s", hipGetErrorString(e));
+      return LSPS_E_HIP;
+    }
+    attr_set = true;
+  }
+  WS2Params p;
+  memset(&p, 0, sizeof(p));
+  p.Small = small;
+  p.Big = big;
+  p.N = N;
+  p.M = M;
+  p.C = C;
+  p.Hs = Hs;
+  p.Ws = Ws;
+  p.qblocks = Ws / 32;
+  p.nchunks = N * Hs * p.qblocks;
+  const int splits = w3x3s2_splits(M, C, p.nchunks);
+  p.chunks_per_split = ceil_div(p.nchunks, splits);
+  const size_t need = w3x3s2_ws_bytes(N, M, C, Hs, Ws);
+  if (need > ws_bytes) {
+    set_error("wgrad workspace too small: need %zu, have %zu", need, ws_bytes);
+    return LSPS_E_WS;
+  }
+  float *zero = (float *)ws;
+  hipError_t e = hipMemsetAsync(zero, 0, 256, st);
+  if (e != hipSuccess) {
+    set_error("hipMemsetAsync: %s", hipGetErrorString(e));
+    return LSPS_E_HIP;
+  }
+  p.zero = zero;
+  p.part = (float *)((char *)ws + 256);
+  hipLaunchKernelGGL(igemm_w3x3s2_kernel, dim3(C / 64, M / 128, splits), dim3(512), WS2_LDS_BYTES, st, p);
+  LSPS_CHECK_LAUNCH("igemm_w3x3s2");
+  const long total = (long)M * C * 9;
+  hipLaunchKernelGGL(reduce_w3x3_kernel, dim3(ceil_div(total, 64)), dim3(256), 0, st, (const float *)p.part, dW, M, C,
                      splits);
   LSPS_CHECK_LAUNCH("reduce_w3x3");
   return 0;
@@ -1700,6 +1864,10 @@ static int run_wgrad(const float *small, const float *big, float *dW, int N, int
                      int Ws, int R, int S, int st_, int pad, void *ws, size_t ws_bytes, hipStream_t st) {
 #ifndef LSPS_NO_W3X3
   if (w3x3_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad)) return run_w3x3(small, big, dW, N, Cb, Hb, Cs, ws, ws_bytes, st);
+#endif
+#ifndef LSPS_NO_W3X3S2
+  if (w3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad))
+    return run_w3x3s2(small, big, dW, N, Cb, Cs, Hs, Ws, ws, ws_bytes, st);
 #endif
   WParams p;
   memset(&p, 0, sizeof(p));
@@ -1808,6 +1976,10 @@ static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int W
   }
   if (w3x3_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, R == 3 ? 1 : -1)) {
     const size_t w3 = w3x3_ws_bytes(N, Cs, Cb, Hb);
+    if (w3 > m) m = w3;
+  }
+  if (w3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, 1)) {
+    const size_t w3 = w3x3s2_ws_bytes(N, Cs, Cb, Hs, Ws);
     if (w3 > m) m = w3;
   }
   return 2 * BIAS_WS_BYTES + m + ((size_t)8 << 20) + 1024;   // + 8 MiB: reduction-split partials of tiny forward problems

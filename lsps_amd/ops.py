@@ -55,6 +55,8 @@ class Profiler(object):
     def w_kernel(cb, hb, wb, cs, r, stride, pad):
         if r == 3 and stride == 1 and pad == 1 and wb == 32 and hb % 2 == 0 and cb % 64 == 0 and cs % 64 == 0:
             return 'igemm_w3x3_kernel'
+        if r == 3 and stride == 2 and pad == 1 and cb % 64 == 0 and cs % 128 == 0 and wb % 64 == 0 and hb % 2 == 0:
+            return 'igemm_w3x3s2_kernel'
         return 'igemm_w_kernel'
 
     def span(self, key, flops, launches):
@@ -205,7 +207,7 @@ class _ConvT2dFn(torch.autograd.Function):
             dw = torch.empty_like(w)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = torch.empty(Co, dtype=torch.float32, device=x.device)
-            with profiler.span('igemm_w_kernel', flops, 1):
+            with profiler.span(Profiler.w_kernel(Co, dy.shape[2], dy.shape[3], Ci, R if R == S else 0, stride, pad), flops, 1):
                 _lib.check(L.lsps_convT2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), N, Ci, H, W, Co,
                                                 R, S, stride, pad, outpad, ws, wsb, st), 'convT2d_wgrad')
         return dx, dw, db, None, None, None, None, None

@@ -52,6 +52,9 @@ CONV_CASES = [
     (2, 1, 64, 128, 16, 7, 2, 3),       # same, non-square image
     (3, 64, 8, 32, 128, 3, 1, 1),       # specialised wgrad kernel (C, K multiples of 64), few chunks
     (7, 128, 2, 32, 64, 3, 1, 1),       # specialised wgrad: one row pair per image, odd N
+    (3, 64, 8, 64, 128, 3, 2, 1),       # specialised stride-2 kernels: non-square (4 x 32 out), odd N
+    (1, 64, 4, 128, 128, 3, 2, 1),      # stride-2: two 32-column blocks per row, a single image
+    (2, 128, 64, 64, 128, 3, 2, 1),     # stride-2: two big-channel tiles
 ]
 
 
@@ -95,6 +98,8 @@ CONVT_CASES = [
     (2, 7, 5, 6, 9, 3, 2, 1, 1),         # ragged
     (2, 6, 7, 5, 10, 3, 1, 1, 0),        # stride 1
     (2, 5, 6, 6, 4, 5, 3, 2, 2),         # stride 3
+    (1, 128, 2, 32, 64, 3, 2, 1, 1),     # specialised stride-2 kernels: two input rows, a single image
+    (3, 128, 4, 64, 128, 3, 2, 1, 1),    # stride-2: two 32-column blocks, odd N
 ]
 
 
