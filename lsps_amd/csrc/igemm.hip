@@ -43,6 +43,7 @@ void set_error(const char *fmt, ...) {
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 struct defeats SROA (scratch)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -570,6 +571,186 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
   }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// "Transposed direction" kernel specialised for 3x3 / STRIDE 2 / pad 1 (the up-sampling transposed convs forward,
+// the down-sampling convs' dgrad): in = small image [N][Cx][Hs][Ws] (Ws % 32 == 0), out = big image [N][M][2Hs][2Ws]
+//   out[m][2p+a][2q+b] = sum_c sum_{(r,s) in class(a,b)} W(m,c,r,s) * in[c][p + dh(r)][q + dw(s)]
+// with class rows a=0: r=1 (dh 0); a=1: r=0 (dh +1), r=2 (dh 0), and the same for columns.  A workgroup owns a tile
+// of the SMALL image (TR rows x 32 columns) for one row parity a (blockIdx.z) and BOTH column parities: the raw
+// input rows of 16 channels are staged once in LDS (TR+1 rows x 33 columns, zero past the edges) and the 3 (a=0)
+// or 6 (a=1) taps are shifted LDS reads; the two column classes are separate accumulators that the epilogue
+// interleaves into float2 stores (full 256-byte rows instead of stride-2 scatter).
+// BM = 128: TR = 4, waves 2x2;  BM = 64 (64-channel outputs): TR = 8, waves 1x4.  Each wave: 64 m x 2 rows x 2 classes.
+// -------------------------------------------------------------------------------------------
+#define TS_CC 16
+#define TS_LDS_FLOATS (6 * TS_CC * 128 + TS_CC * 5 * 34)      // a = 1, BM = 128 (the largest of the four variants)
+
+struct TS2Params {
+  const float *X, *Wp, *bias, *zero;
+  float *Y;
+  int Cx, Hs, Ws, M, Mp;
+  int qblocks, tiles_per_img;    // Ws / 32, (Hs / TR) * qblocks
+  int act;
+  float slope;
+};
+
+template <int APAR, int BM>
+__device__ __forceinline__ void ts2_body(const TS2Params &p, float *lds) {
+  constexpr int NT = APAR ? 6 : 3;                           // taps of this row class
+  constexpr int WAVES_M = BM / 64, WAVES_N = 4 / WAVES_M, TR = 2 * WAVES_N;
+  constexpr int ROWS = TR + 1, CHS = ROWS * 34;
+  constexpr int AROWS = NT * TS_CC;
+  constexpr int A4 = AROWS * BM / 4 / 256;
+  constexpr int B4 = (TS_CC * ROWS * 8 + 255) / 256;
+  static_assert(AROWS * BM + TS_CC * CHS <= TS_LDS_FLOATS, "LDS budget");
+  float *As = lds, *Bs = lds + AROWS * BM;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.y * BM;
+  const int n = blockIdx.x / p.tiles_per_img;
+  const int rem = blockIdx.x - n * p.tiles_per_img;
+  const int p0 = (rem / p.qblocks) * TR, q0 = (rem - (rem / p.qblocks) * p.qblocks) * 32;
+  const int HWs = p.Hs * p.Ws;
+  const float *xn = p.X + (long)n * p.Cx * HWs;
+
+  int b_lds[B4];
+  int b_off[B4];                                             // element offsets inside one 16-channel slab (< 2^31)
+  bool b_use[B4], b_ok[B4];
+#pragma unroll
+  for (int i = 0; i < B4; ++i) {
+    const int u = tid + 256 * i;
+    b_use[i] = u < TS_CC * ROWS * 8;
+    const int line = u >> 3, c4 = u & 7;
+    const int chn = line / ROWS, r = line - chn * ROWS;
+    b_ok[i] = b_use[i] && (p0 + r) < p.Hs;
+    b_lds[i] = chn * CHS + r * 34 + c4 * 4;
+    b_off[i] = chn * HWs + (p0 + r) * p.Ws + q0 + c4 * 4;
+  }
+  // column q0 + 32 (the right neighbour of the tile): one scalar per (channel, row) line
+  const bool h_use = tid < TS_CC * ROWS;
+  const int h_chn = tid / ROWS, h_r = tid - h_chn * ROWS;
+  const bool h_ok = h_use && (p0 + h_r) < p.Hs && (q0 + 32) < p.Ws;
+  const int h_off = h_chn * HWs + (p0 + h_r) * p.Ws + q0 + 32;
+
+  f32x16 acc[2][2][2];                                       // [m tile][row][column class]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][c][r] = 0.f;
+
+  f32x4 areg[A4], breg[B4];
+  float hreg = 0.f;
+  const int nchunks = p.Cx / TS_CC;
+  const int wm = WAVES_M == 2 ? (wave >> 1) : 0, wn = WAVES_M == 2 ? (wave & 1) : wave;
+  const int l31 = lane & 31, half = lane >> 5;
+  const float *Ap = As + half * BM + wm * 64 + l31;
+  const float *Bp = Bs + half * CHS + wn * 2 * 34 + l31;
+
+  for (int ch = -1; ch < nchunks; ++ch) {
+    if (ch >= 0) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4 *>(As + (tid + 256 * i) * 4) = areg[i];
+#pragma unroll
+      for (int i = 0; i < B4; ++i)
+        if (b_use[i]) {
+          float *d = Bs + b_lds[i];
+          d[0] = breg[i][0];
+          d[1] = breg[i][1];
+          d[2] = breg[i][2];
+          d[3] = breg[i][3];
+        }
+      if (h_use) Bs[h_chn * CHS + h_r * 34 + 32] = hreg;
+      __syncthreads();
+    }
+    if (ch + 1 < nchunks) {
+      // packed weights: rows [chunk of 16 channels][tap 0..8][16 channels]; this class uses taps 3..5 (a = 0) or
+      // 0..2 and 6..8 (a = 1)
+      const float *wsrc = p.Wp + (long)(ch + 1) * (9 * TS_CC) * p.Mp + m0;
+#pragma unroll
+      for (int i = 0; i < A4; ++i) {
+        const int u = tid + 256 * i;
+        const int row = u / (BM / 4), c4 = u - row * (BM / 4);
+        const int lt = row / TS_CC;
+        const int grow = (APAR ? (lt < 3 ? lt : lt + 3) : lt + 3) * TS_CC + (row - lt * TS_CC);
+        areg[i] = *reinterpret_cast<const f32x4 *>(wsrc + (long)grow * p.Mp + c4 * 4);
+      }
+      const float *xc = xn + (long)(ch + 1) * TS_CC * HWs;
+#pragma unroll
+      for (int i = 0; i < B4; ++i) {
+        const float *src = b_ok[i] ? (xc + b_off[i]) : p.zero;
+        breg[i] = *reinterpret_cast<const f32x4 *>(src);
+      }
+      {
+        const float *src = h_ok ? (xc + h_off) : p.zero;
+        hreg = *src;
+      }
+    }
+    if (ch >= 0) {
+#pragma unroll
+      for (int lt = 0; lt < NT; ++lt) {
+        const int s = lt % 3;
+        const int dh = (APAR && lt < 3) ? 1 : 0;             // a = 1: r = 0 reads the next input row
+        const int dw = s == 0 ? 1 : 0, cls = s == 1 ? 0 : 1;
+#pragma unroll
+        for (int cp = 0; cp < TS_CC / 2; ++cp) {
+          float a[2], b[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[i] = Ap[(lt * TS_CC + 2 * cp) * BM + i * 32];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) b[j] = Bp[2 * cp * CHS + (j + dh) * 34 + dw];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j][cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j][cls], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const int Wb = 2 * p.Ws;
+  const long HWb = 4L * HWs;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int orow = 2 * (p0 + wn * 2 + j) + APAR;
+    float *yb = p.Y + (long)n * p.M * HWb + (long)orow * Wb + 2 * (q0 + l31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < p.M) {
+          float v0 = acc[i][j][0][r], v1 = acc[i][j][1][r];
+          if (p.bias) {
+            const float bv = p.bias[m];
+            v0 += bv;
+            v1 += bv;
+          }
+          f32x2 o;
+          o[0] = apply_act(v0, p.act, p.slope);
+          o[1] = apply_act(v1, p.act, p.slope);
+          *reinterpret_cast<f32x2 *>(yb + (long)m * HWb) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int BM>
+__global__ __launch_bounds__(256, 2) void igemm_t3x3s2_kernel(TS2Params p) {
+  __shared__ __attribute__((aligned(16))) float lds[TS_LDS_FLOATS];
+  if (blockIdx.z == 0)
+    ts2_body<0, BM>(p, lds);
+  else
+    ts2_body<1, BM>(p, lds);
+}
 
 // -------------------------------------------------------------------------------------------
 // Split-precision variant of the 3x3 / stride-1 / width-32 kernel (math mode 2, experimental): every f32 operand
@@ -1647,6 +1828,56 @@ static int run_forward_dir(const float *in, const float *W, const float *bias, f
   return launch_f(p, cfg, st);
 }
 
+static bool t3x3s2_ok(int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad) {
+  const int tr = Cb >= 128 ? 4 : 8;
+  return R == 3 && S == 3 && st_ == 2 && pad == 1 && Hb == 2 * Hs && Wb == 2 * Ws && (Ws % 32) == 0 && (Hs % tr) == 0 &&
+         (Cs % TS_CC) == 0 && Cb >= 64;
+}
+
+// in [N][Cs][Hs][Ws] -> out [N][M][2Hs][2Ws]
+static int run_t3x3s2(const float *in, const float *W, const float *bias, float *out, int N, int Cs, int Hs, int Ws, int M,
+                      long sm, long sc, int act, float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+  TapList l;
+  l.T = 9;
+  for (int t = 0; t < 9; ++t) {
+    l.dh[t] = 0;
+    l.dw[t] = 0;
+    l.idx[t] = t;
+  }
+  const int RED = Cs * 9;
+  const int Mp = (int)align_up(M, 128);
+  const size_t need = class_bytes(RED, Mp);
+  if (need > ws_bytes) {
+    set_error("conv workspace too small: need %zu, have %zu", need, ws_bytes);
+    return LSPS_E_WS;
+  }
+  TS2Params p;
+  memset(&p, 0, sizeof(p));
+  const int2 *gtab_unused;
+  int rc = launch_pack(W, ws, M, Mp, RED, RED, l, sm, sc, Hs * Ws, Ws, st, &p.Wp, &gtab_unused, &p.zero, TS_CC);
+  if (rc) return rc;
+  p.X = in;
+  p.bias = bias;
+  p.Y = out;
+  p.Cx = Cs;
+  p.Hs = Hs;
+  p.Ws = Ws;
+  p.M = M;
+  p.Mp = Mp;
+  p.qblocks = Ws / 32;
+  p.act = act;
+  p.slope = slope;
+  if (M >= 128) {
+    p.tiles_per_img = (Hs / 4) * p.qblocks;
+    hipLaunchKernelGGL(igemm_t3x3s2_kernel<128>, dim3(N * p.tiles_per_img, ceil_div(M, 128), 2), dim3(256), 0, st, p);
+  } else {
+    p.tiles_per_img = (Hs / 8) * p.qblocks;
+    hipLaunchKernelGGL(igemm_t3x3s2_kernel<64>, dim3(N * p.tiles_per_img, ceil_div(M, 64), 2), dim3(256), 0, st, p);
+  }
+  LSPS_CHECK_LAUNCH("igemm_t3x3s2");
+  return 0;
+}
+
 // "transposed direction": in = small image [N][Cs][Hs][Ws], out = big image [N][Cb][Hb][Wb]
 //   out[n][m][h][w] = sum_{c,r,s} W(m,c,r,s) * in[n][c][(h+pad-r)/st][(w+pad-s)/st]   (divisible, in range)
 static int run_transposed_dir(const float *in, const float *W, const float *bias, float *out, int N, int Cb, int Hb,
@@ -1656,6 +1887,10 @@ static int run_transposed_dir(const float *in, const float *W, const float *bias
   // stride-1 transposed conv == forward 3x3 conv with flipped taps (dh = pad - r)
   if (f3x3_ok(Cs, Hs, Ws, R, S, st_, pad) && Hb == Hs && Wb == Ws && Cb >= 128)
     return run_f3x3(in, W, bias, out, N, Cs, Hs, Cb, sm, sc, true, act, slope, ws, ws_bytes, st);
+#endif
+#ifndef LSPS_NO_T3X3S2
+  if (t3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad) && (g_math_mode != 1 || Cb < 128))
+    return run_t3x3s2(in, W, bias, out, N, Cs, Hs, Ws, Cb, sm, sc, act, slope, ws, ws_bytes, st);
 #endif
   const int M = Cb;
   const int Mp = (int)align_up(M, 128);

@@ -45,10 +45,14 @@ class Profiler(object):
         self.records = []
 
     @staticmethod
-    def f_kernel(M, cin=0, h=0, w=0, r=0, stride=0, pad=0):
-        """Name of the kernel the C library dispatches to (mirrors igemm.hip: f3x3_ok / choose_cfg)."""
+    def f_kernel(M, cin=0, h=0, w=0, r=0, stride=0, pad=0, transposed=False):
+        """Name of the kernel the C library dispatches to (mirrors igemm.hip: f3x3_ok / t3x3s2_ok / choose_cfg).
+        `h`, `w`: the kernel's INPUT image; `transposed`: conv dgrad / convT forward (small image -> big image)."""
         if r == 3 and stride == 1 and pad == 1 and w == 32 and h % 4 == 0 and cin % 8 == 0 and M >= 128:
             return 'igemm_f3x3_kernel'
+        if transposed and r == 3 and stride == 2 and pad == 1 and w % 32 == 0 and h % (4 if M >= 128 else 8) == 0 \
+                and cin % 16 == 0 and M >= 64 and (get_math_mode() != 'bf16' or M < 128):
+            return 'igemm_t3x3s2_kernel'
         return 'igemm_f_kernel<2,2,2,2>' if M >= 128 else ('igemm_f_kernel<2,2,1,4>' if M >= 64 else 'igemm_f_kernel<1,2,1,4>')
 
     @staticmethod
@@ -142,8 +146,8 @@ class _Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            with profiler.span(Profiler.f_kernel(C, K, dy.shape[2], dy.shape[3], R if R == S else 0, stride, pad), flops,
-                               stride * stride):
+            kname = Profiler.f_kernel(C, K, dy.shape[2], dy.shape[3], R if R == S else 0, stride, pad, True)
+            with profiler.span(kname, flops, 1 if 't3x3s2' in kname else stride * stride):
                 _lib.check(L.lsps_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, C, H, W, K, R, S, stride,
                                                pad, ws, wsb, st), 'conv2d_dgrad')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -176,7 +180,8 @@ class _ConvT2dFn(torch.autograd.Function):
         Ho, Wo = convT_out_size(H, R, stride, pad, outpad), convT_out_size(W, S, stride, pad, outpad)
         y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
         ws, wsb = _lib.workspace(L.lsps_convT2d_workspace_bytes(N, Ci, H, W, Co, R, S, stride, pad, outpad), x.device)
-        with profiler.span(Profiler.f_kernel(Co), 2.0 * N * Ci * H * W * Co * R * S, stride * stride):
+        kname = Profiler.f_kernel(Co, Ci, H, W, R if R == S else 0, stride, pad, True)
+        with profiler.span(kname, 2.0 * N * Ci * H * W * Co * R * S, 1 if 't3x3s2' in kname else stride * stride):
             _lib.check(L.lsps_convT2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, Ci, H, W, Co, R, S,
                                           stride, pad, outpad, act, slope, ws, wsb, _lib.stream()), 'convT2d_fwd')
         ctx.geom = (N, Ci, H, W, Co, R, S, stride, pad, outpad, act, slope)
