@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
 
 struct W3Params {
   const float *DY, *X, *zero;
-  float *part;                   // [splits][9][M][C]
+  float *part;                   // [splits][M][C][9]
   int N, M, C, H;
   int nchunks, chunks_per_split; // chunk = (n, row pair)
 };
@@ -1230,14 +1230,14 @@ __global__ __launch_bounds__(256, 2) void igemm_w3x3_kernel(W3Params p) {
   }
 
   const int c = c0 + wn * 32 + l31;
+  // partials in the weight's own layout [split][m][c][t]: a lane's nine taps are 36 contiguous bytes, a wave row is
+  // 1152 contiguous bytes (merged in L2), and the reduction over splits is a plain coalesced sum
+  float *out = p.part + (long)split * p.M * p.C * 9 + (long)c * 9;
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    float *out = p.part + ((long)(split * 9 + t) * p.M) * p.C + c;
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      out[(long)m * p.C] = acc[t][r];
-    }
+    for (int t = 0; t < 9; ++t) out[(long)m * p.C * 9 + t] = acc[t][r];
   }
 }
 
@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(256, 2) void igemm_w3x3_kernel(W3Params p) {
 
 struct WS2Params {
   const float *Small, *Big, *zero;
-  float *part;                   // [splits][9][M][C]
+  float *part;                   // [splits][M][C][9]
   int N, M, C, Hs, Ws;
   int qblocks;                   // Ws / 32
   int nchunks, chunks_per_split; // chunk = (n, small row, 32-column block)
@@ -1385,45 +1385,29 @@ __global__ __launch_bounds__(512, 2) void igemm_w3x3s2_kernel(WS2Params p) {
   }
 
   const int c = c0 + wn * 32 + l31;
+  // partials in the weight's own layout [split][m][c][t]: a lane's nine taps are 36 contiguous bytes, a wave row is
+  // 1152 contiguous bytes (merged in L2), and the reduction over splits is a plain coalesced sum
+  float *out = p.part + (long)split * p.M * p.C * 9 + (long)c * 9;
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    float *out = p.part + ((long)(split * 9 + t) * p.M) * p.C + c;
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      out[(long)m * p.C] = acc[t][r];
-    }
+    for (int t = 0; t < 9; ++t) out[(long)m * p.C * 9 + t] = acc[t][r];
   }
-}
-
-// dW[(m*C + c)*9 + t] = sum_s part[s][t][m][c]   (write-coalesced; the strided partial reads hit in L2 — the
-// read-coalesced / scattered-write variant measured 0.3 ms slower per layer)
-__global__ __launch_bounds__(256) void reduce_w3x3_kernel(const float *__restrict__ part, float *__restrict__ dw, int M,
-                                                          int C, int splits) {
-  // 64 outputs per block, 4 threads per output (each sums every 4th split, fixed order -> deterministic)
-  __shared__ float red[4][64];
-  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + o;                 // index into dW [m][c][t]
-  const long total = (long)M * C * 9;
-  float s = 0.f;
-  if (i < total) {
-    const int t = (int)(i % 9);
-    const long mc = i / 9;
-    const float *src = part + (long)t * M * C + mc;
-    const long stride = 9L * M * C;
-    for (int k = g; k < splits; k += 4) s += src[k * stride];
-  }
-  red[g][o] = s;
-  __syncthreads();
-  if (g == 0 && i < total) dw[i] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
 }
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *part, float *out, long n, int splits) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += part[(long)k * n + i];
-  out[i] = s;
+  // eight independent loads in flight per thread; fixed summation order (deterministic)
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += part[(long)(k + u) * n + i];
+  }
+  for (; k < splits; ++k) s[0] += part[(long)k * n + i];
+  out[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 
@@ -2024,9 +2008,9 @@ static int run_w3x3(const float *dy, const float *x, float *dW, int N, int C, in
     hipLaunchKernelGGL(igemm_w3x3_kernel<0>, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_w3x3");
   const long total = (long)M * C * 9;
-  hipLaunchKernelGGL(reduce_w3x3_kernel, dim3(ceil_div(total, 64)), dim3(256), 0, st, (const float *)p.part, dW, M, C,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float *)p.part, dW, total,
                      splits);
-  LSPS_CHECK_LAUNCH("reduce_w3x3");
+  LSPS_CHECK_LAUNCH("reduce_partials");
   return 0;
 }
 
@@ -2088,9 +2072,9 @@ static int run_w3x3s2(const float *small, const float *big, float *dW, int N, in
   hipLaunchKernelGGL(igemm_w3x3s2_kernel, dim3(C / 64, M / 128, splits), dim3(512), WS2_LDS_BYTES, st, p);
   LSPS_CHECK_LAUNCH("igemm_w3x3s2");
   const long total = (long)M * C * 9;
-  hipLaunchKernelGGL(reduce_w3x3_kernel, dim3(ceil_div(total, 64)), dim3(256), 0, st, (const float *)p.part, dW, M, C,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float *)p.part, dW, total,
                      splits);
-  LSPS_CHECK_LAUNCH("reduce_w3x3");
+  LSPS_CHECK_LAUNCH("reduce_partials");
   return 0;
 }
 
