@@ -128,7 +128,7 @@ def main():
     for _ in range(args.warmup):
         pretrain_step()
     ops.profiler.reset()
-    ops.profiler.enabled = True
+    ops.profiler.enabled = os.environ.get('LSPS_BENCH_NO_EVENTS') != '1'   # debugging aid: time without the HIP events
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -91,6 +91,12 @@ int lsps_inorm_bwd(const float *dout, const float *out, const float *residual /*
  * dx = dy * act'(.) ; kind = LSPS_ACT_LRELU (uses sign of out) or LSPS_ACT_TANH (1-out^2).
  * dx may alias dy.  (autograd of common_net.py:252,264; lsps_nets.py:228)                     */
 int lsps_act_bwd(const float *dy, const float *out, float *dx, long n, int kind, float slope, void *stream);
+/* lsps_act_bwd fused with the bias gradient of a conv / transposed-conv layer whose output went through the
+ * activation (reference: autograd of nn.LeakyReLU / nn.Tanh followed by the bias term of convolution_backward,
+ * common_net.py:250-252, 262-264): dx = dy * act'(out) for [N][C][HW] tensors and db[c] = sum_{n,hw} dx.  One pass.
+ * ws: >= 64*C floats of scratch (the layer's conv workspace is large enough). */
+int lsps_act_bwd_bias(const float *dy, const float *out, float *dx, float *db, int N, int C, int HW, int kind,
+                      float slope, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- losses (lsps_trainer.py:42-60, :107-112, :172-192; helpers.py:20-32) -------------------
  * Forward kernels write ONE float (already divided by `denom`) to out[0].

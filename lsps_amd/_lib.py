@@ -33,6 +33,7 @@ _SIGNATURES = {
     'lsps_inorm_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     'lsps_inorm_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     'lsps_act_bwd': (c_int, [_P, _P, _P, c_long, c_int, c_float, _P]),
+    'lsps_act_bwd_bias': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
     'lsps_loss_workspace_bytes': (c_size_t, [c_long]),
     'lsps_loss_fwd': (c_int, [c_int, _P, _P, c_long, c_float, _P, _P, c_size_t, _P]),
     'lsps_loss_bwd': (c_int, [c_int, _P, _P, c_long, c_float, _P, _P, _P, _P]),

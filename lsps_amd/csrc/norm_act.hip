@@ -182,6 +182,62 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ 
   }
 }
 
+// act_bwd fused with the bias gradient of the same layer: dx = dy * act'(out) and part[s][c] = sum of dx over this block's
+// slice of channel c (conv bias gradient = sum of the pre-activation gradient over n, h, w).  One pass over (dy, out)
+// instead of act_bwd followed by a separate reduction pass over dx.  grid (C, S).
+__global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float *__restrict__ dy, const float *__restrict__ out,
+                                                           float *__restrict__ dx, float *__restrict__ part, int N, int C,
+                                                           int HW, long slice, int kind, float slope) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, sidx = blockIdx.y;
+  const long total = (long)N * HW;
+  const long e0 = (long)sidx * slice;
+  long e1 = e0 + slice;
+  if (e1 > total) e1 = total;
+  float s = 0.f;
+  if ((HW & 3) == 0) {
+    for (long e = e0 + (long)threadIdx.x * 4; e < e1; e += 1024) {
+      const long n = e / HW;
+      const long off = (n * C + c) * HW + (e - n * HW);
+      const float4 d = *reinterpret_cast<const float4 *>(dy + off);
+      const float4 o = *reinterpret_cast<const float4 *>(out + off);
+      float4 r;
+      if (kind == LSPS_ACT_LRELU) {
+        r.x = o.x > 0.f ? d.x : d.x * slope;
+        r.y = o.y > 0.f ? d.y : d.y * slope;
+        r.z = o.z > 0.f ? d.z : d.z * slope;
+        r.w = o.w > 0.f ? d.w : d.w * slope;
+      } else {
+        r.x = d.x * (1.f - o.x * o.x);
+        r.y = d.y * (1.f - o.y * o.y);
+        r.z = d.z * (1.f - o.z * o.z);
+        r.w = d.w * (1.f - o.w * o.w);
+      }
+      *reinterpret_cast<float4 *>(dx + off) = r;
+      s += (r.x + r.y) + (r.z + r.w);
+    }
+  } else {
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+      const long n = e / HW;
+      const long off = (n * C + c) * HW + (e - n * HW);
+      const float o = out[off], d = dy[off];
+      const float r = kind == LSPS_ACT_LRELU ? (o > 0.f ? d : d * slope) : d * (1.f - o * o);
+      dx[off] = r;
+      s += r;
+    }
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) part[(long)sidx * C + c] = s;
+}
+
+__global__ __launch_bounds__(256) void sum_slices_kernel(const float *__restrict__ part, float *__restrict__ out, int C, int S) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += part[(long)k * C + c];
+  out[c] = s;
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(const float *__restrict__ x, const float *__restrict__ y, float alpha,
                                                    float *__restrict__ out, long n) {
   const long stride = (long)gridDim.x * 256 * 4;
@@ -255,6 +311,42 @@ int lsps_act_bwd(const float *dy, const float *out, float *dx, long n, int kind,
   if (n == 0) return 0;
   hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, out, dx, n, kind, slope);
   LSPS_CHECK_LAUNCH("act_bwd");
+  return 0;
+}
+
+int lsps_act_bwd_bias(const float *dy, const float *out, float *dx, float *db, int N, int C, int HW, int kind, float slope,
+                      void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(dy && out && dx && db && N >= 0 && C > 0 && HW > 0, "act_bwd_bias: bad argument");
+  LSPS_CHECK_ARG(kind == LSPS_ACT_LRELU || kind == LSPS_ACT_TANH, "act_bwd_bias: unknown activation");
+  LSPS_CHECK_ARG((((uintptr_t)dy | (uintptr_t)out | (uintptr_t)dx) & 15) == 0, "act_bwd_bias: pointers must be 16-byte aligned");
+  const long total = (long)N * HW;
+  long S = (total + 32767) / 32768;            // >= 32 K elements per block, at most 64 slices
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  if (S > 1 && (ws == nullptr || (size_t)S * C * sizeof(float) > ws_bytes)) {
+    set_error("act_bwd_bias: workspace too small: need %zu, have %zu", (size_t)S * C * sizeof(float), ws_bytes);
+    return LSPS_E_WS;
+  }
+  if (total == 0) {
+    hipError_t e = hipMemsetAsync(db, 0, (size_t)C * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) {
+      set_error("hipMemsetAsync: %s", hipGetErrorString(e));
+      return LSPS_E_HIP;
+    }
+    return 0;
+  }
+  long slice = (total + S - 1) / S;
+  slice = (slice + 3) / 4 * 4;
+  float *part = S == 1 ? db : (float *)ws;
+  hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(C, (int)S), dim3(256), 0, (hipStream_t)stream, dy, out, dx, part, N, C, HW,
+                     slice, kind, slope);
+  LSPS_CHECK_LAUNCH("act_bwd_bias");
+  if (S > 1) {
+    hipLaunchKernelGGL(sum_slices_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float *)part, db,
+                       C, (int)S);
+    LSPS_CHECK_LAUNCH("act_bwd_bias_reduce");
+  }
   return 0;
 }
 

@@ -109,6 +109,21 @@ def convT_out_size(h, r, stride, pad, outpad):
 # ------------------------------------------------------------------------------------------
 # Conv2d (+ fused bias and LeakyReLU/Tanh epilogue)
 # ------------------------------------------------------------------------------------------
+def _act_backward(L, dy, y, act, slope, want_db, channels, ws, wsb, st):
+    """Gradient through the fused output activation of a conv / transposed conv.  When the layer's bias gradient is
+    wanted too it comes out of the same pass (db = sum over n, h, w of the pre-activation gradient)."""
+    if act == ACT_NONE:
+        return dy, None
+    dpre = torch.empty_like(dy)
+    if want_db:
+        db = torch.empty(channels, dtype=torch.float32, device=dy.device)
+        _lib.check(L.lsps_act_bwd_bias(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dpre), _lib.ptr(db), dy.shape[0], channels,
+                                       dy.shape[2] * dy.shape[3], act, slope, ws, wsb, st), 'act_bwd_bias')
+        return dpre, db
+    _lib.check(L.lsps_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dpre), dy.numel(), act, slope, st), 'act_bwd')
+    return dpre, None
+
+
 class _Conv2dFn(torch.autograd.Function):
     """nn.Conv2d [+ nn.LeakyReLU(inplace)] — common_net.py:250-252, 162-163; lsps_nets.py:123-124."""
 
@@ -138,12 +153,9 @@ class _Conv2dFn(torch.autograd.Function):
         dy = _c(dy)
         st = _lib.stream()
         flops = 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S
-        if act != ACT_NONE:
-            dpre = torch.empty_like(dy)
-            _lib.check(L.lsps_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dpre), dy.numel(), act, slope, st), 'act_bwd')
-            dy = dpre
         ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, R, S, stride, pad), x.device)
         dx = dw = db = None
+        dy, db = _act_backward(L, dy, y, act, slope, ctx.has_bias and ctx.needs_input_grad[2], K, ws, wsb, st)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             kname = Profiler.f_kernel(C, K, dy.shape[2], dy.shape[3], R if R == S else 0, stride, pad, True)
@@ -152,11 +164,12 @@ class _Conv2dFn(torch.autograd.Function):
                                                pad, ws, wsb, st), 'conv2d_dgrad')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = torch.empty(K, dtype=torch.float32, device=x.device)
+            db_here = None                  # the bias gradient, unless the fused act_bwd pass already produced it
+            if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
+                db = db_here = torch.empty(K, dtype=torch.float32, device=x.device)
             with profiler.span(Profiler.w_kernel(C, H, W, K, R if R == S else 0, stride, pad), flops, 1):
-                _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), N, C, H, W, K, R,
-                                               S, stride, pad, ws, wsb, st), 'conv2d_wgrad')
+                _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db_here), N, C, H, W, K,
+                                               R, S, stride, pad, ws, wsb, st), 'conv2d_wgrad')
         return dx, dw, db, None, None, None, None
 
 
@@ -197,12 +210,9 @@ class _ConvT2dFn(torch.autograd.Function):
         dy = _c(dy)
         st = _lib.stream()
         flops = 2.0 * N * Ci * H * W * Co * R * S
-        if act != ACT_NONE:
-            dpre = torch.empty_like(dy)
-            _lib.check(L.lsps_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dpre), dy.numel(), act, slope, st), 'act_bwd')
-            dy = dpre
         ws, wsb = _lib.workspace(L.lsps_convT2d_workspace_bytes(N, Ci, H, W, Co, R, S, stride, pad, outpad), x.device)
         dx = dw = db = None
+        dy, db = _act_backward(L, dy, y, act, slope, ctx.has_bias and ctx.needs_input_grad[2], Co, ws, wsb, st)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             with profiler.span(Profiler.f_kernel(Ci), flops, 1):
@@ -210,10 +220,11 @@ class _ConvT2dFn(torch.autograd.Function):
                                                 pad, outpad, ws, wsb, st), 'convT2d_dgrad')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = torch.empty(Co, dtype=torch.float32, device=x.device)
+            db_here = None
+            if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
+                db = db_here = torch.empty(Co, dtype=torch.float32, device=x.device)
             with profiler.span(Profiler.w_kernel(Co, dy.shape[2], dy.shape[3], Ci, R if R == S else 0, stride, pad), flops, 1):
-                _lib.check(L.lsps_convT2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), N, Ci, H, W, Co,
+                _lib.check(L.lsps_convT2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db_here), N, Ci, H, W, Co,
                                                 R, S, stride, pad, outpad, ws, wsb, st), 'convT2d_wgrad')
         return dx, dw, db, None, None, None, None, None
 
