@@ -1413,6 +1413,261 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *part,
 
 
 // -------------------------------------------------------------------------------------------
+// Single-input-channel convolutions (the 7x7 stems: 1 -> 64 channels, stride 1 in the generator, stride 2 in the
+// discriminator).  They carry 0.3 % of the flops but stream the largest activations of the net (64 x 128 x 128 floats
+// per sample), so they are HBM-bound: the kernels below read the input image / dy and write the output exactly once.
+// The contraction (49 taps, padded to 50) still runs on the matrix pipe — K = taps for the forward, K = pixels for the
+// weight gradient — with the image rows staged in LDS (zero halo) and the taps as per-lane LDS offsets.
+// -------------------------------------------------------------------------------------------
+#define C1_KS 25                  // k-steps of 2 taps: up to 50 taps (7x7 = 49)
+#define C1_MAXLDS 5400            // floats of staged image rows (21 KB: with the weight tile a workgroup stays under 36 KB)
+
+struct C1Params {
+  const float *X, *W, *bias;
+  float *Y;
+  int N, H, Wd, K, P, Q, R, S, stride, pad;
+  int TP, rows, LW;              // output rows per workgroup, staged input rows, LDS row stride (Wd + 2 pad)
+  int act;
+  float slope;
+};
+
+__device__ __forceinline__ void c1_stage_rows(float *xs, const float *xn, int row0, int rows, int LW, int H, int Wd, int pad,
+                                               int tid, int nthreads) {
+  for (int u = tid; u < rows * LW; u += nthreads) {
+    const int r = u / LW, c = u - r * LW;
+    const int ih = row0 + r, iw = c - pad;
+    const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < Wd;
+    // unconditional load from a clamped address + select: a predicated load makes hipcc branch around every load
+    const float v = xn[(long)min(max(ih, 0), H - 1) * Wd + min(max(iw, 0), Wd - 1)];
+    xs[u] = ok ? v : 0.f;
+  }
+}
+
+// out[n][k][p][q] = act(bias[k] + sum_t W[k][t] * x[n][p*s + r_t - pad][q*s + c_t - pad]);  grid (P/TP, ceil(K/64), N)
+#define C1_WLD 51                 // LDS row stride of the zero-padded weight tile [64 k][50 taps] (51 % 32 = 19: conflict-free)
+#define C1_FIXED_LDS ((64 * C1_WLD + 64 + 2 * C1_KS) * sizeof(float))
+// The stores are the floor here (64 x 128 x 128 floats per sample; a store-only variant of this kernel runs at 4.0 TB/s,
+// a compute-only one at 0.86 of that time).  Weights and tap offsets live in registers for the whole workgroup; a
+// variant that re-read them from LDS to run 4 waves per SIMD was not faster.
+__global__ __launch_bounds__(256, 2) void c1_fwd_kernel(C1Params p) {
+  extern __shared__ __attribute__((aligned(16))) float c1_lds[];
+  float *wl = c1_lds, *bl = wl + 64 * C1_WLD;
+  int *tl = reinterpret_cast<int *>(bl + 64);
+  float *xs = bl + 64 + 2 * C1_KS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int n = blockIdx.z, m0 = blockIdx.y * 64, p0 = blockIdx.x * p.TP;
+  const int T = p.R * p.S;
+
+  c1_stage_rows(xs, p.X + (long)n * p.H * p.Wd, p0 * p.stride - p.pad, p.rows, p.LW, p.H, p.Wd, p.pad, tid, 256);
+  // weights (coalesced: 64 x T contiguous floats), bias and tap offsets go through LDS once per workgroup
+  for (int u = tid; u < 64 * 2 * C1_KS; u += 256) {
+    const int k = u / (2 * C1_KS), t = u - k * (2 * C1_KS);
+    const bool ok = t < T && m0 + k < p.K;
+    const float v = p.W[(long)min(m0 + k, p.K - 1) * T + min(t, T - 1)];
+    wl[k * C1_WLD + t] = ok ? v : 0.f;
+  }
+  if (tid < 64) {
+    const float v = p.bias ? p.bias[min(m0 + tid, p.K - 1)] : 0.f;
+    bl[tid] = v;
+  }
+  if (tid < 2 * C1_KS) {
+    const int r = tid < T ? tid / p.S : 0, c = tid < T ? tid - r * p.S : 0;
+    tl[tid] = r * p.LW + c;
+  }
+  __syncthreads();
+
+  float a[C1_KS][2];
+  int boff[C1_KS];
+#pragma unroll
+  for (int ks = 0; ks < C1_KS; ++ks) {
+    boff[ks] = tl[2 * ks + half];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[ks][i] = wl[(i * 32 + l31) * C1_WLD + 2 * ks + half];
+  }
+  const int qblocks = p.Q / 32, nseg = p.TP * qblocks;
+  const long PQ = (long)p.P * p.Q;
+  const bool lrelu = p.act == LSPS_ACT_LRELU, other = p.act != LSPS_ACT_LRELU && p.act != LSPS_ACT_NONE;
+  const bool full = m0 + 64 <= p.K;
+  for (int seg = wave; seg < nseg; seg += 4) {
+    const int pr = seg / qblocks, q0 = (seg - pr * qblocks) * 32;
+    const float *Bp = xs + pr * p.stride * p.LW + (q0 + l31) * p.stride;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#ifdef LSPS_ABL_C1_NOMFMA
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#else
+#pragma unroll
+    for (int ks = 0; ks < C1_KS; ++ks) {
+#endif
+      const float b = Bp[boff[ks]];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][i], b, acc[i], 0, 0, 0);
+    }
+#ifdef LSPS_ABL_C1_NOSTORE
+    if (acc[0][0] != 123.f && acc[1][3] != 77.f) continue;
+#endif
+    float *yb = p.Y + ((long)n * p.K + m0) * PQ + (long)(p0 + pr) * p.Q + q0 + l31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[i][r] + bl[kl];
+        if (lrelu) v = v > 0.f ? v : v * p.slope;
+        if (other) v = apply_act(v, p.act, p.slope);
+        if (full || m0 + kl < p.K) yb[(long)kl * PQ] = v;
+      }
+  }
+}
+
+// dW[k][t] = sum_{n,p,q} dy[n][k][p][q] * x[n][p*s + r_t - pad][q*s + c_t - pad]   (K <= 64, T <= 64, Q in {32, 64, 128})
+// Per iteration: RB = 128 / Q output rows of one image (128 pixels = one 32-pixel segment per wave): dy[64 k][128] and
+// the (RB-1)*s + R input rows are staged in LDS; the reduction index of the MFMA is the pixel, its columns are the
+// taps (per-lane LDS offsets).  Both operands of the NEXT iteration are fetched into registers before the MFMAs of the
+// current one are issued.
+#define C1W_LDA 129
+#define C1W_XMAX 1536             // floats of staged input rows: 6 per thread
+struct C1WParams {
+  const float *X, *DY;
+  float *part;                   // [blocks][K * T]
+  int N, H, Wd, K, P, Q, R, S, stride, pad;
+  int LW, RB, xrows;             // LDS row stride (Wd + 2 pad), output rows per iteration, staged input rows
+  int iters_total, iters_per_block;      // iterations = N * P / RB
+};
+
+__global__ __launch_bounds__(256, 2) void c1_wgrad_kernel(C1WParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[64 * C1W_LDA + C1W_XMAX];
+  float *dys = lds, *xs = lds + 64 * C1W_LDA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int T = p.R * p.S;
+  const long PQ = (long)p.P * p.Q;
+  const int HWx = p.H * p.Wd;
+
+  int toff[2];                    // LDS offset of this lane's tap in column tiles 0 (taps 0..31) and 1 (taps 32..63)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int t = j * 32 + l31;
+    const int r = t < T ? t / p.S : 0, c = t < T ? t - r * p.S : 0;
+    toff[j] = r * p.LW + c;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging assignment (fixed per thread): dy float4 u = tid + 256 i -> (k, 4 pixels of the 128); x element u -> (row, col)
+  const int q4 = p.Q / 4;
+  int d_off[8], d_lds[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int u = tid + 256 * i;
+    const int k = u >> 5, c4 = u & 31;                     // 32 float4 = 128 pixels per channel
+    const int rb = c4 / q4, cq = c4 - rb * q4;             // pixel -> (row in the iteration, column)
+    d_off[i] = (k < p.K ? k : 0) * (int)PQ + rb * p.Q + cq * 4;
+    d_lds[i] = k * C1W_LDA + c4 * 4;
+  }
+  const int xcount = p.xrows * p.LW;
+  int x_r[6], x_c[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int u = tid + 256 * i;
+    x_r[i] = u / p.LW;
+    x_c[i] = u - x_r[i] * p.LW - p.pad;
+  }
+
+  f32x4 dreg[8];
+  float xreg[6];
+  auto fetch = [&](int it) {
+    const int n = it / (p.P / p.RB), pr = (it - n * (p.P / p.RB)) * p.RB;
+    const float *dyn = p.DY + (long)n * p.K * PQ + (long)pr * p.Q;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dreg[i] = *reinterpret_cast<const f32x4 *>(dyn + d_off[i]);
+    const float *xn = p.X + (long)n * HWx;
+    const int row0 = pr * p.stride - p.pad;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int ih = row0 + x_r[i], iw = x_c[i];
+      const bool ok = tid + 256 * i < xcount && ih >= 0 && ih < p.H && iw >= 0 && iw < p.Wd;
+      const float v = xn[min(max(ih, 0), p.H - 1) * p.Wd + min(max(iw, 0), p.Wd - 1)];     // clamped, unconditional
+      xreg[i] = ok ? v : 0.f;
+    }
+  };
+
+  const int it_begin = blockIdx.x * p.iters_per_block;
+  int it_end = it_begin + p.iters_per_block;
+  if (it_end > p.iters_total) it_end = p.iters_total;
+  if (it_begin < it_end) fetch(it_begin);
+  const int qblocks = p.Q / 32;
+  const int srow = wave / qblocks, sq0 = (wave - srow * qblocks) * 32;      // this wave's segment: (row, first column)
+  const float *Ap = dys + l31 * C1W_LDA + wave * 32 + half;
+  const float *Bp = xs + srow * p.stride * p.LW + (sq0 + half) * p.stride;
+  for (int it = it_begin; it < it_end; ++it) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool live = (tid + 256 * i) >> 5 < p.K;        // channels >= K are zero rows
+      float *d = dys + d_lds[i];
+      d[0] = live ? dreg[i][0] : 0.f;
+      d[1] = live ? dreg[i][1] : 0.f;
+      d[2] = live ? dreg[i][2] : 0.f;
+      d[3] = live ? dreg[i][3] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (tid + 256 * i < xcount) xs[tid + 256 * i] = xreg[i];
+    __syncthreads();
+    if (it + 1 < it_end) fetch(it + 1);
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {             // pixels 2ks + half of the wave's segment
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = Ap[i * 32 * C1W_LDA + 2 * ks];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bp[toff[j] + 2 * ks * p.stride];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // the four waves' partial sums are added in a fixed order through LDS (deterministic), then written once per block
+  float *red = lds;               // [64 k][64 t]
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, t = j * 32 + l31;
+            const float v = acc[i][j][r];
+            red[k * 64 + t] = w == 0 ? v : red[k * 64 + t] + v;
+          }
+    }
+  }
+  __syncthreads();
+  float *out = p.part + (long)blockIdx.x * p.K * T;
+  for (int u = tid; u < p.K * T; u += 256) {
+    const int k = u / T, t = u - k * T;
+    out[u] = red[k * 64 + t];
+  }
+}
+
+// -------------------------------------------------------------------------------------------
 // col2im for the dgrad of a 1-input-channel conv computed as a GEMM over taps:
 //   Z[n][t][p][q] = sum_k W[k][t] dy[n][k][p][q]   (MFMA kernel, M = R*S rows)
 //   dx[n][h][w]   = sum_{t=(r,s) valid} Z[n][t][(h+pad-r)/st][(w+pad-s)/st]
@@ -1734,6 +1989,45 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   return 0;
 }
 
+static bool c1_fwd_ok(int Cb, int Hb, int Wb, int Hs, int Ws, int R, int S, int st_, int pad, long sm) {
+  return Cb == 1 && R * S <= 2 * C1_KS && (Ws % 32) == 0 && (st_ == 1 || st_ == 2) && sm == (long)R * S &&
+         (long)R * (Wb + 2 * pad) <= C1_MAXLDS;
+}
+
+static int run_c1_fwd(const float *in, const float *W, const float *bias, float *out, int N, int Hb, int Wb, int M, int Hs,
+                      int Ws, int R, int S, int st_, int pad, int act, float slope, hipStream_t st) {
+  C1Params p;
+  memset(&p, 0, sizeof(p));
+  p.X = in;
+  p.W = W;
+  p.bias = bias;
+  p.Y = out;
+  p.N = N;
+  p.H = Hb;
+  p.Wd = Wb;
+  p.K = M;
+  p.P = Hs;
+  p.Q = Ws;
+  p.R = R;
+  p.S = S;
+  p.stride = st_;
+  p.pad = pad;
+  p.LW = Wb + 2 * pad;
+  // output rows per workgroup: as many as fit in LDS (amortises the weight / tap set-up), while >= 1024 workgroups remain
+  int tp = 32;
+  while (tp > 1 && ((Hs % tp) != 0 || (long)((tp - 1) * st_ + R) * p.LW > C1_MAXLDS ||
+                    ((long)N * (Hs / tp) * ceil_div(M, 64) < 1024 && tp > 4)))
+    tp >>= 1;
+  p.TP = tp;
+  p.rows = (tp - 1) * st_ + R;
+  p.act = act;
+  p.slope = slope;
+  hipLaunchKernelGGL(c1_fwd_kernel, dim3(Hs / tp, ceil_div(M, 64), N), dim3(256),
+                     C1_FIXED_LDS + (size_t)p.rows * p.LW * sizeof(float), st, p);
+  LSPS_CHECK_LAUNCH("c1_fwd");
+  return 0;
+}
+
 // "forward direction": in = big image [N][Cb][Hb][Wb], out = small image [N][Cs][Hs][Ws]
 //   out[n][m][p][q] = sum_{c,r,s} W(m,c,r,s) * in[n][c][p*st-pad+r][q*st-pad+s]
 //   weight element address: W[m*sm + c*sc + r*S + s]
@@ -1743,6 +2037,10 @@ static int run_forward_dir(const float *in, const float *W, const float *bias, f
 #ifndef LSPS_NO_F3X3
   if (f3x3_ok(Cb, Hb, Wb, R, S, st_, pad) && Cs >= 128)
     return run_f3x3(in, W, bias, out, N, Cb, Hb, Cs, sm, sc, false, act, slope, ws, ws_bytes, st);
+#endif
+#ifndef LSPS_NO_C1
+  if (c1_fwd_ok(Cb, Hb, Wb, Hs, Ws, R, S, st_, pad, sm))
+    return run_c1_fwd(in, W, bias, out, N, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad, act, slope, st);
 #endif
   TapList l;
   l.T = R * S;
@@ -2078,11 +2376,60 @@ static int run_w3x3s2(const float *small, const float *big, float *dW, int N, in
   return 0;
 }
 
+#define C1W_BLOCKS 512
+static bool c1_wgrad_ok(int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad) {
+  if (!(Cb == 1 && Cs <= 64 && R * S <= 64 && (Ws == 32 || Ws == 64 || Ws == 128) && (st_ == 1 || st_ == 2))) return false;
+  const int rb = 128 / Ws;
+  return (Hs % rb) == 0 && (long)((rb - 1) * st_ + R) * (Wb + 2 * pad) <= C1W_XMAX && (long)Cs * Hs * Ws < (1L << 31);
+}
+
+static size_t c1_wgrad_ws_bytes(int Cs, int R, int S) { return (size_t)C1W_BLOCKS * Cs * R * S * sizeof(float) + 256; }
+
+static int run_c1_wgrad(const float *small, const float *big, float *dW, int N, int Hb, int Wb, int Cs, int Hs, int Ws,
+                        int R, int S, int st_, int pad, void *ws, size_t ws_bytes, hipStream_t st) {
+  C1WParams p;
+  memset(&p, 0, sizeof(p));
+  p.X = big;
+  p.DY = small;
+  p.N = N;
+  p.H = Hb;
+  p.Wd = Wb;
+  p.K = Cs;
+  p.P = Hs;
+  p.Q = Ws;
+  p.R = R;
+  p.S = S;
+  p.stride = st_;
+  p.pad = pad;
+  p.LW = Wb + 2 * pad;
+  p.RB = 128 / Ws;
+  p.xrows = (p.RB - 1) * st_ + R;
+  p.iters_total = N * (Hs / p.RB);
+  int blocks = p.iters_total < C1W_BLOCKS ? p.iters_total : C1W_BLOCKS;
+  p.iters_per_block = ceil_div(p.iters_total, blocks);
+  blocks = ceil_div(p.iters_total, p.iters_per_block);
+  if (c1_wgrad_ws_bytes(Cs, R, S) > ws_bytes) {
+    set_error("wgrad workspace too small: need %zu, have %zu", c1_wgrad_ws_bytes(Cs, R, S), ws_bytes);
+    return LSPS_E_WS;
+  }
+  p.part = (float *)ws;
+  hipLaunchKernelGGL(c1_wgrad_kernel, dim3(blocks), dim3(256), 0, st, p);
+  LSPS_CHECK_LAUNCH("c1_wgrad");
+  const long nW = (long)Cs * R * S;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(nW, 256)), dim3(256), 0, st, (const float *)p.part, dW, nW, blocks);
+  LSPS_CHECK_LAUNCH("reduce_partials");
+  return 0;
+}
+
 // dW[m][(c,t)] = sum_{n,p,q} small[n][m][p][q] * big[n][c][p*st-pad+r][q*st-pad+s]
 static int run_wgrad(const float *small, const float *big, float *dW, int N, int Cb, int Hb, int Wb, int Cs, int Hs,
                      int Ws, int R, int S, int st_, int pad, void *ws, size_t ws_bytes, hipStream_t st) {
 #ifndef LSPS_NO_W3X3
   if (w3x3_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad)) return run_w3x3(small, big, dW, N, Cb, Hb, Cs, ws, ws_bytes, st);
+#endif
+#ifndef LSPS_NO_C1
+  if (c1_wgrad_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad))
+    return run_c1_wgrad(small, big, dW, N, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad, ws, ws_bytes, st);
 #endif
 #ifndef LSPS_NO_W3X3S2
   if (w3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad))
@@ -2201,6 +2548,7 @@ static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int W
     const size_t w3 = w3x3s2_ws_bytes(N, Cs, Cb, Hs, Ws);
     if (w3 > m) m = w3;
   }
+  if (Cb == 1 && Cs <= 64 && c1_wgrad_ws_bytes(Cs, R, S) > m) m = c1_wgrad_ws_bytes(Cs, R, S);
   return 2 * BIAS_WS_BYTES + m + ((size_t)8 << 20) + 1024;   // + 8 MiB: reduction-split partials of tiny forward problems
 }
 

@@ -53,6 +53,8 @@ class Profiler(object):
         if transposed and r == 3 and stride == 2 and pad == 1 and w % 32 == 0 and h % (4 if M >= 128 else 8) == 0 \
                 and cin % 16 == 0 and M >= 64 and (get_math_mode() != 'bf16' or M < 128):
             return 'igemm_t3x3s2_kernel'
+        if not transposed and cin == 1 and 0 < r * r <= 50 and stride in (1, 2) and w >= 32:
+            return 'c1_fwd_kernel'                # approximate mirror of c1_fwd_ok (output width % 32 == 0)
         return 'igemm_f_kernel<2,2,2,2>' if M >= 128 else ('igemm_f_kernel<2,2,1,4>' if M >= 64 else 'igemm_f_kernel<1,2,1,4>')
 
     @staticmethod
@@ -61,6 +63,8 @@ class Profiler(object):
             return 'igemm_w3x3_kernel'
         if r == 3 and stride == 2 and pad == 1 and cb % 64 == 0 and cs % 128 == 0 and wb % 64 == 0 and hb % 2 == 0:
             return 'igemm_w3x3s2_kernel'
+        if cb == 1 and cs <= 64 and 0 < r * r <= 64 and stride in (1, 2) and wb // stride in (32, 64, 128):
+            return 'c1_wgrad_kernel'
         return 'igemm_w_kernel'
 
     def span(self, key, flops, launches):

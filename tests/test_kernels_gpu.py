@@ -55,6 +55,9 @@ CONV_CASES = [
     (3, 64, 8, 64, 128, 3, 2, 1),       # specialised stride-2 kernels: non-square (4 x 32 out), odd N
     (1, 64, 4, 128, 128, 3, 2, 1),      # stride-2: two 32-column blocks per row, a single image
     (2, 128, 64, 64, 128, 3, 2, 1),     # stride-2: two big-channel tiles
+    (3, 1, 32, 64, 40, 5, 1, 2),        # single-input-channel kernels: 5x5, K not a multiple of 32, non-square
+    (2, 1, 16, 64, 64, 7, 2, 3),        # single-input-channel, stride 2, one row tile
+    (1, 1, 24, 32, 8, 3, 1, 1),         # single-input-channel 3x3, 8 output channels, row tile of 8 with 3 tiles
 ]
 
 
