@@ -573,6 +573,156 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
 
 
 // -------------------------------------------------------------------------------------------
+// "Forward direction" kernel specialised for 3x3 / STRIDE 2 / pad 1 (down-sampling convs forward, up-sampling
+// transposed convs' dgrad): in = big image [N][Cx][2P][2Q], out = small image [N][M][P][Q], Q % 32 == 0.
+// Same structure as igemm_f3x3_kernel (tile 128 channels x 4 output rows x 32 columns, 8 input channels per chunk,
+// weights [chunk][tap][8][Mp]); the 9 input rows of the tile are staged DE-INTERLEAVED by column parity like in
+// igemm_w3x3s2_kernel (per row: O'[33] = odd columns with the left neighbour first, then E[32] = even columns), so the
+// stride-2 taps are unit-stride LDS reads: s=0 -> O'[q], s=1 -> E[q], s=2 -> O'[q+1].
+// -------------------------------------------------------------------------------------------
+#define FS2_ROW 65
+#define FS2_ROWS 9                                   // 2 * 4 + 1 input rows per tile
+#define FS2_CH (FS2_ROWS * FS2_ROW)                  // 585 floats per channel (585 % 32 = 9)
+
+struct FS2Params {
+  const float *X, *Wp, *bias, *zero;
+  float *Y;
+  int Cx, P, Q, M, Mp;           // output [P][Q]; input [2P][2Q]
+  int qblocks, tiles_per_img;    // Q / 32, (P / 4) * qblocks
+  int act;
+  float slope;
+};
+
+__global__ __launch_bounds__(256, 2) void igemm_f3x3s2_kernel(FS2Params p) {
+  constexpr int BM = 128, RC = F3_CC * 9;
+  constexpr int A4 = RC * BM / 4 / 256;                            // 9 float4 of weights per thread per chunk
+  constexpr int LINES = F3_CC * FS2_ROWS;                          // 72 (channel, row) lines of 64 columns
+  constexpr int B4 = (LINES * 16 + 255) / 256;                     // 5 float4 of input per thread per chunk (4.5)
+  __shared__ __attribute__((aligned(16))) float lds[RC * BM + F3_CC * FS2_CH];
+  float *As = lds, *Bs = lds + RC * BM;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.y * BM;
+  const int n = blockIdx.x / p.tiles_per_img;
+  const int rem = blockIdx.x - n * p.tiles_per_img;
+  const int p0 = (rem / p.qblocks) * 4, q0 = (rem - (rem / p.qblocks) * p.qblocks) * 32;
+  const int Hx = 2 * p.P, Wx = 2 * p.Q, HWx = Hx * Wx;
+  const float *xn = p.X + (long)n * p.Cx * HWx;
+
+  int b_lds[B4], b_off[B4];
+  bool b_use[B4], b_ok[B4];
+#pragma unroll
+  for (int i = 0; i < B4; ++i) {
+    const int u = tid + 256 * i;
+    b_use[i] = u < LINES * 16;
+    const int line = u >> 4, c4 = u & 15;
+    const int chn = line / FS2_ROWS, r = line - chn * FS2_ROWS;
+    const int ih = 2 * p0 - 1 + r;
+    b_ok[i] = b_use[i] && ih >= 0;                                 // ih <= 2 p0 + 7 < 2P always
+    b_lds[i] = chn * FS2_CH + r * FS2_ROW + 2 * c4;
+    b_off[i] = chn * HWx + ih * Wx + 2 * q0 + c4 * 4;
+  }
+  const bool h_use = tid < LINES;                                   // column 2 q0 - 1 of every line
+  const int h_chn = tid / FS2_ROWS, h_r = tid - h_chn * FS2_ROWS;
+  const bool h_ok = h_use && (2 * p0 - 1 + h_r) >= 0 && q0 > 0;
+  const int h_off = h_chn * HWx + (2 * p0 - 1 + h_r) * Wx + 2 * q0 - 1;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 areg[A4], breg[B4];
+  float hreg = 0.f;
+  const int nchunks = p.Cx / F3_CC;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const float *Ap = As + half * BM + wm * 64 + l31;
+  const float *Bp = Bs + half * FS2_CH + wn * 4 * FS2_ROW + l31;     // wave's output rows wn*2 + j -> input rows 2(wn*2+j) + r
+
+  for (int ch = -1; ch < nchunks; ++ch) {
+    if (ch >= 0) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4 *>(As + (tid + 256 * i) * 4) = areg[i];
+#pragma unroll
+      for (int i = 0; i < B4; ++i)
+        if (b_use[i]) {
+          float *d = Bs + b_lds[i];
+          d[33] = breg[i][0];                                      // E[2 c4]
+          d[1] = breg[i][1];                                       // O'[2 c4 + 1]
+          d[34] = breg[i][2];                                      // E[2 c4 + 1]
+          d[2] = breg[i][3];                                       // O'[2 c4 + 2]
+        }
+      if (h_use) Bs[h_chn * FS2_CH + h_r * FS2_ROW] = hreg;        // O'[0]
+      __syncthreads();
+    }
+    if (ch + 1 < nchunks) {
+      const float *wsrc = p.Wp + (long)(ch + 1) * RC * p.Mp + m0;
+#pragma unroll
+      for (int i = 0; i < A4; ++i) {
+        const int u = tid + 256 * i;
+        const int row = u >> 5, c4 = u & 31;
+        areg[i] = *reinterpret_cast<const f32x4 *>(wsrc + (long)row * p.Mp + c4 * 4);
+      }
+      const float *xc = xn + (long)(ch + 1) * F3_CC * HWx;
+#pragma unroll
+      for (int i = 0; i < B4; ++i) {
+        const float *src = b_ok[i] ? (xc + b_off[i]) : p.zero;
+        breg[i] = *reinterpret_cast<const f32x4 *>(src);
+      }
+      {
+        const float *src = h_ok ? (xc + h_off) : p.zero;
+        hreg = *src;
+      }
+    }
+    if (ch >= 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int tr = t / 3, ts = t - tr * 3;
+        const int coff = ts == 1 ? 33 : (ts == 2 ? 1 : 0);
+#pragma unroll
+        for (int cp = 0; cp < F3_CC / 2; ++cp) {
+          const int kk = t * (F3_CC / 2) + cp;
+          float a[2], b[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[i] = Ap[2 * kk * BM + i * 32];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) b[j] = Bp[2 * cp * FS2_CH + (2 * j + tr) * FS2_ROW + coff];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const long PQ = (long)p.P * p.Q;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float *yb = p.Y + (long)n * p.M * PQ + (long)(p0 + wn * 2 + j) * p.Q + q0 + l31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < p.M) {
+          float v = acc[i][j][r];
+          if (p.bias) v += p.bias[m];
+          yb[(long)m * PQ] = apply_act(v, p.act, p.slope);
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
 // "Transposed direction" kernel specialised for 3x3 / STRIDE 2 / pad 1 (the up-sampling transposed convs forward,
 // the down-sampling convs' dgrad): in = small image [N][Cx][Hs][Ws] (Ws % 32 == 0), out = big image [N][M][2Hs][2Ws]
 //   out[m][2p+a][2q+b] = sum_c sum_{(r,s) in class(a,b)} W(m,c,r,s) * in[c][p + dh(r)][q + dw(s)]
@@ -1989,6 +2139,50 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   return 0;
 }
 
+static bool f3x3s2_ok(int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad) {
+  return R == 3 && S == 3 && st_ == 2 && pad == 1 && Hb == 2 * Hs && Wb == 2 * Ws && (Ws % 32) == 0 && (Hs % 4) == 0 &&
+         (Cb % F3_CC) == 0 && Cs >= 128 && (long)F3_CC * Hb * Wb < (1L << 31);
+}
+
+// in [N][Cb][2Hs][2Ws] -> out [N][M][Hs][Ws]
+static int run_f3x3s2(const float *in, const float *W, const float *bias, float *out, int N, int Cb, int Hs, int Ws, int M,
+                      long sm, long sc, int act, float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+  TapList l;
+  l.T = 9;
+  for (int t = 0; t < 9; ++t) {
+    l.dh[t] = 0;
+    l.dw[t] = 0;
+    l.idx[t] = t;
+  }
+  const int RED = Cb * 9;
+  const int Mp = (int)align_up(M, 128);
+  const size_t need = class_bytes(RED, Mp);
+  if (need > ws_bytes) {
+    set_error("conv workspace too small: need %zu, have %zu", need, ws_bytes);
+    return LSPS_E_WS;
+  }
+  FS2Params p;
+  memset(&p, 0, sizeof(p));
+  const int2 *gtab_unused;
+  int rc = launch_pack(W, ws, M, Mp, RED, RED, l, sm, sc, 4 * Hs * Ws, 2 * Ws, st, &p.Wp, &gtab_unused, &p.zero, F3_CC);
+  if (rc) return rc;
+  p.X = in;
+  p.bias = bias;
+  p.Y = out;
+  p.Cx = Cb;
+  p.P = Hs;
+  p.Q = Ws;
+  p.M = M;
+  p.Mp = Mp;
+  p.qblocks = Ws / 32;
+  p.tiles_per_img = (Hs / 4) * p.qblocks;
+  p.act = act;
+  p.slope = slope;
+  hipLaunchKernelGGL(igemm_f3x3s2_kernel, dim3(N * p.tiles_per_img, Mp / 128), dim3(256), 0, st, p);
+  LSPS_CHECK_LAUNCH("igemm_f3x3s2");
+  return 0;
+}
+
 static bool c1_fwd_ok(int Cb, int Hb, int Wb, int Hs, int Ws, int R, int S, int st_, int pad, long sm) {
   return Cb == 1 && R * S <= 2 * C1_KS && (Ws % 32) == 0 && (st_ == 1 || st_ == 2) && sm == (long)R * S &&
          (long)R * (Wb + 2 * pad) <= C1_MAXLDS;
@@ -2037,6 +2231,10 @@ static int run_forward_dir(const float *in, const float *W, const float *bias, f
 #ifndef LSPS_NO_F3X3
   if (f3x3_ok(Cb, Hb, Wb, R, S, st_, pad) && Cs >= 128)
     return run_f3x3(in, W, bias, out, N, Cb, Hb, Cs, sm, sc, false, act, slope, ws, ws_bytes, st);
+#endif
+#ifndef LSPS_NO_F3X3S2
+  if (f3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad) && g_math_mode != 1)
+    return run_f3x3s2(in, W, bias, out, N, Cb, Hs, Ws, Cs, sm, sc, act, slope, ws, ws_bytes, st);
 #endif
 #ifndef LSPS_NO_C1
   if (c1_fwd_ok(Cb, Hb, Wb, Hs, Ws, R, S, st_, pad, sm))

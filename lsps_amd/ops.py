@@ -53,6 +53,9 @@ class Profiler(object):
         if transposed and r == 3 and stride == 2 and pad == 1 and w % 32 == 0 and h % (4 if M >= 128 else 8) == 0 \
                 and cin % 16 == 0 and M >= 64 and (get_math_mode() != 'bf16' or M < 128):
             return 'igemm_t3x3s2_kernel'
+        if not transposed and r == 3 and stride == 2 and pad == 1 and w % 64 == 0 and h % 8 == 0 and cin % 8 == 0 \
+                and M >= 128 and get_math_mode() != 'bf16':
+            return 'igemm_f3x3s2_kernel'
         if not transposed and cin == 1 and 0 < r * r <= 50 and stride in (1, 2) and w >= 32:
             return 'c1_fwd_kernel'                # approximate mirror of c1_fwd_ok (output width % 32 == 0)
         return 'igemm_f_kernel<2,2,2,2>' if M >= 128 else ('igemm_f_kernel<2,2,1,4>' if M >= 64 else 'igemm_f_kernel<1,2,1,4>')
@@ -219,7 +222,7 @@ class _ConvT2dFn(torch.autograd.Function):
         dy, db = _act_backward(L, dy, y, act, slope, ctx.has_bias and ctx.needs_input_grad[2], Co, ws, wsb, st)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            with profiler.span(Profiler.f_kernel(Ci), flops, 1):
+            with profiler.span(Profiler.f_kernel(Ci, Co, dy.shape[2], dy.shape[3], R if R == S else 0, stride, pad), flops, 1):
                 _lib.check(L.lsps_convT2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, Ci, H, W, Co, R, S, stride,
                                                 pad, outpad, ws, wsb, st), 'convT2d_dgrad')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
