@@ -171,7 +171,7 @@ def main():
         if t_bf16:
             extra['pretrain_step_bf16_mfma_bs%d' % args.batch] = {
                 'steps_per_s': 1.0 / t_bf16, 'ms_per_step': 1e3 * t_bf16,
-                'note': 'residual 3x3 convs on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 in registers, f32 '
+                'note': 'residual 3x3 convs on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 when staged into LDS, f32 '
                         'accumulate, f32 tensors/statistics/Adam); NOT the headline value'}
             extra['pretrain_step_f32_split_bs%d' % args.batch] = {
                 'steps_per_s': 1.0 / t_split, 'ms_per_step': 1e3 * t_split,
