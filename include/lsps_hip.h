@@ -145,6 +145,9 @@ int lsps_adam_step(float *p, const float *g, float *m, float *v,
 
 /* elementwise helpers used by the trainer glue (GaussianNoiseLayer common_net.py:39-40 etc.) */
 int lsps_axpy(const float *x, const float *y, float alpha, float *out, long n, void *stream);  /* out = x + alpha*y */
+/* out = (x ? x : 0) + t*m: nn.Dropout on the residual branch of a residual block (common_net.py:171-172, m = keep mask/(1-p))
+ * followed by `out += residual` (:180); with x == NULL it is the branch's backward (dt = dy*m). */
+int lsps_mul_add(const float *x, const float *t, const float *m, float *out, long n, void *stream);
 
 /* ---- data step either side of the path -------------------------------------------------
  * lsps_crop_normalize: reference src/data/dataset_hand2.py:27-31 `normalize(img, com, cube)` for a batch:

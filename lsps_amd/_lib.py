@@ -43,6 +43,7 @@ _SIGNATURES = {
     'lsps_linear_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P]),
     'lsps_adam_step': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int] + [c_float] * 6 + [_P]),
     'lsps_axpy': (c_int, [_P, _P, c_float, _P, c_long, _P]),
+    'lsps_mul_add': (c_int, [_P, _P, _P, _P, c_long, _P]),
     'lsps_crop_normalize': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     'lsps_crop_augment': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
 }

@@ -238,6 +238,30 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(const float *__restrict
   out[c] = s;
 }
 
+// out = (x ? x : 0) + t * m   (dropout applied to a residual branch: nn.Dropout after the second InstanceNorm of a
+// residual block, common_net.py:171-172, followed by `out += residual`, :180; m = keep mask / (1 - p))
+__global__ __launch_bounds__(256) void mul_add_kernel(const float *__restrict__ x, const float *__restrict__ t,
+                                                      const float *__restrict__ m, float *__restrict__ out, long n) {
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 a = *reinterpret_cast<const float4 *>(t + i);
+      const float4 b = *reinterpret_cast<const float4 *>(m + i);
+      float4 r = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+      if (x) {
+        const float4 c = *reinterpret_cast<const float4 *>(x + i);
+        r.x += c.x;
+        r.y += c.y;
+        r.z += c.z;
+        r.w += c.w;
+      }
+      *reinterpret_cast<float4 *>(out + i) = r;
+    } else {
+      for (long k = i; k < n; ++k) out[k] = (x ? x[k] : 0.f) + t[k] * m[k];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(const float *__restrict__ x, const float *__restrict__ y, float alpha,
                                                    float *__restrict__ out, long n) {
   const long stride = (long)gridDim.x * 256 * 4;
@@ -347,6 +371,17 @@ int lsps_act_bwd_bias(const float *dy, const float *out, float *dx, float *db, i
                        C, (int)S);
     LSPS_CHECK_LAUNCH("act_bwd_bias_reduce");
   }
+  return 0;
+}
+
+int lsps_mul_add(const float *x, const float *t, const float *m, float *out, long n, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(t && m && out && n >= 0, "mul_add: bad argument");
+  LSPS_CHECK_ARG((((uintptr_t)x | (uintptr_t)t | (uintptr_t)m | (uintptr_t)out) & 15) == 0,
+                 "mul_add: pointers must be 16-byte aligned");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(mul_add_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, t, m, out, n);
+  LSPS_CHECK_LAUNCH("mul_add");
   return 0;
 }
 

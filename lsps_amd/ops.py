@@ -424,6 +424,35 @@ class _AxpyFn(torch.autograd.Function):
         return g, gy, None
 
 
+class _MulAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t, m):
+        L = _lib.lib()
+        x, t, m = _c(x), _c(t), _c(m)
+        assert x.shape == t.shape == m.shape
+        out = torch.empty_like(t)
+        _lib.check(L.lsps_mul_add(_lib.ptr(x), _lib.ptr(t), _lib.ptr(m), _lib.ptr(out), t.numel(), _lib.stream()), 'mul_add')
+        ctx.save_for_backward(m)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        g = _c(g)
+        gt = None
+        if ctx.needs_input_grad[1]:
+            gt = torch.empty_like(g)
+            _lib.check(_lib.lib().lsps_mul_add(None, _lib.ptr(g), _lib.ptr(m), _lib.ptr(gt), g.numel(), _lib.stream()),
+                       'mul_add')
+        return g, gt, None
+
+
+def mul_add(x, t, m):
+    """x + t*m: dropout mask (already divided by 1-p) on a residual branch, then the skip connection
+    (common_net.py:171-172,180)."""
+    return _MulAddFn.apply(x, t, m)
+
+
 def axpy(x, y, alpha=1.0):
     """x + alpha*y (GaussianNoiseLayer: common_net.py:39-40; reparameterisation: lsps_nets.py:78)."""
     return _AxpyFn.apply(x, y, float(alpha))

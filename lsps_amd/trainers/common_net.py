@@ -101,18 +101,25 @@ class LeakyINSResBlock(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, dropout=0.0):
         super(LeakyINSResBlock, self).__init__()
+        layers = [Conv2d(inplanes, planes, 3, stride, 1), _Fused('InstanceNorm2d'), _Fused('LeakyReLU'),
+                  Conv2d(planes, planes, 3, 1, 1), _Fused('InstanceNorm2d + residual add')]
+        self.dropout = float(dropout)
         if dropout > 0:
-            raise NotImplementedError("res_dropout_ratio > 0 is not used by the shipped configs")
-        self.model = nn.Sequential(
-            Conv2d(inplanes, planes, 3, stride, 1), _Fused('InstanceNorm2d'), _Fused('LeakyReLU'),
-            Conv2d(planes, planes, 3, 1, 1), _Fused('InstanceNorm2d + residual add'))
+            layers.append(_Fused('Dropout'))            # same child count as the reference (common_net.py:171-172)
+        self.model = nn.Sequential(*layers)
         self.model.apply(gaussian_weights_init)
 
-    def forward(self, x):
+    def forward(self, x, drop_mask=None):
+        """`drop_mask` (tests): the keep mask ALREADY divided by 1-p; default: drawn here in training mode."""
         c1, c2 = self.model[0], self.model[3]
         h = ops.conv2d(x, c1.weight, None, c1.stride, 1)
         h = ops.instance_norm_(h, None, LRELU_SLOPE)
         h = ops.conv2d(h, c2.weight, None, 1, 1)
+        if self.dropout > 0 and (self.training or drop_mask is not None):
+            h = ops.instance_norm_(h, None, -1.0)
+            if drop_mask is None:
+                drop_mask = (torch.rand_like(h) >= self.dropout).to(h.dtype) / (1.0 - self.dropout)
+            return ops.mul_add(x, h, drop_mask)
         return ops.instance_norm_(h, x, -1.0)
 
 
@@ -188,19 +195,26 @@ class LeakyINSResNeXtBlock(nn.Module):
 
     def __init__(self, inplanes, planes, k=2, cardinality=8, dropout=0.0):
         super(LeakyINSResNeXtBlock, self).__init__()
+        layers = [Conv2d(inplanes, k * inplanes, 1, 1, 0), _Fused('InstanceNorm2d'), _Fused('LeakyReLU'),
+                  Conv2dGrouped(k * inplanes, k * inplanes, 3, 1, 1, groups=cardinality), _Fused('InstanceNorm2d'),
+                  _Fused('LeakyReLU'), Conv2d(k * inplanes, planes, 1, 1, 0), _Fused('InstanceNorm2d + residual add')]
+        self.dropout = float(dropout)
         if dropout > 0:
-            raise NotImplementedError("res_dropout_ratio > 0 is not used by the shipped configs")
-        self.model = nn.Sequential(
-            Conv2d(inplanes, k * inplanes, 1, 1, 0), _Fused('InstanceNorm2d'), _Fused('LeakyReLU'),
-            Conv2dGrouped(k * inplanes, k * inplanes, 3, 1, 1, groups=cardinality), _Fused('InstanceNorm2d'),
-            _Fused('LeakyReLU'), Conv2d(k * inplanes, planes, 1, 1, 0), _Fused('InstanceNorm2d + residual add'))
+            layers.append(_Fused('Dropout'))            # common_net.py:123-124
+        self.model = nn.Sequential(*layers)
         self.model.apply(gaussian_weights_init)
 
-    def forward(self, x):
+    def forward(self, x, drop_mask=None):
         c1, c2, c3 = self.model[0], self.model[3], self.model[6]
         h = ops.instance_norm_(ops.conv2d(x, c1.weight, None, 1, 0), None, LRELU_SLOPE)   # biases cancel under IN
         h = ops.instance_norm_(c2(h, use_bias=False), None, LRELU_SLOPE)
-        return ops.instance_norm_(ops.conv2d(h, c3.weight, None, 1, 0), x, -1.0)
+        h = ops.conv2d(h, c3.weight, None, 1, 0)
+        if self.dropout > 0 and (self.training or drop_mask is not None):
+            h = ops.instance_norm_(h, None, -1.0)
+            if drop_mask is None:
+                drop_mask = (torch.rand_like(h) >= self.dropout).to(h.dtype) / (1.0 - self.dropout)
+            return ops.mul_add(x, h, drop_mask)
+        return ops.instance_norm_(h, x, -1.0)
 
 
 class LeakyReLUINSConv2d(nn.Module):

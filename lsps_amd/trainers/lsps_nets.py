@@ -164,13 +164,11 @@ class SharedResGen(_Net):
     (residual blocks, 3x3 stride-2 transposed convs, 1x1 transposed conv + tanh) (lsps_nets.py:164-272)."""
 
     def _res_block(self, tch, params):
-        return LeakyINSResBlock(tch, tch)
+        return LeakyINSResBlock(tch, tch, dropout=params.get('res_dropout_ratio', 0))   # lsps_nets.py:176-179
 
     def __init__(self, params):
         super(SharedResGen, self).__init__()
         ch = params['ch']
-        if params.get('res_dropout_ratio', 0):
-            raise NotImplementedError("res_dropout_ratio > 0 is not used by the shipped configs")
         res_block = lambda tch: self._res_block(tch, params)   # noqa: E731
 
         def encoder(input_dim):
@@ -237,4 +235,4 @@ class SharedResXGen(SharedResGen):
     def _res_block(self, tch, params):
         k = params['n_resnext_k'] if 'n_resnext_k' in params.keys() else 1
         c = params['n_resnext_c'] if 'n_resnext_c' in params.keys() else 4
-        return LeakyINSResNeXtBlock(tch, tch, k=k, cardinality=c)
+        return LeakyINSResNeXtBlock(tch, tch, k=k, cardinality=c, dropout=params.get('res_dropout_ratio', 0))

@@ -190,12 +190,16 @@ def instance_norm(x):
     return (x - mu) / torch.sqrt(var + IN_EPS)
 
 
-def leaky_ins_res_block(x, p, key):
-    """LeakyINSResBlock (common_net.py:160-181): x + IN(conv(LReLU(IN(conv(x)))))."""
+def leaky_ins_res_block(x, p, key, drop_mask=None):
+    """LeakyINSResBlock (common_net.py:160-181): x + [Dropout](IN(conv(LReLU(IN(conv(x)))))).  `drop_mask`: the
+    keep mask divided by (1-p) that nn.Dropout(p) multiplies by in training mode (:171-172); None = no dropout."""
     h = F.conv2d(x, p[key + '.model.0.weight'], p[key + '.model.0.bias'], stride=1, padding=1)
     h = F.leaky_relu(instance_norm(h), LRELU_SLOPE)
     h = F.conv2d(h, p[key + '.model.3.weight'], p[key + '.model.3.bias'], stride=1, padding=1)
-    return x + instance_norm(h)
+    h = instance_norm(h)
+    if drop_mask is not None:
+        h = h * drop_mask
+    return x + h
 
 
 def leaky_ins_resnext_block(x, p, key, groups):

@@ -384,3 +384,19 @@ def run_step_cases(A, config, shapes_mod, n=2, post_n=8):
         R['vae_update.it%d' % it] = OrderedDict(dec=dec, **A.scalars(tr))
     R['vae_update.params'] = A.params(tr, 'vae')
     return R
+
+
+# ---------------------------------------------------------------------------------------------
+# residual block with dropout (`res_dropout_ratio` > 0: lsps_nets.py:176-179 -> common_net.py:171-172)
+# ---------------------------------------------------------------------------------------------
+DROP_P, DROP_CH, DROP_N, DROP_HW = 0.3, 16, 3, 32
+
+
+def dropout_case_inputs():
+    """Seeded input, weights, keep-mask/(1-p) and upstream gradient of the dropout residual-block case."""
+    rs = np.random.RandomState(4242)
+    shape = (DROP_N, DROP_CH, DROP_HW, DROP_HW)
+    keep = (rs.uniform(size=shape) >= DROP_P).astype(np.float32) / np.float32(1.0 - DROP_P)
+    return dict(x=noise(shape, 51), gy=noise(shape, 52), mask=keep,
+                w0=noise((DROP_CH, DROP_CH, 3, 3), 53, 0.05), b0=noise((DROP_CH,), 54, 0.05),
+                w3=noise((DROP_CH, DROP_CH, 3, 3), 55, 0.05), b3=noise((DROP_CH,), 56, 0.05))

@@ -174,10 +174,49 @@ class RefShapes(object):
         return self._shapes(cfg['name'], cfg)
 
 
+def run_dropout_case(ref):
+    """The reference's own LeakyINSResBlock(dropout=p) in training mode, with nn.Dropout's random keep mask replaced
+    by the recorded one (F.dropout is patched for the duration), forward + backward; and in eval mode."""
+    import torch
+    import torch.nn.functional as F
+    d = cases.dropout_case_inputs()
+    blk = ref.LeakyINSResBlock(cases.DROP_CH, cases.DROP_CH, dropout=cases.DROP_P)
+    assert type(blk.model[5]).__name__ == 'Dropout'
+    blk.load_state_dict({'model.0.weight': torch.as_tensor(d['w0']), 'model.0.bias': torch.as_tensor(d['b0']),
+                         'model.3.weight': torch.as_tensor(d['w3']), 'model.3.bias': torch.as_tensor(d['b3'])})
+    mask = torch.as_tensor(d['mask'])
+    orig = F.dropout
+
+    def recorded(input, p=0.5, training=True, inplace=False):
+        assert abs(p - cases.DROP_P) < 1e-12
+        return input * mask if training else input
+    F.dropout = recorded
+    try:
+        blk.train()
+        x = torch.as_tensor(d['x']).clone().requires_grad_(True)
+        y = blk(x)
+        y.backward(torch.as_tensor(d['gy']))
+        out = {'drop.train.y': y.detach().numpy().copy(), 'drop.train.dx': x.grad.numpy().copy(),
+               'drop.train.dw0': blk.model[0].weight.grad.numpy().copy(),
+               'drop.train.dw3': blk.model[3].weight.grad.numpy().copy()}
+        blk.eval()
+        with torch.no_grad():
+            out['drop.eval.y'] = blk(torch.as_tensor(d['x']).clone()).numpy().copy()
+    finally:
+        F.dropout = orig
+    return out
+
+
 def main(which):
     import torch
     torch.set_num_threads(8)
     A = RefAdapter()
+    if which in ('all', 'dropout'):
+        path = os.path.join(HERE, 'golden_dropout.npz')
+        np.savez_compressed(path, **run_dropout_case(A.ref))
+        print('dropout case ->', path, os.path.getsize(path) // 1024, 'KiB')
+        if which == 'dropout':
+            return
     shapes = RefShapes(A.ref)
     for config in (['tiny', 'full'] if which == 'all' else [which]):
         R = OrderedDict()

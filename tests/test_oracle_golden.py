@@ -2,6 +2,7 @@
 (tests/golden/make_golden.py).  This is what pins the oracle: every public method of the nets
 and every update step, tiny (ch=8/4) and full (ch=64) width.  Tolerance: 1e-4 relative to the
 tensor's abs-max (same torch CPU kernels, different op composition => ~1e-6 expected)."""
+import numpy as np
 import pytest
 import torch
 
@@ -57,3 +58,22 @@ def test_shape_tables_match_reference_keys(golden):
     for net, shapes in (('gen', lsps_ref.gen_shapes(hp['gen'])), ('dis', lsps_ref.dis_shapes(hp['dis']))):
         for k, s in shapes.items():
             assert tuple(g['pretrain.it0.%s.params/%s/shape' % (net, k)]) == tuple(s)
+
+
+def test_resblock_dropout_matches_reference():
+    """`res_dropout_ratio` > 0 (lsps_nets.py:176-179): the oracle's residual block with the recorded keep mask against
+    the reference's own LeakyINSResBlock(dropout=p) (golden_dropout.npz), forward and backward, train and eval."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'golden_dropout.npz'))
+    d = cases.dropout_case_inputs()
+    p = {'b.model.0.weight': torch.as_tensor(d['w0']).requires_grad_(True), 'b.model.0.bias': torch.as_tensor(d['b0']),
+         'b.model.3.weight': torch.as_tensor(d['w3']).requires_grad_(True), 'b.model.3.bias': torch.as_tensor(d['b3'])}
+    x = torch.as_tensor(d['x']).clone().requires_grad_(True)
+    y = lsps_ref.leaky_ins_res_block(x, p, 'b', drop_mask=torch.as_tensor(d['mask']))
+    y.backward(torch.as_tensor(d['gy']))
+    for name, got in (('y', y), ('dx', x.grad), ('dw0', p['b.model.0.weight'].grad), ('dw3', p['b.model.3.weight'].grad)):
+        want = G['drop.train.' + name]
+        assert np.abs(got.detach().numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), name
+    with torch.no_grad():
+        ye = lsps_ref.leaky_ins_res_block(torch.as_tensor(d['x']), p, 'b')
+    assert np.abs(ye.numpy() - G['drop.eval.y']).max() <= 1e-5

@@ -213,3 +213,50 @@ def test_icvl_config_bf16_against_oracle():
     for k in s_ref:
         assert abs(s_ref[k] - s_hip[k]) <= 5e-2 * max(abs(s_ref[k]), 1e-3), (k, s_ref[k], s_hip[k])
     assert np.abs(xaa - xaa_ref).max() <= 3e-2 and np.abs(xaba - xaba_ref).max() <= 3e-2
+
+
+def test_resblock_dropout_against_reference():
+    """`res_dropout_ratio` > 0: the HIP residual block (IN kernel + lsps_mul_add) with the recorded keep mask against the
+    reference's own LeakyINSResBlock(dropout=p), forward and backward; eval mode is the plain fused block; a generator
+    built with the key runs and draws its own masks in training mode."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import os
+    import yaml
+    from lsps_amd import synth, trainers
+    from lsps_amd.trainers.common_net import LeakyINSResBlock
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'golden_dropout.npz'))
+    d = cases.dropout_case_inputs()
+    blk = LeakyINSResBlock(cases.DROP_CH, cases.DROP_CH, dropout=cases.DROP_P).cuda()
+    assert len(blk.model) == 6                       # Dropout is child 5, as in the reference
+    blk.load_state_dict({'model.0.weight': torch.as_tensor(d['w0']), 'model.0.bias': torch.as_tensor(d['b0']),
+                         'model.3.weight': torch.as_tensor(d['w3']), 'model.3.bias': torch.as_tensor(d['b3'])})
+    blk.train()
+    x = torch.as_tensor(d['x']).cuda().requires_grad_(True)
+    y = blk(x, drop_mask=torch.as_tensor(d['mask']).cuda())
+    y.backward(torch.as_tensor(d['gy']).cuda())
+    for name, got in (('y', y), ('dx', x.grad), ('dw0', blk.model[0].weight.grad), ('dw3', blk.model[3].weight.grad)):
+        want = G['drop.train.' + name]
+        err = np.abs(got.detach().cpu().numpy() - want).max() / max(1.0, np.abs(want).max())
+        assert err <= 1e-3, (name, err)
+    blk.eval()
+    with torch.no_grad():
+        ye = blk(torch.as_tensor(d['x']).cuda())
+    assert np.abs(ye.cpu().numpy() - G['drop.eval.y']).max() <= 1e-3
+    # own masks in training mode: about p of the branch is dropped, the skip connection is untouched
+    blk.train()
+    with torch.no_grad():
+        xin = torch.as_tensor(d['x']).cuda()
+        branch = blk(xin) - xin
+    frac0 = float((branch == 0).float().mean())
+    assert abs(frac0 - cases.DROP_P) < 0.02, frac0
+    # the YAML key is honoured by the generator
+    hp = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'exps',
+                                          'nnyu.yaml')))['train']['hyperparameters']
+    hp = synth.tiny_hyperparameters(hp)
+    hp['gen']['res_dropout_ratio'] = 0.25
+    gen = trainers.SharedResGen(hp['gen']).cuda()
+    assert sum(1 for m in gen.modules() if isinstance(m, LeakyINSResBlock) and m.dropout == 0.25) == 14
+    xa, _, _ = synth.make_batch(2, 3)
+    out = gen(torch.as_tensor(xa).cuda(), torch.as_tensor(xa).cuda())
+    assert all(bool(torch.isfinite(t).all()) for t in out)
