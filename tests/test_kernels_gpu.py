@@ -58,6 +58,15 @@ CONV_CASES = [
     (3, 1, 32, 64, 40, 5, 1, 2),        # single-input-channel kernels: 5x5, K not a multiple of 32, non-square
     (2, 1, 16, 64, 64, 7, 2, 3),        # single-input-channel, stride 2, one row tile
     (1, 1, 24, 32, 8, 3, 1, 1),         # single-input-channel 3x3, 8 output channels, row tile of 8 with 3 tiles
+    # dispatch-boundary shapes of the specialised kernels
+    (1, 64, 8, 192, 128, 3, 2, 1),      # stride-2 kernels with THREE 32-column blocks per output row
+    (2, 72, 8, 64, 192, 3, 2, 1),       # C % 8 == 0 but not % 64 (fwd specialised, wgrad generic), M = 192 (masked half tile)
+    (1, 64, 12, 64, 128, 3, 2, 1),      # output height 6: not a multiple of 4 -> generic forward, specialised wgrad
+    (2, 24, 8, 32, 192, 3, 1, 1),       # stride-1 3x3 kernel: 3 channel chunks, M = 192
+    (2, 1, 32, 192, 20, 7, 1, 3),       # single-channel: Q = 192 (forward specialised, wgrad generic)
+    (2, 1, 8, 128, 64, 7, 1, 3),        # single-channel: one row tile of 8, Q = 128
+    (1, 128, 16, 32, 64, 3, 2, 1),      # stride 2 with 16 output columns: everything generic
+    (2, 64, 16, 64, 64, 3, 2, 1),       # stride 2, M = 64: forward generic (needs M >= 128), dgrad on the BM=64 transposed kernel
 ]
 
 
@@ -103,6 +112,10 @@ CONVT_CASES = [
     (2, 5, 6, 6, 4, 5, 3, 2, 2),         # stride 3
     (1, 128, 2, 32, 64, 3, 2, 1, 1),     # specialised stride-2 kernels: two input rows, a single image
     (3, 128, 4, 64, 128, 3, 2, 1, 1),    # stride-2: two 32-column blocks, odd N
+    (1, 144, 8, 96, 64, 3, 2, 1, 1),     # Ci = 144 (9 chunks of 16), three column blocks, 64 outputs (BM = 64, TR = 8)
+    (1, 144, 4, 96, 64, 3, 2, 1, 1),     # H = 4 with 64 outputs: TR = 8 does not divide -> generic transposed path
+    (2, 40, 8, 32, 192, 3, 2, 1, 1),     # Ci % 16 != 0 -> generic forward; dgrad specialised (C % 8 == 0), Co = 192
+    (2, 64, 6, 32, 128, 3, 2, 1, 1),     # H = 6: not a multiple of 4 -> generic
 ]
 
 
