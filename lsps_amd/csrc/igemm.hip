@@ -593,6 +593,7 @@ struct FS2Params {
   float slope;
 };
 
+template <bool BF16>
 __global__ __launch_bounds__(256, 2) void igemm_f3x3s2_kernel(FS2Params p) {
   constexpr int BM = 128, RC = F3_CC * 9;
   constexpr int A4 = RC * BM / 4 / 256;                            // 9 float4 of weights per thread per chunk
@@ -680,7 +681,38 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3s2_kernel(FS2Params p) {
         hreg = *src;
       }
     }
-    if (ch >= 0) {
+    if (ch >= 0 && BF16) {
+      // bf16 MFMA mode: K = 16 = (2 taps) x (8 channels): lanes 0-31 carry tap 2g, lanes 32-63 tap 2g+1 (the fifth
+      // group's upper half re-reads tap 8 and is zeroed); operands rounded to bf16 in registers
+      const float *A0 = As + wm * 64 + l31;
+      const float *B0 = Bs + wn * 4 * FS2_ROW + l31;
+#pragma unroll
+      for (int g = 0; g < 5; ++g) {
+        const int t0 = 2 * g, t1 = (2 * g + 1 <= 8) ? 2 * g + 1 : 8;
+        const int tsel = half ? t1 : t0;
+        const int tr = tsel / 3, ts = tsel - tr * 3;
+        const int boff = tr * FS2_ROW + (ts == 1 ? 33 : (ts == 2 ? 1 : 0));
+        const bool dead = (2 * g + 1 > 8) && half;
+        bf16x8 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)A0[(tsel * F3_CC + e) * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = B0[e * FS2_CH + 2 * j * FS2_ROW + boff];
+            bf[j][e] = (__bf16)(dead ? 0.f : v);
+          }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (ch >= 0 && !BF16) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int tr = t / 3, ts = t - tr * 3;
@@ -745,7 +777,7 @@ struct TS2Params {
   float slope;
 };
 
-template <int APAR, int BM>
+template <int APAR, int BM, bool BF16>
 __device__ __forceinline__ void ts2_body(const TS2Params &p, float *lds) {
   constexpr int NT = APAR ? 6 : 3;                           // taps of this row class
   constexpr int WAVES_M = BM / 64, WAVES_N = 4 / WAVES_M, TR = 2 * WAVES_N;
@@ -842,7 +874,33 @@ __device__ __forceinline__ void ts2_body(const TS2Params &p, float *lds) {
         hreg = *src;
       }
     }
-    if (ch >= 0) {
+    if (ch >= 0 && BF16) {
+      // bf16 MFMA mode: K = 16 = the chunk's 16 channels of one tap (lanes 0-31: channels 0-7, lanes 32-63: 8-15),
+      // gathered from the same f32 LDS tiles and rounded to bf16 in registers
+      const float *A0 = As + 8 * half * BM + wm * 64 + l31;
+      const float *B0 = Bs + 8 * half * CHS + wn * 2 * 34 + l31;
+#pragma unroll
+      for (int lt = 0; lt < NT; ++lt) {
+        const int s = lt % 3;
+        const int dh = (APAR && lt < 3) ? 1 : 0;
+        const int dw = s == 0 ? 1 : 0, cls = s == 1 ? 0 : 1;
+        bf16x8 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)A0[(lt * TS_CC + e) * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bf[j][e] = (__bf16)B0[e * CHS + (j + dh) * 34 + dw];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j][cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j][cls], 0, 0, 0);
+      }
+    }
+    if (ch >= 0 && !BF16) {
 #pragma unroll
       for (int lt = 0; lt < NT; ++lt) {
         const int s = lt % 3;
@@ -893,13 +951,13 @@ __device__ __forceinline__ void ts2_body(const TS2Params &p, float *lds) {
   }
 }
 
-template <int BM>
+template <int BM, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void igemm_t3x3s2_kernel(TS2Params p) {
   __shared__ __attribute__((aligned(16))) float lds[TS_LDS_FLOATS];
   if (blockIdx.z == 0)
-    ts2_body<0, BM>(p, lds);
+    ts2_body<0, BM, BF16>(p, lds);
   else
-    ts2_body<1, BM>(p, lds);
+    ts2_body<1, BM, BF16>(p, lds);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1414,6 +1472,7 @@ struct WS2Params {
   int nchunks, chunks_per_split; // chunk = (n, small row, 32-column block)
 };
 
+template <bool BF16>
 __global__ __launch_bounds__(512, 2) void igemm_w3x3s2_kernel(WS2Params p) {
   extern __shared__ __attribute__((aligned(16))) float ws2_lds[];
   float *As = ws2_lds, *Bs = ws2_lds + 128 * WS2_LDA;
@@ -1503,7 +1562,28 @@ __global__ __launch_bounds__(512, 2) void igemm_w3x3s2_kernel(WS2Params p) {
       }
 #endif
     }
-    if (ch >= ch_begin) {
+    if (ch >= ch_begin && BF16) {
+      // bf16 MFMA mode: K = 16 consecutive small pixels per MFMA (lanes 0-31: pixels 0-7 of the group, lanes 32-63:
+      // 8-15), operands rounded to bf16 in registers; 2 groups x 9 taps per chunk
+      const float *A0 = As + (wm * 32 + l31) * WS2_LDA + 8 * half;
+      const float *B0 = Bs + (wn * 32 + l31) * WS2_CH + 8 * half;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        bf16x8 af;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) af[e] = (__bf16)A0[g * 16 + e];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int r = t / 3, sx = t - r * 3;
+          const int off = r * WS2_ROW + (sx == 1 ? 33 : (sx == 2 ? 1 : 0)) + g * 16;
+          bf16x8 bf;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bf[e] = (__bf16)B0[off + e];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    if (ch >= ch_begin && !BF16) {
       // k-step kq covers small pixels 2kq + half; the operands of step kq+1 are fetched from LDS before the nine
       // MFMAs of step kq are issued (the compiler does not pipeline the reads across iterations by itself)
       float a_nx = Ap[0], b_nx[9];
@@ -2178,7 +2258,10 @@ static int run_f3x3s2(const float *in, const float *W, const float *bias, float 
   p.tiles_per_img = (Hs / 4) * p.qblocks;
   p.act = act;
   p.slope = slope;
-  hipLaunchKernelGGL(igemm_f3x3s2_kernel, dim3(N * p.tiles_per_img, Mp / 128), dim3(256), 0, st, p);
+  if (g_math_mode == 1)
+    hipLaunchKernelGGL(igemm_f3x3s2_kernel<true>, dim3(N * p.tiles_per_img, Mp / 128), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(igemm_f3x3s2_kernel<false>, dim3(N * p.tiles_per_img, Mp / 128), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_f3x3s2");
   return 0;
 }
@@ -2233,7 +2316,7 @@ static int run_forward_dir(const float *in, const float *W, const float *bias, f
     return run_f3x3(in, W, bias, out, N, Cb, Hb, Cs, sm, sc, false, act, slope, ws, ws_bytes, st);
 #endif
 #ifndef LSPS_NO_F3X3S2
-  if (f3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad) && g_math_mode != 1)
+  if (f3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad))
     return run_f3x3s2(in, W, bias, out, N, Cb, Hs, Ws, Cs, sm, sc, act, slope, ws, ws_bytes, st);
 #endif
 #ifndef LSPS_NO_C1
@@ -2347,12 +2430,21 @@ static int run_t3x3s2(const float *in, const float *W, const float *bias, float 
   p.qblocks = Ws / 32;
   p.act = act;
   p.slope = slope;
+  const bool bf = g_math_mode == 1;
   if (M >= 128) {
     p.tiles_per_img = (Hs / 4) * p.qblocks;
-    hipLaunchKernelGGL(igemm_t3x3s2_kernel<128>, dim3(N * p.tiles_per_img, ceil_div(M, 128), 2), dim3(256), 0, st, p);
+    const dim3 grid(N * p.tiles_per_img, ceil_div(M, 128), 2);
+    if (bf)
+      hipLaunchKernelGGL((igemm_t3x3s2_kernel<128, true>), grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((igemm_t3x3s2_kernel<128, false>), grid, dim3(256), 0, st, p);
   } else {
     p.tiles_per_img = (Hs / 8) * p.qblocks;
-    hipLaunchKernelGGL(igemm_t3x3s2_kernel<64>, dim3(N * p.tiles_per_img, ceil_div(M, 64), 2), dim3(256), 0, st, p);
+    const dim3 grid(N * p.tiles_per_img, ceil_div(M, 64), 2);
+    if (bf)
+      hipLaunchKernelGGL((igemm_t3x3s2_kernel<64, true>), grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((igemm_t3x3s2_kernel<64, false>), grid, dim3(256), 0, st, p);
   }
   LSPS_CHECK_LAUNCH("igemm_t3x3s2");
   return 0;
@@ -2369,7 +2461,7 @@ static int run_transposed_dir(const float *in, const float *W, const float *bias
     return run_f3x3(in, W, bias, out, N, Cs, Hs, Cb, sm, sc, true, act, slope, ws, ws_bytes, st);
 #endif
 #ifndef LSPS_NO_T3X3S2
-  if (t3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad) && (g_math_mode != 1 || Cb < 128))
+  if (t3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad))
     return run_t3x3s2(in, W, bias, out, N, Cs, Hs, Ws, Cb, sm, sc, act, slope, ws, ws_bytes, st);
 #endif
   const int M = Cb;
@@ -2531,8 +2623,11 @@ static int run_w3x3s2(const float *small, const float *big, float *dW, int N, in
                       size_t ws_bytes, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {                        // 67 KB of LDS: above the 64 KB static limit, so dynamic + opt-in
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_w3x3s2_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_w3x3s2_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS2_LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_w3x3s2_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS2_LDS_BYTES);
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(igemm_w3x3s2): %s", hipGetErrorString(e));
       return LSPS_E_HIP;
@@ -2565,7 +2660,10 @@ static int run_w3x3s2(const float *small, const float *big, float *dW, int N, in
   }
   p.zero = zero;
   p.part = (float *)((char *)ws + 256);
-  hipLaunchKernelGGL(igemm_w3x3s2_kernel, dim3(C / 64, M / 128, splits), dim3(512), WS2_LDS_BYTES, st, p);
+  if (g_math_mode == 1)
+    hipLaunchKernelGGL(igemm_w3x3s2_kernel<true>, dim3(C / 64, M / 128, splits), dim3(512), WS2_LDS_BYTES, st, p);
+  else
+    hipLaunchKernelGGL(igemm_w3x3s2_kernel<false>, dim3(C / 64, M / 128, splits), dim3(512), WS2_LDS_BYTES, st, p);
   LSPS_CHECK_LAUNCH("igemm_w3x3s2");
   const long total = (long)M * C * 9;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float *)p.part, dW, total,

@@ -51,10 +51,10 @@ class Profiler(object):
         if r == 3 and stride == 1 and pad == 1 and w == 32 and h % 4 == 0 and cin % 8 == 0 and M >= 128:
             return 'igemm_f3x3_kernel'
         if transposed and r == 3 and stride == 2 and pad == 1 and w % 32 == 0 and h % (4 if M >= 128 else 8) == 0 \
-                and cin % 16 == 0 and M >= 64 and (get_math_mode() != 'bf16' or M < 128):
+                and cin % 16 == 0 and M >= 64:
             return 'igemm_t3x3s2_kernel'
         if not transposed and r == 3 and stride == 2 and pad == 1 and w % 64 == 0 and h % 8 == 0 and cin % 8 == 0 \
-                and M >= 128 and get_math_mode() != 'bf16':
+                and M >= 128:
             return 'igemm_f3x3s2_kernel'
         if not transposed and cin == 1 and 0 < r * r <= 50 and stride in (1, 2) and w >= 32:
             return 'c1_fwd_kernel'                # approximate mirror of c1_fwd_ok (output width % 32 == 0)

@@ -317,7 +317,8 @@ def test_ops_reject_cpu_tensors():
 @pytest.mark.parametrize("case", [(3, 256, 32, 32, 256, 3, 1, 1), (2, 8, 32, 32, 130, 3, 1, 1), (5, 16, 8, 32, 128, 3, 1, 1),
                                   (3, 64, 8, 32, 128, 3, 1, 1), (7, 128, 2, 32, 64, 3, 1, 1),
                                   (2, 64, 128, 128, 128, 3, 2, 1), (4, 512, 8, 8, 1024, 3, 2, 1), (2, 1, 128, 128, 64, 7, 1, 3),
-                                  (5, 3, 17, 13, 37, 3, 1, 1), (6, 2048, 2, 2, 20, 2, 1, 0)],
+                                  (5, 3, 17, 13, 37, 3, 1, 1), (6, 2048, 2, 2, 20, 2, 1, 0),
+                                  (2, 128, 64, 64, 256, 3, 2, 1), (1, 64, 8, 192, 128, 3, 2, 1), (3, 144, 16, 64, 64, 3, 2, 1)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_conv3x3_bf16_math_mode(case):
     """BASELINE config 5: the MFMA conv kernels (specialised 3x3 and generic) with bf16 operands (f32 accumulate, f32 tensors).
