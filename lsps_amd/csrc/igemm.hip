@@ -1032,7 +1032,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
   constexpr int ROWS = TR + 2, BPL = ROWS * F3_LDW * 8;      // bf16 elements per limb plane of the input tile
   constexpr int ACH = NP * FS_APLANE;                        // bf16 elements of weights per (m-tile, channel chunk)
   constexpr int A16 = ACH / 8 / 256;                         // 16-byte units of weights per thread per chunk (5 per limb)
-  constexpr int WM = TR == 4 ? 2 : 1;
+  constexpr int WM = TR >= 4 ? 2 : 1;                        // MFMA row tiles per wave
+  constexpr int JN = TR == 8 ? 4 : 2;                        // image rows per wave (TR = 8: 128 ch x 256 px tile,
+                                                             // twice the weight reuse: the bf16 mode is L2-bound)
+  constexpr int BP = (ROWS * 32 + 255) / 256;                // staged pixels per thread (TR = 8: 320 pixels -> 2)
   __shared__ __attribute__((aligned(16))) unsigned short lds[ACH + NP * BPL];
   unsigned short *Aq = lds, *Bq = lds + ACH;
 
@@ -1053,24 +1056,31 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
 
   // B staging: thread (r, col) owns ONE pixel of the staged rows and gathers its 8 channels (8 coalesced dword
   // loads: lanes = consecutive pixels), so that after the split each limb is ONE 16-byte LDS store
-  const bool b_use = tid < ROWS * 32;
-  const int b_r = tid >> 5, b_col = tid & 31;
-  const int b_img_row = row0 - 1 + b_r;
-  const bool b_ok = b_use && b_img_row >= 0 && b_img_row < p.H;
-  const int b_lds = (b_r * F3_LDW + 1 + b_col) * 8;
-  const long b_off = (long)b_img_row * 32 + b_col;
+  bool b_use[BP], b_ok[BP];
+  int b_lds[BP];
+  long b_off[BP];
+#pragma unroll
+  for (int q = 0; q < BP; ++q) {
+    const int u = tid + 256 * q;
+    b_use[q] = u < ROWS * 32;
+    const int b_r = u >> 5, b_col = u & 31;
+    const int b_img_row = row0 - 1 + b_r;
+    b_ok[q] = b_use[q] && b_img_row >= 0 && b_img_row < p.H;
+    b_lds[q] = (b_r * F3_LDW + 1 + b_col) * 8;
+    b_off[q] = (long)b_img_row * 32 + b_col;
+  }
 
-  f32x16 acc[WM][2];
+  f32x16 acc[WM][JN];
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < JN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 areg[A16];
-  float breg[8];
-  const int wm = TR == 4 ? (wave >> 1) : wave, wn = TR == 4 ? (wave & 1) : 0;
+  float breg[BP][8];
+  const int wm = TR >= 4 ? (wave >> 1) : wave, wn = TR >= 4 ? (wave & 1) : 0;
   const int l31 = lane & 31, half = lane >> 5;
   const unsigned short *wq = p.Wq + (long)blockIdx.y * nchunks * ACH;
 
@@ -1079,22 +1089,24 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < A16; ++i) *reinterpret_cast<f32x4 *>(Aq + (tid + 256 * i) * 8) = areg[i];
-      if (b_use) {
-        u16x8 h8, m8, l8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          unsigned short h, m, l;
-          split3_scalar(breg[e], h, m, l);
-          h8[e] = h;
-          m8[e] = m;
-          l8[e] = l;
+      for (int q = 0; q < BP; ++q)
+        if (b_use[q]) {
+          u16x8 h8, m8, l8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            unsigned short h, m, l;
+            split3_scalar(breg[q][e], h, m, l);
+            h8[e] = h;
+            m8[e] = m;
+            l8[e] = l;
+          }
+          *reinterpret_cast<u16x8 *>(Bq + b_lds[q]) = h8;
+          if (NP == 3) {
+            *reinterpret_cast<u16x8 *>(Bq + BPL + b_lds[q]) = m8;
+            *reinterpret_cast<u16x8 *>(Bq + 2 * BPL + b_lds[q]) = l8;
+          }
         }
-        *reinterpret_cast<u16x8 *>(Bq + b_lds) = h8;
-        if (NP == 3) {
-          *reinterpret_cast<u16x8 *>(Bq + BPL + b_lds) = m8;
-          *reinterpret_cast<u16x8 *>(Bq + 2 * BPL + b_lds) = l8;
-        }
-      }
       __syncthreads();
     }
     if (ch + 1 < nchunks) {
@@ -1107,10 +1119,12 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
       for (int i = 0; i < A16; ++i) areg[i] = *reinterpret_cast<const f32x4 *>(src + (tid + 256 * i) * 8);
       const float *xc = xn + (long)(ch + 1) * F3_CC * HW;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float *s2 = b_ok ? (xc + (long)e * HW + b_off) : p.zero;
-        breg[e] = *s2;
-      }
+      for (int q = 0; q < BP; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float *s2 = b_ok[q] ? (xc + (long)e * HW + b_off[q]) : p.zero;
+          breg[q][e] = *s2;
+        }
     }
     if (ch >= 0) {
 #pragma unroll
@@ -1118,15 +1132,15 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
         const int t0 = 2 * g, t1 = 2 * g + 1;                // t1 == 9: the all-zero tap
         const int tb1 = t1 <= 8 ? t1 : 8;
         const int arow = (half ? t1 : t0) * 128 + wm * WM * 32 + l31;
-        const int boff = (half ? (tb1 / 3) * F3_LDW + (tb1 % 3) : (t0 / 3) * F3_LDW + (t0 % 3)) + wn * 2 * F3_LDW + l31;
-        bf16x8 af[NP][WM], bf[NP][2];
+        const int boff = (half ? (tb1 / 3) * F3_LDW + (tb1 % 3) : (t0 / 3) * F3_LDW + (t0 % 3)) + wn * JN * F3_LDW + l31;
+        bf16x8 af[NP][WM], bf[NP][JN];
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
           for (int i = 0; i < WM; ++i)
             af[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8 *>(Aq + pl * FS_APLANE + (arow + i * 32) * 8));
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < JN; ++j)
             bf[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8 *>(Bq + pl * BPL + (boff + j * F3_LDW) * 8));
         }
         // six limb products, smallest first; the tile loop is INSIDE so that consecutive MFMAs hit different
@@ -1138,15 +1152,15 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
 #pragma unroll
           for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < JN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[term]][i], bf[TB[term]][j], acc[i][j], 0, 0, 0);
       }
     }
   }
 
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    float *yb = p.Y + (long)n * p.M * HW + (long)(row0 + wn * 2 + j) * 32 + l31;
+  for (int j = 0; j < JN; ++j) {
+    float *yb = p.Y + (long)n * p.M * HW + (long)(row0 + wn * JN + j) * 32 + l31;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -2169,7 +2183,8 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
     q.Cx = Cin;
     q.H = H;
     q.M = M;
-    const int tr2 = ((long)N * (H / 4) * (Mp / 128) >= 512) ? 4 : 2;
+    int tr2 = ((long)N * (H / 4) * (Mp / 128) >= 512) ? 4 : 2;
+    if (np == 1 && (H % 8) == 0 && (long)N * (H / 8) * (Mp / 128) >= 1024) tr2 = 8;   // bf16: L2-bound, reuse weights twice
     q.tiles_per_img = H / tr2;
     q.act = act;
     q.slope = slope;
@@ -2180,7 +2195,9 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
       else
         hipLaunchKernelGGL((igemm_f3x3_split_kernel<2, 3>), grid2, dim3(256), 0, st, q);
     } else {
-      if (tr2 == 4)
+      if (tr2 == 8)
+        hipLaunchKernelGGL((igemm_f3x3_split_kernel<8, 1>), grid2, dim3(256), 0, st, q);
+      else if (tr2 == 4)
         hipLaunchKernelGGL((igemm_f3x3_split_kernel<4, 1>), grid2, dim3(256), 0, st, q);
       else
         hipLaunchKernelGGL((igemm_f3x3_split_kernel<2, 1>), grid2, dim3(256), 0, st, q);
