@@ -1,0 +1,575 @@
+// 3x3 / stride 2 / pad 1 kernels (down-sampling convs, up-sampling transposed convs): forward direction, transposed direction, weight gradient.
+#ifndef LSPS_CONV3X3S2_H
+#define LSPS_CONV3X3S2_H
+#include "conv_types.h"
+#include "conv3x3.h"
+
+namespace lsps {
+
+// -------------------------------------------------------------------------------------------
+// "Forward direction" kernel specialised for 3x3 / STRIDE 2 / pad 1 (down-sampling convs forward, up-sampling
+// transposed convs' dgrad): in = big image [N][Cx][2P][2Q], out = small image [N][M][P][Q], Q % 32 == 0.
+// Same structure as igemm_f3x3_kernel (tile 128 channels x 4 output rows x 32 columns, 8 input channels per chunk,
+// weights [chunk][tap][8][Mp]); the 9 input rows of the tile are staged DE-INTERLEAVED by column parity like in
+// igemm_w3x3s2_kernel (per row: O'[33] = odd columns with the left neighbour first, then E[32] = even columns), so the
+// stride-2 taps are unit-stride LDS reads: s=0 -> O'[q], s=1 -> E[q], s=2 -> O'[q+1].
+// -------------------------------------------------------------------------------------------
+#define FS2_ROW 65
+#define FS2_ROWS 9                                   // 2 * 4 + 1 input rows per tile
+#define FS2_CH (FS2_ROWS * FS2_ROW)                  // 585 floats per channel (585 % 32 = 9)
+
+struct FS2Params {
+  const float *X, *Wp, *bias, *zero;
+  float *Y;
+  int Cx, P, Q, M, Mp;           // output [P][Q]; input [2P][2Q]
+  int qblocks, tiles_per_img;    // Q / 32, (P / 4) * qblocks
+  int act;
+  float slope;
+};
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 2) void igemm_f3x3s2_kernel(FS2Params p) {
+  constexpr int BM = 128, RC = F3_CC * 9;
+  constexpr int A4 = RC * BM / 4 / 256;                            // 9 float4 of weights per thread per chunk
+  constexpr int LINES = F3_CC * FS2_ROWS;                          // 72 (channel, row) lines of 64 columns
+  constexpr int B4 = (LINES * 16 + 255) / 256;                     // 5 float4 of input per thread per chunk (4.5)
+  __shared__ __attribute__((aligned(16))) float lds[RC * BM + F3_CC * FS2_CH];
+  float *As = lds, *Bs = lds + RC * BM;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.y * BM;
+  const int n = blockIdx.x / p.tiles_per_img;
+  const int rem = blockIdx.x - n * p.tiles_per_img;
+  const int p0 = (rem / p.qblocks) * 4, q0 = (rem - (rem / p.qblocks) * p.qblocks) * 32;
+  const int Hx = 2 * p.P, Wx = 2 * p.Q, HWx = Hx * Wx;
+  const float *xn = p.X + (long)n * p.Cx * HWx;
+
+  int b_lds[B4], b_off[B4];
+  bool b_use[B4], b_ok[B4];
+#pragma unroll
+  for (int i = 0; i < B4; ++i) {
+    const int u = tid + 256 * i;
+    b_use[i] = u < LINES * 16;
+    const int line = u >> 4, c4 = u & 15;
+    const int chn = line / FS2_ROWS, r = line - chn * FS2_ROWS;
+    const int ih = 2 * p0 - 1 + r;
+    b_ok[i] = b_use[i] && ih >= 0;                                 // ih <= 2 p0 + 7 < 2P always
+    b_lds[i] = chn * FS2_CH + r * FS2_ROW + 2 * c4;
+    b_off[i] = chn * HWx + ih * Wx + 2 * q0 + c4 * 4;
+  }
+  const bool h_use = tid < LINES;                                   // column 2 q0 - 1 of every line
+  const int h_chn = tid / FS2_ROWS, h_r = tid - h_chn * FS2_ROWS;
+  const bool h_ok = h_use && (2 * p0 - 1 + h_r) >= 0 && q0 > 0;
+  const int h_off = h_chn * HWx + (2 * p0 - 1 + h_r) * Wx + 2 * q0 - 1;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 areg[A4], breg[B4];
+  float hreg = 0.f;
+  const int nchunks = p.Cx / F3_CC;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const float *Ap = As + half * BM + wm * 64 + l31;
+  const float *Bp = Bs + half * FS2_CH + wn * 4 * FS2_ROW + l31;     // wave's output rows wn*2 + j -> input rows 2(wn*2+j) + r
+
+  for (int ch = -1; ch < nchunks; ++ch) {
+    if (ch >= 0) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4 *>(As + (tid + 256 * i) * 4) = areg[i];
+#pragma unroll
+      for (int i = 0; i < B4; ++i)
+        if (b_use[i]) {
+          float *d = Bs + b_lds[i];
+          d[33] = breg[i][0];                                      // E[2 c4]
+          d[1] = breg[i][1];                                       // O'[2 c4 + 1]
+          d[34] = breg[i][2];                                      // E[2 c4 + 1]
+          d[2] = breg[i][3];                                       // O'[2 c4 + 2]
+        }
+      if (h_use) Bs[h_chn * FS2_CH + h_r * FS2_ROW] = hreg;        // O'[0]
+      __syncthreads();
+    }
+    if (ch + 1 < nchunks) {
+      const float *wsrc = p.Wp + (long)(ch + 1) * RC * p.Mp + m0;
+#pragma unroll
+      for (int i = 0; i < A4; ++i) {
+        const int u = tid + 256 * i;
+        const int row = u >> 5, c4 = u & 31;
+        areg[i] = *reinterpret_cast<const f32x4 *>(wsrc + (long)row * p.Mp + c4 * 4);
+      }
+      const float *xc = xn + (long)(ch + 1) * F3_CC * HWx;
+#pragma unroll
+      for (int i = 0; i < B4; ++i) {
+        const float *src = b_ok[i] ? (xc + b_off[i]) : p.zero;
+        breg[i] = *reinterpret_cast<const f32x4 *>(src);
+      }
+      {
+        const float *src = h_ok ? (xc + h_off) : p.zero;
+        hreg = *src;
+      }
+    }
+    if (ch >= 0 && BF16) {
+      // bf16 MFMA mode: K = 16 = (2 taps) x (8 channels): lanes 0-31 carry tap 2g, lanes 32-63 tap 2g+1 (the fifth
+      // group's upper half re-reads tap 8 and is zeroed); operands rounded to bf16 in registers
+      const float *A0 = As + wm * 64 + l31;
+      const float *B0 = Bs + wn * 4 * FS2_ROW + l31;
+#pragma unroll
+      for (int g = 0; g < 5; ++g) {
+        const int t0 = 2 * g, t1 = (2 * g + 1 <= 8) ? 2 * g + 1 : 8;
+        const int tsel = half ? t1 : t0;
+        const int tr = tsel / 3, ts = tsel - tr * 3;
+        const int boff = tr * FS2_ROW + (ts == 1 ? 33 : (ts == 2 ? 1 : 0));
+        const bool dead = (2 * g + 1 > 8) && half;
+        bf16x8 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)A0[(tsel * F3_CC + e) * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = B0[e * FS2_CH + 2 * j * FS2_ROW + boff];
+            bf[j][e] = (__bf16)(dead ? 0.f : v);
+          }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (ch >= 0 && !BF16) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int tr = t / 3, ts = t - tr * 3;
+        const int coff = ts == 1 ? 33 : (ts == 2 ? 1 : 0);
+#pragma unroll
+        for (int cp = 0; cp < F3_CC / 2; ++cp) {
+          const int kk = t * (F3_CC / 2) + cp;
+          float a[2], b[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[i] = Ap[2 * kk * BM + i * 32];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) b[j] = Bp[2 * cp * FS2_CH + (2 * j + tr) * FS2_ROW + coff];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const long PQ = (long)p.P * p.Q;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float *yb = p.Y + (long)n * p.M * PQ + (long)(p0 + wn * 2 + j) * p.Q + q0 + l31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < p.M) {
+          float v = acc[i][j][r];
+          if (p.bias) v += p.bias[m];
+          yb[(long)m * PQ] = apply_act(v, p.act, p.slope);
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// "Transposed direction" kernel specialised for 3x3 / STRIDE 2 / pad 1 (the up-sampling transposed convs forward,
+// the down-sampling convs' dgrad): in = small image [N][Cx][Hs][Ws] (Ws % 32 == 0), out = big image [N][M][2Hs][2Ws]
+//   out[m][2p+a][2q+b] = sum_c sum_{(r,s) in class(a,b)} W(m,c,r,s) * in[c][p + dh(r)][q + dw(s)]
+// with class rows a=0: r=1 (dh 0); a=1: r=0 (dh +1), r=2 (dh 0), and the same for columns.  A workgroup owns a tile
+// of the SMALL image (TR rows x 32 columns) for one row parity a (blockIdx.z) and BOTH column parities: the raw
+// input rows of 16 channels are staged once in LDS (TR+1 rows x 33 columns, zero past the edges) and the 3 (a=0)
+// or 6 (a=1) taps are shifted LDS reads; the two column classes are separate accumulators that the epilogue
+// interleaves into float2 stores (full 256-byte rows instead of stride-2 scatter).
+// BM = 128: TR = 4, waves 2x2;  BM = 64 (64-channel outputs): TR = 8, waves 1x4.  Each wave: 64 m x 2 rows x 2 classes.
+// -------------------------------------------------------------------------------------------
+#define TS_CC 16
+#define TS_LDS_FLOATS (6 * TS_CC * 128 + TS_CC * 5 * 34)      // a = 1, BM = 128 (the largest of the four variants)
+
+struct TS2Params {
+  const float *X, *Wp, *bias, *zero;
+  float *Y;
+  int Cx, Hs, Ws, M, Mp;
+  int qblocks, tiles_per_img;    // Ws / 32, (Hs / TR) * qblocks
+  int act;
+  float slope;
+};
+
+template <int APAR, int BM, bool BF16>
+__device__ __forceinline__ void ts2_body(const TS2Params &p, float *lds) {
+  constexpr int NT = APAR ? 6 : 3;                           // taps of this row class
+  constexpr int WAVES_M = BM / 64, WAVES_N = 4 / WAVES_M, TR = 2 * WAVES_N;
+  constexpr int ROWS = TR + 1, CHS = ROWS * 34;
+  constexpr int AROWS = NT * TS_CC;
+  constexpr int A4 = AROWS * BM / 4 / 256;
+  constexpr int B4 = (TS_CC * ROWS * 8 + 255) / 256;
+  static_assert(AROWS * BM + TS_CC * CHS <= TS_LDS_FLOATS, "LDS budget");
+  float *As = lds, *Bs = lds + AROWS * BM;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.y * BM;
+  const int n = blockIdx.x / p.tiles_per_img;
+  const int rem = blockIdx.x - n * p.tiles_per_img;
+  const int p0 = (rem / p.qblocks) * TR, q0 = (rem - (rem / p.qblocks) * p.qblocks) * 32;
+  const int HWs = p.Hs * p.Ws;
+  const float *xn = p.X + (long)n * p.Cx * HWs;
+
+  int b_lds[B4];
+  int b_off[B4];                                             // element offsets inside one 16-channel slab (< 2^31)
+  bool b_use[B4], b_ok[B4];
+#pragma unroll
+  for (int i = 0; i < B4; ++i) {
+    const int u = tid + 256 * i;
+    b_use[i] = u < TS_CC * ROWS * 8;
+    const int line = u >> 3, c4 = u & 7;
+    const int chn = line / ROWS, r = line - chn * ROWS;
+    b_ok[i] = b_use[i] && (p0 + r) < p.Hs;
+    b_lds[i] = chn * CHS + r * 34 + c4 * 4;
+    b_off[i] = chn * HWs + (p0 + r) * p.Ws + q0 + c4 * 4;
+  }
+  // column q0 + 32 (the right neighbour of the tile): one scalar per (channel, row) line
+  const bool h_use = tid < TS_CC * ROWS;
+  const int h_chn = tid / ROWS, h_r = tid - h_chn * ROWS;
+  const bool h_ok = h_use && (p0 + h_r) < p.Hs && (q0 + 32) < p.Ws;
+  const int h_off = h_chn * HWs + (p0 + h_r) * p.Ws + q0 + 32;
+
+  f32x16 acc[2][2][2];                                       // [m tile][row][column class]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][c][r] = 0.f;
+
+  f32x4 areg[A4], breg[B4];
+  float hreg = 0.f;
+  const int nchunks = p.Cx / TS_CC;
+  const int wm = WAVES_M == 2 ? (wave >> 1) : 0, wn = WAVES_M == 2 ? (wave & 1) : wave;
+  const int l31 = lane & 31, half = lane >> 5;
+  const float *Ap = As + half * BM + wm * 64 + l31;
+  const float *Bp = Bs + half * CHS + wn * 2 * 34 + l31;
+
+  for (int ch = -1; ch < nchunks; ++ch) {
+    if (ch >= 0) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4 *>(As + (tid + 256 * i) * 4) = areg[i];
+#pragma unroll
+      for (int i = 0; i < B4; ++i)
+        if (b_use[i]) {
+          float *d = Bs + b_lds[i];
+          d[0] = breg[i][0];
+          d[1] = breg[i][1];
+          d[2] = breg[i][2];
+          d[3] = breg[i][3];
+        }
+      if (h_use) Bs[h_chn * CHS + h_r * 34 + 32] = hreg;
+      __syncthreads();
+    }
+    if (ch + 1 < nchunks) {
+      // packed weights: rows [chunk of 16 channels][tap 0..8][16 channels]; this class uses taps 3..5 (a = 0) or
+      // 0..2 and 6..8 (a = 1)
+      const float *wsrc = p.Wp + (long)(ch + 1) * (9 * TS_CC) * p.Mp + m0;
+#pragma unroll
+      for (int i = 0; i < A4; ++i) {
+        const int u = tid + 256 * i;
+        const int row = u / (BM / 4), c4 = u - row * (BM / 4);
+        const int lt = row / TS_CC;
+        const int grow = (APAR ? (lt < 3 ? lt : lt + 3) : lt + 3) * TS_CC + (row - lt * TS_CC);
+        areg[i] = *reinterpret_cast<const f32x4 *>(wsrc + (long)grow * p.Mp + c4 * 4);
+      }
+      const float *xc = xn + (long)(ch + 1) * TS_CC * HWs;
+#pragma unroll
+      for (int i = 0; i < B4; ++i) {
+        const float *src = b_ok[i] ? (xc + b_off[i]) : p.zero;
+        breg[i] = *reinterpret_cast<const f32x4 *>(src);
+      }
+      {
+        const float *src = h_ok ? (xc + h_off) : p.zero;
+        hreg = *src;
+      }
+    }
+    if (ch >= 0 && BF16) {
+      // bf16 MFMA mode: K = 16 = the chunk's 16 channels of one tap (lanes 0-31: channels 0-7, lanes 32-63: 8-15),
+      // gathered from the same f32 LDS tiles and rounded to bf16 in registers
+      const float *A0 = As + 8 * half * BM + wm * 64 + l31;
+      const float *B0 = Bs + 8 * half * CHS + wn * 2 * 34 + l31;
+#pragma unroll
+      for (int lt = 0; lt < NT; ++lt) {
+        const int s = lt % 3;
+        const int dh = (APAR && lt < 3) ? 1 : 0;
+        const int dw = s == 0 ? 1 : 0, cls = s == 1 ? 0 : 1;
+        bf16x8 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)A0[(lt * TS_CC + e) * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bf[j][e] = (__bf16)B0[e * CHS + (j + dh) * 34 + dw];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j][cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j][cls], 0, 0, 0);
+      }
+    }
+    if (ch >= 0 && !BF16) {
+#pragma unroll
+      for (int lt = 0; lt < NT; ++lt) {
+        const int s = lt % 3;
+        const int dh = (APAR && lt < 3) ? 1 : 0;             // a = 1: r = 0 reads the next input row
+        const int dw = s == 0 ? 1 : 0, cls = s == 1 ? 0 : 1;
+#pragma unroll
+        for (int cp = 0; cp < TS_CC / 2; ++cp) {
+          float a[2], b[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[i] = Ap[(lt * TS_CC + 2 * cp) * BM + i * 32];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) b[j] = Bp[2 * cp * CHS + (j + dh) * 34 + dw];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j][cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j][cls], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const int Wb = 2 * p.Ws;
+  const long HWb = 4L * HWs;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int orow = 2 * (p0 + wn * 2 + j) + APAR;
+    float *yb = p.Y + (long)n * p.M * HWb + (long)orow * Wb + 2 * (q0 + l31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < p.M) {
+          float v0 = acc[i][j][0][r], v1 = acc[i][j][1][r];
+          if (p.bias) {
+            const float bv = p.bias[m];
+            v0 += bv;
+            v1 += bv;
+          }
+          f32x2 o;
+          o[0] = apply_act(v0, p.act, p.slope);
+          o[1] = apply_act(v1, p.act, p.slope);
+          *reinterpret_cast<f32x2 *>(yb + (long)m * HWb) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, bool BF16 = false>
+__global__ __launch_bounds__(256, 2) void igemm_t3x3s2_kernel(TS2Params p) {
+  __shared__ __attribute__((aligned(16))) float lds[TS_LDS_FLOATS];
+  if (blockIdx.z == 0)
+    ts2_body<0, BM, BF16>(p, lds);
+  else
+    ts2_body<1, BM, BF16>(p, lds);
+}
+
+// -------------------------------------------------------------------------------------------
+// W kernel specialised for 3x3 / STRIDE 2 / pad 1 (the down-sampling convs and the up-sampling transposed convs:
+// "small" image [N][M][Hs][Ws], "big" image [N][C][2Hs][2Ws], Ws % 32 == 0):
+//   dW[m][c][r][s] = sum_{n,p,q} small[n][m][p][q] * big[n][c][2p + r - 1][2q + s - 1]
+// Chunk = one row segment of 32 small pixels.  The three big rows it touches are staged ONCE in LDS for 64 big
+// channels, DE-INTERLEAVED by column parity (odd columns with their left halo: O'[0..32], even columns: E[0..31]),
+// so that the stride-2 tap reads become unit-stride LDS reads: tap s=0 -> O'[q], s=1 -> E[q], s=2 -> O'[q+1].
+// A big element serves only ~9/4 taps here (9 in the stride-1 kernel), so the tile is 128 (m) x 64 (c) x 9 taps
+// on 512 threads (8 waves, 9 accumulators each) to keep ~70 flop per staged byte.
+// -------------------------------------------------------------------------------------------
+#define WS2_LDA 33                // small tile [128 m][32 px + 1]
+#define WS2_ROW 65                // one big row in LDS: O'[33] then E[32]
+#define WS2_CH (3 * WS2_ROW)      // 195 floats per big channel (195 % 32 = 3: conflict-free across 32 channels)
+#define WS2_LDS_BYTES ((128 * WS2_LDA + 64 * WS2_CH) * sizeof(float))
+
+struct WS2Params {
+  const float *Small, *Big, *zero;
+  float *part;                   // [splits][M][C][9]
+  int N, M, C, Hs, Ws;
+  int qblocks;                   // Ws / 32
+  int nchunks, chunks_per_split; // chunk = (n, small row, 32-column block)
+};
+
+template <bool BF16>
+__global__ __launch_bounds__(512, 2) void igemm_w3x3s2_kernel(WS2Params p) {
+  extern __shared__ __attribute__((aligned(16))) float ws2_lds[];
+  float *As = ws2_lds, *Bs = ws2_lds + 128 * WS2_LDA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = blockIdx.x * 64, m0 = blockIdx.y * 128, split = blockIdx.z;
+  const int HWs = p.Hs * p.Ws, Wb = 2 * p.Ws;
+  const long HWb = 4L * HWs;
+  const int ch_begin = split * p.chunks_per_split;
+  int ch_end = ch_begin + p.chunks_per_split;
+  if (ch_end > p.nchunks) ch_end = p.nchunks;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  f32x4 areg[2], breg[6];
+  float hreg = 0.f;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const float *Ap = As + (wm * 32 + l31) * WS2_LDA + half;
+  const float *Bp = Bs + (wn * 32 + l31) * WS2_CH + half;
+  const int per_img = p.Hs * p.qblocks;
+
+  for (int ch = ch_begin - 1; ch < ch_end; ++ch) {
+#ifdef LSPS_ABL_WS2_NOSTAGE
+    if (ch == ch_begin) {
+#else
+    if (ch >= ch_begin) {
+#endif
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int u = tid + 512 * i;
+        float *d = As + (u >> 3) * WS2_LDA + (u & 7) * 4;
+        d[0] = areg[i][0];
+        d[1] = areg[i][1];
+        d[2] = areg[i][2];
+        d[3] = areg[i][3];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int u = tid + 512 * i;
+        const int line = u >> 4, c4 = u & 15;            // line = channel * 3 + row
+        float *d = Bs + line * WS2_ROW + 2 * c4;         // (line * 65 == ch * 195 + row * 65)
+        d[33] = breg[i][0];                              // E[2 c4]
+        d[1] = breg[i][1];                               // O'[2 c4 + 1]
+        d[34] = breg[i][2];                              // E[2 c4 + 1]
+        d[2] = breg[i][3];                               // O'[2 c4 + 2]
+      }
+      if (tid < 192) Bs[tid * WS2_ROW] = hreg;           // O'[0]: the column left of the block (zero at the image edge)
+      __syncthreads();
+    }
+    if (ch + 1 < ch_end) {
+      const int nc = ch + 1;
+      const int n = nc / per_img;
+      const int rem = nc - n * per_img;
+      const int y = rem / p.qblocks, q0 = (rem - y * p.qblocks) * 32;
+      const float *sb = p.Small + ((long)n * p.M + m0) * HWs + y * p.Ws + q0;
+#ifdef LSPS_ABL_WS2_NOLOAD
+      if (ch < ch_begin) {
+#endif
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int u = tid + 512 * i;
+        areg[i] = *reinterpret_cast<const f32x4 *>(sb + (long)(u >> 3) * HWs + (u & 7) * 4);
+      }
+      const float *bb = p.Big + ((long)n * p.C + c0) * HWb + 2 * q0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int u = tid + 512 * i;
+        const int line = u >> 4, c4 = u & 15;
+        const int chn = line / 3, r = line - chn * 3;
+        const int rb = 2 * y - 1 + r;
+        const float *src = rb >= 0 ? (bb + (long)chn * HWb + (long)rb * Wb + c4 * 4) : p.zero;
+        breg[i] = *reinterpret_cast<const f32x4 *>(src);
+      }
+      if (tid < 192) {
+        const int chn = tid / 3, r = tid - chn * 3;
+        const int rb = 2 * y - 1 + r;
+        const float *src = (rb >= 0 && q0 > 0) ? (bb + (long)chn * HWb + (long)rb * Wb - 1) : p.zero;
+        hreg = *src;
+      }
+#ifdef LSPS_ABL_WS2_NOLOAD
+      }
+#endif
+    }
+    if (ch >= ch_begin && BF16) {
+      // bf16 MFMA mode: K = 16 consecutive small pixels per MFMA (lanes 0-31: pixels 0-7 of the group, lanes 32-63:
+      // 8-15), operands rounded to bf16 in registers; 2 groups x 9 taps per chunk
+      const float *A0 = As + (wm * 32 + l31) * WS2_LDA + 8 * half;
+      const float *B0 = Bs + (wn * 32 + l31) * WS2_CH + 8 * half;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        bf16x8 af;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) af[e] = (__bf16)A0[g * 16 + e];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int r = t / 3, sx = t - r * 3;
+          const int off = r * WS2_ROW + (sx == 1 ? 33 : (sx == 2 ? 1 : 0)) + g * 16;
+          bf16x8 bf;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bf[e] = (__bf16)B0[off + e];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    if (ch >= ch_begin && !BF16) {
+      // k-step kq covers small pixels 2kq + half; the operands of step kq+1 are fetched from LDS before the nine
+      // MFMAs of step kq are issued (the compiler does not pipeline the reads across iterations by itself)
+      float a_nx = Ap[0], b_nx[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        b_nx[3 * r + 0] = Bp[r * WS2_ROW];
+        b_nx[3 * r + 1] = Bp[r * WS2_ROW + 33];
+        b_nx[3 * r + 2] = Bp[r * WS2_ROW + 1];
+      }
+#pragma unroll
+      for (int kq = 0; kq < 16; ++kq) {
+        const float a = a_nx;
+        float b[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) b[t] = b_nx[t];
+        if (kq + 1 < 16) {
+          a_nx = Ap[2 * kq + 2];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            b_nx[3 * r + 0] = Bp[r * WS2_ROW + 2 * kq + 2];
+            b_nx[3 * r + 1] = Bp[r * WS2_ROW + 33 + 2 * kq + 2];
+            b_nx[3 * r + 2] = Bp[r * WS2_ROW + 2 * kq + 3];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  const int c = c0 + wn * 32 + l31;
+  // partials in the weight's own layout [split][m][c][t]: a lane's nine taps are 36 contiguous bytes, a wave row is
+  // 1152 contiguous bytes (merged in L2), and the reduction over splits is a plain coalesced sum
+  float *out = p.part + (long)split * p.M * p.C * 9 + (long)c * 9;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) out[(long)m * p.C * 9 + t] = acc[t][r];
+  }
+}
+
+}  // namespace lsps
+#endif
