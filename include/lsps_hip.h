@@ -58,6 +58,12 @@ int lsps_conv2d_dgrad(const float *dy, const float *w, float *dx,
                       int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
                       void *ws, size_t ws_bytes, void *stream);
 /* dw[K,C,R,S] and (optional) db[K] are OVERWRITTEN */
+/* dx = conv2d_dgrad(dy, w) + addend: the input gradient of the FIRST conv of a residual block plus the gradient that
+ * arrives over the skip connection (reference: autograd's sum at `out += residual`, common_net.py:177-181).  For the
+ * 3x3 residual convs the addend is folded into the kernel's epilogue; otherwise dgrad followed by an add pass. */
+int lsps_conv2d_dgrad_acc(const float *dy, const float *w, const float *addend, float *dx,
+                          int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
+                          void *ws, size_t ws_bytes, void *stream);
 int lsps_conv2d_wgrad(const float *x, const float *dy, float *dw, float *db /*nullable*/,
                       int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
                       void *ws, size_t ws_bytes, void *stream);

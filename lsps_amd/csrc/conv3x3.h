@@ -18,6 +18,7 @@ namespace lsps {
 
 struct F3Params {
   const float *X, *Wp, *bias, *zero;
+  const float *R;                // optional addend with Y's layout (dgrad of a residual block: + skip gradient)
   float *Y;
   int Cx, H, M, Mp, NT;          // NT = N * (H/TR) pixel tiles
   int tiles_per_img;             // H / TR
@@ -150,7 +151,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
         if (m < p.M) {
           float v = acc[i][j][r];
           if (p.bias) v += p.bias[m];
-          yb[(long)m * HW] = apply_act(v, p.act, p.slope);
+          v = apply_act(v, p.act, p.slope);
+          if (p.R) v += p.R[(yb - p.Y) + (long)m * HW];
+          yb[(long)m * HW] = v;
         }
       }
     }
@@ -214,6 +217,7 @@ __global__ __launch_bounds__(256) void pack_split_kernel(FSPack p) {
 
 struct FSParams {
   const float *X, *bias, *zero;
+  const float *R;                // optional addend with Y's layout
   const unsigned short *Wq;
   float *Y;
   int Cx, H, M, tiles_per_img;
@@ -366,7 +370,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
         if (m < p.M) {
           float v = acc[i][j][r];
           if (p.bias) v += p.bias[m];
-          yb[(long)m * HW] = apply_act(v, p.act, p.slope);
+          v = apply_act(v, p.act, p.slope);
+          if (p.R) v += p.R[(yb - p.Y) + (long)m * HW];
+          yb[(long)m * HW] = v;
         }
       }
     }

@@ -426,6 +426,21 @@ __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
   }
 }
 
+// y += a (fallback of lsps_conv2d_dgrad_acc for layers outside the fused 3x3 path)
+__global__ __launch_bounds__(256) void add_inplace_kernel(float *__restrict__ y, const float *__restrict__ a, long n) {
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n && ((((uintptr_t)y | (uintptr_t)a) & 15) == 0)) {
+      f32x4 v = *reinterpret_cast<f32x4 *>(y + i);
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(a + i);
+      v += b;
+      *reinterpret_cast<f32x4 *>(y + i) = v;
+    } else {
+      for (long k = i; k < n && k < i + 4; ++k) y[k] += a[k];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *part, float *out, long n, int splits) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;

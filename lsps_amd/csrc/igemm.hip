@@ -162,7 +162,8 @@ static bool f3x3_ok(int Cin, int H, int W, int R, int S, int st_, int pad) {
 
 // in [N][Cin][H][32] -> out [N][M][H][32]; tapidx maps kernel tap t=(dh+1)*3+(dw+1) to the weight's r*3+s
 static int run_f3x3(const float *in, const float *W, const float *bias, float *out, int N, int Cin, int H, int M,
-                    long sm, long sc, bool flip, int act, float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+                    long sm, long sc, bool flip, int act, float slope, void *ws, size_t ws_bytes, hipStream_t st,
+                    const float *addend = nullptr) {
   TapList l;
   l.T = 9;
   for (int t = 0; t < 9; ++t) {
@@ -200,6 +201,7 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
     memset(&q, 0, sizeof(q));
     q.X = in;
     q.bias = bias;
+    q.R = addend;
     q.zero = (const float *)ws;
     q.Wq = pk.Wq;
     q.Y = out;
@@ -240,6 +242,7 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   if (rc) return rc;
   p.X = in;
   p.bias = bias;
+  p.R = addend;
   p.Y = out;
   p.Cx = Cin;
   p.H = H;
@@ -973,6 +976,27 @@ int lsps_conv2d_dgrad(const float *dy, const float *w, float *dx, int N, int C, 
   // out channel m = c: W[k][c][r][s] -> sm = R*S ; reduction channel k -> sc = C*R*S
   return run_transposed_dir(dy, w, nullptr, dx, N, C, H, W, K, P, Q, R, S, stride, pad, (long)R * S, (long)C * R * S,
                             LSPS_ACT_NONE, 1.f, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_conv2d_dgrad_acc(const float *dy, const float *w, const float *addend, float *dx, int N, int C, int H, int W, int K,
+                          int R, int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(dy && w && dx && addend && ws, "conv2d_dgrad_acc: null pointer");
+  LSPS_CHECK_ARG(conv_args_ok(N, C, H, W, K, R, S, stride, pad), "conv2d_dgrad_acc: unsupported geometry");
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+#ifndef LSPS_NO_F3X3
+  // the residual convs: the addend is folded into the epilogue of the 3x3 kernel (no separate pass)
+  if (f3x3_ok(K, P, Q, R, S, stride, pad) && H == P && W == Q && C >= 128)
+    return run_f3x3(dy, w, nullptr, dx, N, K, P, C, (long)R * S, (long)C * R * S, true, LSPS_ACT_NONE, 1.f, ws, ws_bytes,
+                    (hipStream_t)stream, addend);
+#endif
+  int rc = lsps_conv2d_dgrad(dy, w, dx, N, C, H, W, K, R, S, stride, pad, ws, ws_bytes, stream);
+  if (rc) return rc;
+  const long n = (long)N * C * H * W;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n + 1023) / 1024 < 65535 * 16 ? (n + 1023) / 1024 : 65535 * 16)),
+                     dim3(256), 0, (hipStream_t)stream, dx, addend, n);
+  LSPS_CHECK_LAUNCH("add_inplace");
+  return 0;
 }
 
 int lsps_conv2d_wgrad(const float *x, const float *dy, float *dw, float *db, int N, int C, int H, int W, int K, int R,

@@ -276,6 +276,85 @@ class _InormFn(torch.autograd.Function):
         return dy, (dout if ctx.has_res and ctx.needs_input_grad[1] else None), None
 
 
+class _ResBlockFn(torch.autograd.Function):
+    """LeakyINSResBlock as ONE autograd node: x + IN(conv3x3(LReLU(IN(conv3x3(x))))) (common_net.py:160-181, stride 1).
+    Same kernels as the composed form; what the fusion buys is the backward: the gradient arriving over the skip
+    connection is added in the epilogue of the first conv's dgrad kernel (`lsps_conv2d_dgrad_acc`) instead of a separate
+    3-pass add by autograd, and five saved-tensor / node hand-offs disappear."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2):
+        L = _lib.lib()
+        x, w1, w2 = _c(x), _c(w1), _c(w2)
+        N, C, H, W = x.shape
+        K = w1.shape[0]
+        assert w1.shape == (K, C, 3, 3) and w2.shape == (K, K, 3, 3) and K == C, "residual block: C -> C, 3x3"
+        st = _lib.stream()
+        ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, 3, 3, 1, 1), x.device)
+        flops = 2.0 * N * K * H * W * C * 9
+        a1 = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(a1)
+        r1 = torch.empty(N * K, dtype=torch.float32, device=x.device)
+        r2 = torch.empty_like(r1)
+        kname = Profiler.f_kernel(K, C, H, W, 3, 1, 1)
+        with profiler.span(kname, flops, 1):
+            _lib.check(L.lsps_conv2d_fwd(_lib.ptr(x), _lib.ptr(w1), None, _lib.ptr(a1), N, C, H, W, K, 3, 3, 1, 1, ACT_NONE,
+                                         1.0, ws, wsb, st), 'conv2d_fwd')
+        _lib.check(L.lsps_inorm_fwd(_lib.ptr(a1), None, _lib.ptr(a1), _lib.ptr(r1), N * K, H * W, IN_EPS, LRELU_SLOPE, st),
+                   'inorm_fwd')
+        with profiler.span(kname, flops, 1):
+            _lib.check(L.lsps_conv2d_fwd(_lib.ptr(a1), _lib.ptr(w2), None, _lib.ptr(y), N, K, H, W, K, 3, 3, 1, 1, ACT_NONE,
+                                         1.0, ws, wsb, st), 'conv2d_fwd')
+        _lib.check(L.lsps_inorm_fwd(_lib.ptr(y), _lib.ptr(x), _lib.ptr(y), _lib.ptr(r2), N * K, H * W, IN_EPS, -1.0, st),
+                   'inorm_fwd')
+        ctx.save_for_backward(x, w1, w2, a1, y, r1, r2)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        x, w1, w2, a1, y, r1, r2 = ctx.saved_tensors
+        g = _c(g)
+        N, C, H, W = x.shape
+        K = w1.shape[0]
+        st = _lib.stream()
+        ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, 3, 3, 1, 1), x.device)
+        flops = 2.0 * N * K * H * W * C * 9
+        fk, wk = Profiler.f_kernel(C, K, H, W, 3, 1, 1, True), Profiler.w_kernel(C, H, W, K, 3, 1, 1)
+        dh2 = torch.empty_like(y)
+        _lib.check(L.lsps_inorm_bwd(_lib.ptr(g), _lib.ptr(y), _lib.ptr(x), _lib.ptr(r2), _lib.ptr(dh2), N * K, H * W, -1.0,
+                                    st), 'inorm_bwd')
+        dw1 = dw2 = dx = None
+        if ctx.needs_input_grad[2]:
+            dw2 = torch.empty_like(w2)
+            with profiler.span(wk, flops, 1):
+                _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(a1), _lib.ptr(dh2), _lib.ptr(dw2), None, N, K, H, W, K, 3, 3, 1, 1,
+                                               ws, wsb, st), 'conv2d_wgrad')
+        da1 = torch.empty_like(a1)
+        with profiler.span(fk, flops, 1):
+            _lib.check(L.lsps_conv2d_dgrad(_lib.ptr(dh2), _lib.ptr(w2), _lib.ptr(da1), N, K, H, W, K, 3, 3, 1, 1, ws, wsb,
+                                           st), 'conv2d_dgrad')
+        dh1 = dh2                                        # dh2 is dead from here on: reuse its storage
+        _lib.check(L.lsps_inorm_bwd(_lib.ptr(da1), _lib.ptr(a1), None, _lib.ptr(r1), _lib.ptr(dh1), N * K, H * W,
+                                    LRELU_SLOPE, st), 'inorm_bwd')
+        if ctx.needs_input_grad[1]:
+            dw1 = torch.empty_like(w1)
+            with profiler.span(wk, flops, 1):
+                _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dh1), _lib.ptr(dw1), None, N, C, H, W, K, 3, 3, 1, 1, ws,
+                                               wsb, st), 'conv2d_wgrad')
+        if ctx.needs_input_grad[0]:
+            dx = da1                                     # da1 is dead: reuse
+            with profiler.span(fk, flops, 1):
+                _lib.check(L.lsps_conv2d_dgrad_acc(_lib.ptr(dh1), _lib.ptr(w1), _lib.ptr(g), _lib.ptr(dx), N, C, H, W, K, 3, 3,
+                                                   1, 1, ws, wsb, st), 'conv2d_dgrad_acc')
+        return dx, dw1, dw2
+
+
+def res_block(x, w1, w2):
+    """x + IN(conv3x3(LReLU(IN(conv3x3(x, w1))), w2)) — LeakyINSResBlock (common_net.py:160-181), one autograd node."""
+    return _ResBlockFn.apply(x, w1, w2)
+
+
 def instance_norm_(y, residual=None, slope=-1.0):
     """In-place fused InstanceNorm: y <- act(IN(y)) (+ residual).  slope < 0: no activation."""
     return _InormFn.apply(y, residual, float(slope))

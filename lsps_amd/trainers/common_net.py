@@ -112,10 +112,13 @@ class LeakyINSResBlock(nn.Module):
     def forward(self, x, drop_mask=None):
         """`drop_mask` (tests): the keep mask ALREADY divided by 1-p; default: drawn here in training mode."""
         c1, c2 = self.model[0], self.model[3]
+        dropping = self.dropout > 0 and (self.training or drop_mask is not None)
+        if not dropping and c1.stride == 1 and c1.weight.shape[0] == c1.weight.shape[1] and torch.is_grad_enabled():
+            return ops.res_block(x, c1.weight, c2.weight)          # one autograd node (fused skip-gradient add)
         h = ops.conv2d(x, c1.weight, None, c1.stride, 1)
         h = ops.instance_norm_(h, None, LRELU_SLOPE)
         h = ops.conv2d(h, c2.weight, None, 1, 1)
-        if self.dropout > 0 and (self.training or drop_mask is not None):
+        if dropping:
             h = ops.instance_norm_(h, None, -1.0)
             if drop_mask is None:
                 drop_mask = (torch.rand_like(h) >= self.dropout).to(h.dtype) / (1.0 - self.dropout)

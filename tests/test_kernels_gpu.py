@@ -368,3 +368,28 @@ def test_conv3x3_f32_split_math_mode(case):
         ops.set_math_mode('f32')
     errs = dict(y=_rel(y, y_ref), dx=_rel(xd.grad, x.grad), dw=_rel(wd.grad, w.grad))
     assert errs['y'] < 1e-4 and errs['dx'] < 1e-4 and errs['dw'] < 2e-4, errs
+
+
+@pytest.mark.parametrize("case", [(2, 256, 8, 32, 256, 3, 1, 1),      # fused: addend in the 3x3 kernel's epilogue
+                                  (3, 12, 9, 11, 20, 5, 2, 2),        # fallback: dgrad, then an add pass
+                                  (2, 1, 32, 32, 16, 7, 1, 3)],       # fallback through the single-channel tap-GEMM dgrad
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_dgrad_acc(case):
+    """lsps_conv2d_dgrad_acc: dx = dgrad(dy, w) + addend (the skip-connection gradient of a residual block)."""
+    _need_gpu()
+    from lsps_amd import _lib
+    N, C, H, W, K, R, st, pad = case
+    L = _lib.lib()
+    x = _rand(N, C, H, W, seed=1).requires_grad_(True)
+    w = _rand(K, C, R, R, seed=2, scale=0.1)
+    y = F.conv2d(x, w, None, stride=st, padding=pad)
+    gy = _rand(*y.shape, seed=4)
+    y.backward(gy)
+    add = _rand(N, C, H, W, seed=9)
+    want = x.grad + add
+    gyd, wd, addd = gy.cuda().contiguous(), w.cuda().contiguous(), add.cuda().contiguous()
+    dx = torch.empty(N, C, H, W, device='cuda')
+    ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, R, R, st, pad), dx.device)
+    _lib.check(L.lsps_conv2d_dgrad_acc(_lib.ptr(gyd), _lib.ptr(wd), _lib.ptr(addd), _lib.ptr(dx), N, C, H, W, K, R, R, st,
+                                       pad, ws, wsb, _lib.stream()), 'dgrad_acc')
+    assert _rel(dx, want) < 1e-4
