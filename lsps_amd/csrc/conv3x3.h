@@ -16,6 +16,21 @@ namespace lsps {
 #define F3_CC 8
 #define F3_LDW 34                 // 32 pixels + left/right halo column (always zero: W == 32, pad == 1)
 
+// XCD-aware workgroup -> tile mapping.  Workgroups are handed to the 8 XCDs round-robin in linear launch order and each
+// XCD has its own L2.  `lin` = linear workgroup id; this returns (pixel tile, m tile) such that one XCD walks a
+// CONTIGUOUS range of pixel tiles with the m tiles of a pixel tile adjacent in time: the second 128-channel tile re-reads
+// the input rows from that XCD's L2 instead of HBM, and so does the 2-row halo shared with the next pixel tile.
+__device__ __forceinline__ void xcd_tile(int lin, int NT, int MT, int &tile, int &mt) {
+  if ((NT & 7) == 0) {
+    const int xcd = lin & 7, q = lin >> 3;
+    mt = q % MT;
+    tile = xcd * (NT >> 3) + q / MT;
+  } else {
+    tile = lin % NT;
+    mt = lin / NT;
+  }
+}
+
 struct F3Params {
   const float *X, *Wp, *bias, *zero;
   const float *R;                // optional addend with Y's layout (dgrad of a residual block: + skip gradient)
@@ -40,9 +55,11 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.y * BM;
-  const int n = blockIdx.x / p.tiles_per_img;
-  const int row0 = (blockIdx.x - n * p.tiles_per_img) * TR;      // first output row of the tile
+  int tile, mt;
+  xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, tile, mt);
+  const int m0 = mt * BM;
+  const int n = tile / p.tiles_per_img;
+  const int row0 = (tile - n * p.tiles_per_img) * TR;            // first output row of the tile
   const int HW = p.H * 32;
   const float *xn = p.X + (long)n * p.Cx * HW;
 
@@ -242,9 +259,11 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.y * 128;
-  const int n = blockIdx.x / p.tiles_per_img;
-  const int row0 = (blockIdx.x - n * p.tiles_per_img) * TR;
+  int tile, mt;
+  xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, tile, mt);
+  const int m0 = mt * 128;
+  const int n = tile / p.tiles_per_img;
+  const int row0 = (tile - n * p.tiles_per_img) * TR;
   const int HW = p.H * 32;
   const float *xn = p.X + (long)n * p.Cx * HW;
   const int nchunks = p.Cx / 8;
@@ -283,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
   float breg[BP][8];
   const int wm = TR >= 4 ? (wave >> 1) : wave, wn = TR >= 4 ? (wave & 1) : 0;
   const int l31 = lane & 31, half = lane >> 5;
-  const unsigned short *wq = p.Wq + (long)blockIdx.y * nchunks * ACH;
+  const unsigned short *wq = p.Wq + (long)mt * nchunks * ACH;
 
   for (int ch = -1; ch < nchunks; ++ch) {
     if (ch >= 0) {
@@ -403,7 +422,23 @@ __global__ __launch_bounds__(256, 2) void igemm_w3x3_kernel(W3Params p) {
   float *As = lds, *Bs = lds + 64 * W3_LDA;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c0 = blockIdx.x * 64, m0 = blockIdx.y * 64, split = blockIdx.z;
+  // XCD-aware mapping: the (C/64) x (M/64) output tiles of ONE pixel split all read the same dy / x chunks, so they are
+  // placed on one XCD (shared L2), adjacent in launch order; the splits are dealt round-robin to the XCDs
+  int c0, m0, split;
+  {
+    const int tiles = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    int t;
+    if ((gridDim.z & 7) == 0) {
+      const int xcd = lin & 7, q = lin >> 3;
+      t = q % tiles;
+      split = (q / tiles) * 8 + xcd;
+    } else {
+      t = lin % tiles;
+      split = lin / tiles;
+    }
+    c0 = (t % gridDim.x) * 64;
+    m0 = (t / gridDim.x) * 64;
+  }
   const int HW = p.H * 32, rows2 = p.H / 2;
   const int ch_begin = split * p.chunks_per_split;
   int ch_end = ch_begin + p.chunks_per_split;
