@@ -103,13 +103,12 @@ def main():
 
     import lsps_amd.trainers as trainers
     from lsps_amd import ops, synth
-    from oracle import lsps_ref            # only for the key->shape tables of the seeded weights + cpu_baseline
 
     hp = load_hp()
     tr = trainers.LSPSTrainer(hp)
     tr.cuda(local_rank)
-    for net, shapes, seed in ((tr.gen, lsps_ref.gen_shapes(hp['gen']), 1), (tr.dis, lsps_ref.dis_shapes(hp['dis']), 2),
-                              (tr.vae, lsps_ref.vae_shapes(hp['vae']), 3)):
+    for net, seed in ((tr.gen, 1), (tr.dis, 2), (tr.vae, 3)):      # seeded weights, shapes from the nets' own state dicts
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
         net.load_state_dict({k: torch.as_tensor(v) for k, v in synth.make_state_dict(shapes, seed).items()})
     tr.gen.train()
     tr.dis.train()
