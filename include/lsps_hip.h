@@ -149,6 +149,23 @@ int lsps_adam_step(float *p, const float *g, float *m, float *v,
                    int nseg, int max_seg_len, float lr, float beta1, float beta2, float eps, float weight_decay,
                    float gscale, void *stream);
 
+/* ---- BatchNorm (nn.BatchNorm2d / nn.BatchNorm1d of the BN block variants of common_net.py:183-322; not instantiated by
+ * the shipped configs) [+ LeakyReLU].  x, y: [N][C][HW] (HW = 1 for BatchNorm1d).  training != 0: batch statistics
+ * (biased variance for the normalisation, running statistics updated with the unbiased one and `momentum`, as torch
+ * does; run_mean / run_var may be NULL); training == 0: running statistics.  gamma / beta nullable (affine=False, or
+ * beta alone = the `Bias2d` of the "BNNS" blocks, common_net.py:92-105,296-322).  slope < 0: no activation.
+ * mean[C] / rstd[C] are outputs saved for the backward, which returns dx and (nullable) dgamma, dbeta; g is the
+ * gradient w.r.t. the PRE-activation output (apply lsps_act_bwd first).  ws: lsps_bnorm_workspace_bytes(C). */
+size_t lsps_bnorm_workspace_bytes(int C);
+int lsps_bnorm_fwd(const float *x, const float *gamma, const float *beta, float *run_mean, float *run_var, float *y,
+                   float *mean, float *rstd, int N, int C, int HW, int training, float eps, float momentum, float slope,
+                   void *ws, size_t ws_bytes, void *stream);
+int lsps_bnorm_bwd(const float *g, const float *x, const float *mean, const float *rstd, const float *gamma, float *dx,
+                   float *dgamma, float *dbeta, int N, int C, int HW, int training, void *ws, size_t ws_bytes, void *stream);
+/* out = act(x), kind = LSPS_ACT_LRELU (slope 0 = nn.ReLU, common_net.py:146,361) | LSPS_ACT_TANH | LSPS_ACT_SOFTPLUS
+ * (GaussianVAE2D, common_net.py:71-80); lsps_act_bwd is its backward (from the output). */
+int lsps_act_fwd(const float *x, float *out, long n, int kind, float slope, void *stream);
+
 /* elementwise helpers used by the trainer glue (GaussianNoiseLayer common_net.py:39-40 etc.) */
 int lsps_axpy(const float *x, const float *y, float alpha, float *out, long n, void *stream);  /* out = x + alpha*y */
 /* out = (x ? x : 0) + t*m: nn.Dropout on the residual branch of a residual block (common_net.py:171-172, m = keep mask/(1-p))

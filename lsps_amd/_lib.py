@@ -44,6 +44,10 @@ _SIGNATURES = {
     'lsps_linear_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P]),
     'lsps_adam_step': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int] + [c_float] * 6 + [_P]),
     'lsps_axpy': (c_int, [_P, _P, c_float, _P, c_long, _P]),
+    'lsps_bnorm_workspace_bytes': (c_size_t, [c_int]),
+    'lsps_bnorm_fwd': (c_int, [_P] * 8 + [c_int] * 4 + [c_float] * 3 + [_P, c_size_t, _P]),
+    'lsps_bnorm_bwd': (c_int, [_P] * 8 + [c_int] * 4 + [_P, c_size_t, _P]),
+    'lsps_act_fwd': (c_int, [_P, _P, c_long, c_int, c_float, _P]),
     'lsps_mul_add': (c_int, [_P, _P, _P, _P, c_long, _P]),
     'lsps_crop_normalize': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     'lsps_crop_augment': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

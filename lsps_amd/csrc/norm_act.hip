@@ -166,17 +166,23 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ 
         r.y = o.y > 0.f ? d.y : d.y * slope;
         r.z = o.z > 0.f ? d.z : d.z * slope;
         r.w = o.w > 0.f ? d.w : d.w * slope;
-      } else {
+      } else if (kind == LSPS_ACT_TANH) {
         r.x = d.x * (1.f - o.x * o.x);
         r.y = d.y * (1.f - o.y * o.y);
         r.z = d.z * (1.f - o.z * o.z);
         r.w = d.w * (1.f - o.w * o.w);
+      } else {                                   // softplus: sigmoid(z) = 1 - exp(-softplus(z))
+        r.x = o.x > 20.f ? d.x : d.x * (1.f - expf(-o.x));
+        r.y = o.y > 20.f ? d.y : d.y * (1.f - expf(-o.y));
+        r.z = o.z > 20.f ? d.z : d.z * (1.f - expf(-o.z));
+        r.w = o.w > 20.f ? d.w : d.w * (1.f - expf(-o.w));
       }
       *reinterpret_cast<float4 *>(dx + i) = r;
     } else {
       for (long k = i; k < n; ++k) {
         const float o = out[k], d = dy[k];
-        dx[k] = kind == LSPS_ACT_LRELU ? (o > 0.f ? d : d * slope) : d * (1.f - o * o);
+        dx[k] = kind == LSPS_ACT_LRELU ? (o > 0.f ? d : d * slope)
+                                       : (kind == LSPS_ACT_TANH ? d * (1.f - o * o) : (o > 20.f ? d : d * (1.f - expf(-o))));
       }
     }
   }
@@ -262,6 +268,149 @@ __global__ __launch_bounds__(256) void mul_add_kernel(const float *__restrict__ 
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// BatchNorm (nn.BatchNorm2d / nn.BatchNorm1d of the BN block variants, common_net.py:183-322): per-channel statistics
+// over (N, HW).  Not on the shipped configs' path (they use InstanceNorm); kept simple: one statistics pass with
+// double accumulators (sum, sum of squares), one apply pass.  x: [N][C][HW].
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                       const float *__restrict__ mean, double *__restrict__ part, int N,
+                                                       int C, int HW, long slice) {
+  // g == nullptr: part = (sum x, sum x^2);  g != nullptr (backward): xh = (x - mean) -> part = (sum g, sum g*(x - mean))
+  __shared__ double red[2][4];
+  const int c = blockIdx.x, sidx = blockIdx.y;
+  const long total = (long)N * HW;
+  const long e0 = (long)sidx * slice;
+  long e1 = e0 + slice;
+  if (e1 > total) e1 = total;
+  const float mu = g ? mean[c] : 0.f;
+  double s0 = 0.0, s1 = 0.0;
+  for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+    const long n = e / HW;
+    const long off = (n * C + c) * HW + (e - n * HW);
+    const float v = x[off];
+    if (g) {
+      const float gv = g[off];
+      s0 += gv;
+      s1 += (double)gv * (double)(v - mu);
+    } else {
+      s0 += v;
+      s1 += (double)v * (double)v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s0 += __shfl_xor(s0, o, 64);
+    s1 += __shfl_xor(s1, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s0;
+    red[1][threadIdx.x >> 6] = s1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[((long)sidx * C + c) * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    part[((long)sidx * C + c) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+// forward finalize: batch mean / biased var -> mean, rstd; running stats updated with the UNBIASED variance
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double *__restrict__ part, int S, int C, long count, float eps,
+                                                          float momentum, float *__restrict__ mean, float *__restrict__ rstd,
+                                                          float *__restrict__ run_mean, float *__restrict__ run_var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = 0; k < S; ++k) {
+    s0 += part[((long)k * C + c) * 2];
+    s1 += part[((long)k * C + c) * 2 + 1];
+  }
+  const double m = s0 / (double)count;
+  double var = s1 / (double)count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (run_mean) {
+    const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_eval_stats_kernel(const float *__restrict__ run_mean, const float *__restrict__ run_var,
+                                                            float eps, int C, float *__restrict__ mean, float *__restrict__ rstd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = run_mean[c];
+  rstd[c] = 1.f / sqrtf(run_var[c] + eps);
+}
+
+// y = act((x - mean) * rstd * gamma + beta)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                                       const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, float *__restrict__ y, long total, int C,
+                                                       int HW, float slope) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)((i / HW) % C);
+    float v = (x[i] - mean[c]) * rstd[c];
+    if (gamma) v *= gamma[c];
+    if (beta) v += beta[c];
+    if (slope >= 0.f) v = v > 0.f ? v : v * slope;
+    y[i] = v;
+  }
+}
+
+// backward finalize: per channel a = sum g, b = sum g*(x-mean) -> dgamma = b*rstd, dbeta = a, and the two means the
+// apply pass needs (train mode): ma = a/count, mb = b*rstd^2/count
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double *__restrict__ part, int S, int C, long count,
+                                                              const float *__restrict__ rstd, float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta, float *__restrict__ ma,
+                                                              float *__restrict__ mb) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < S; ++k) {
+    a += part[((long)k * C + c) * 2];
+    b += part[((long)k * C + c) * 2 + 1];
+  }
+  if (dgamma) dgamma[c] = (float)(b * (double)rstd[c]);
+  if (dbeta) dbeta[c] = (float)a;
+  ma[c] = (float)(a / (double)count);
+  mb[c] = (float)(b * (double)rstd[c] * (double)rstd[c] / (double)count);
+}
+
+// dx = gamma * rstd * (g - ma - (x - mean) * mb)   (training)   |   gamma * rstd * g   (eval: constants)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ g, const float *__restrict__ x,
+                                                           const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                           const float *__restrict__ gamma, const float *__restrict__ ma,
+                                                           const float *__restrict__ mb, float *__restrict__ dx, long total,
+                                                           int C, int HW, int training) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)((i / HW) % C);
+    const float sc = rstd[c] * (gamma ? gamma[c] : 1.f);
+    float v = g[i];
+    if (training) v = v - ma[c] - (x[i] - mean[c]) * mb[c];
+    dx[i] = v * sc;
+  }
+}
+
+// out = act(x): standalone activation forward (ReLU = LRELU with slope 0, Softplus, Tanh) for the block variants whose
+// activation does not follow a conv directly (common_net.py:146,361; GaussianVAE2D :71-80)
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ x, float *__restrict__ out, long n, int kind,
+                                                      float slope) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = x[i];
+    float r;
+    if (kind == LSPS_ACT_LRELU)
+      r = v > 0.f ? v : v * slope;
+    else if (kind == LSPS_ACT_TANH)
+      r = tanhf(v);
+    else
+      r = v > 20.f ? v : log1pf(expf(v));
+    out[i] = r;
+  }
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(const float *__restrict__ x, const float *__restrict__ y, float alpha,
                                                    float *__restrict__ out, long n) {
   const long stride = (long)gridDim.x * 256 * 4;
@@ -330,7 +479,7 @@ int lsps_inorm_bwd(const float *dout, const float *out, const float *residual, c
 int lsps_act_bwd(const float *dy, const float *out, float *dx, long n, int kind, float slope, void *stream) {
   (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime
   LSPS_CHECK_ARG(dy && out && dx && n >= 0, "act_bwd: bad argument");
-  LSPS_CHECK_ARG(kind == LSPS_ACT_LRELU || kind == LSPS_ACT_TANH, "act_bwd: unknown activation");
+  LSPS_CHECK_ARG(kind == LSPS_ACT_LRELU || kind == LSPS_ACT_TANH || kind == LSPS_ACT_SOFTPLUS, "act_bwd: unknown activation");
   LSPS_CHECK_ARG((((uintptr_t)dy | (uintptr_t)out | (uintptr_t)dx) & 15) == 0, "act_bwd: pointers must be 16-byte aligned");
   if (n == 0) return 0;
   hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, out, dx, n, kind, slope);
@@ -382,6 +531,79 @@ int lsps_mul_add(const float *x, const float *t, const float *m, float *out, lon
   if (n == 0) return 0;
   hipLaunchKernelGGL(mul_add_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, t, m, out, n);
   LSPS_CHECK_LAUNCH("mul_add");
+  return 0;
+}
+
+static long bn_slices(long total) {
+  long S = (total + 16383) / 16384;
+  if (S > 64) S = 64;
+  return S < 1 ? 1 : S;
+}
+
+size_t lsps_bnorm_workspace_bytes(int C) { return (size_t)64 * C * 2 * sizeof(double) + 2 * (size_t)C * sizeof(float) + 256; }
+
+int lsps_bnorm_fwd(const float *x, const float *gamma, const float *beta, float *run_mean, float *run_var, float *y,
+                   float *mean, float *rstd, int N, int C, int HW, int training, float eps, float momentum, float slope,
+                   void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(x && y && mean && rstd && N > 0 && C > 0 && HW > 0, "bnorm_fwd: bad argument");
+  LSPS_CHECK_ARG(training || (run_mean && run_var), "bnorm_fwd: eval mode needs running statistics");
+  LSPS_CHECK_ARG(ws && ws_bytes >= lsps_bnorm_workspace_bytes(C), "bnorm_fwd: workspace too small");
+  const long total = (long)N * HW;
+  hipStream_t st = (hipStream_t)stream;
+  if (training) {
+    const long S = bn_slices(total);
+    const long slice = (total + S - 1) / S;
+    double *part = (double *)ws;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, (int)S), dim3(256), 0, st, x, (const float *)nullptr, (const float *)nullptr,
+                       part, N, C, HW, slice);
+    LSPS_CHECK_LAUNCH("bn_stats");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double *)part, (int)S, C, total, eps,
+                       momentum, mean, rstd, run_mean, run_var);
+    LSPS_CHECK_LAUNCH("bn_finalize");
+  } else {
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float *)run_mean,
+                       (const float *)run_var, eps, C, mean, rstd);
+    LSPS_CHECK_LAUNCH("bn_eval_stats");
+  }
+  const long n = total * C;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, (const float *)mean, (const float *)rstd, gamma,
+                     beta, y, n, C, HW, slope);
+  LSPS_CHECK_LAUNCH("bn_apply");
+  return 0;
+}
+
+int lsps_bnorm_bwd(const float *g, const float *x, const float *mean, const float *rstd, const float *gamma, float *dx,
+                   float *dgamma, float *dbeta, int N, int C, int HW, int training, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(g && x && mean && rstd && dx && N > 0 && C > 0 && HW > 0, "bnorm_bwd: bad argument");
+  LSPS_CHECK_ARG(ws && ws_bytes >= lsps_bnorm_workspace_bytes(C), "bnorm_bwd: workspace too small");
+  const long total = (long)N * HW;
+  hipStream_t st = (hipStream_t)stream;
+  const long S = bn_slices(total);
+  const long slice = (total + S - 1) / S;
+  double *part = (double *)ws;
+  float *ma = (float *)((char *)ws + (size_t)64 * C * 2 * sizeof(double));
+  float *mb = ma + C;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(C, (int)S), dim3(256), 0, st, x, g, mean, part, N, C, HW, slice);
+  LSPS_CHECK_LAUNCH("bn_bwd_stats");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double *)part, (int)S, C, total,
+                     rstd, dgamma, dbeta, ma, mb);
+  LSPS_CHECK_LAUNCH("bn_bwd_finalize");
+  const long n = total * C;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, st, g, x, mean, rstd, gamma, (const float *)ma,
+                     (const float *)mb, dx, n, C, HW, training);
+  LSPS_CHECK_LAUNCH("bn_bwd_apply");
+  return 0;
+}
+
+int lsps_act_fwd(const float *x, float *out, long n, int kind, float slope, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(x && out && n >= 0, "act_fwd: bad argument");
+  LSPS_CHECK_ARG(kind == LSPS_ACT_LRELU || kind == LSPS_ACT_TANH || kind == LSPS_ACT_SOFTPLUS, "act_fwd: unknown activation");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, out, n, kind, slope);
+  LSPS_CHECK_LAUNCH("act_fwd");
   return 0;
 }
 

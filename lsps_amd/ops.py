@@ -532,6 +532,77 @@ def mul_add(x, t, m):
     return _MulAddFn.apply(x, t, m)
 
 
+class _BnormFn(torch.autograd.Function):
+    """nn.BatchNorm2d / nn.BatchNorm1d [+ nn.LeakyReLU] of the BN block variants (common_net.py:183-322).  `x`: [N, C, ...]."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, training, slope, eps, momentum):
+        L = _lib.lib()
+        x = _c(x)
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws, wsb = _lib.workspace(L.lsps_bnorm_workspace_bytes(C), x.device)
+        _lib.check(L.lsps_bnorm_fwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var),
+                                    _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), N, C, HW, int(bool(training)), eps, momentum,
+                                    slope, ws, wsb, _lib.stream()), 'bnorm_fwd')
+        ctx.geom = (N, C, HW, bool(training), slope)
+        ctx.save_for_backward(x, gamma, mean, rstd, y if slope >= 0 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        x, gamma, mean, rstd, y = ctx.saved_tensors
+        N, C, HW, training, slope = ctx.geom
+        g = _c(g)
+        st = _lib.stream()
+        if slope >= 0:
+            gp = torch.empty_like(g)
+            _lib.check(L.lsps_act_bwd(_lib.ptr(g), _lib.ptr(y), _lib.ptr(gp), g.numel(), ACT_LRELU, slope, st), 'act_bwd')
+            g = gp
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[2] else None
+        ws, wsb = _lib.workspace(L.lsps_bnorm_workspace_bytes(C), x.device)
+        _lib.check(L.lsps_bnorm_bwd(_lib.ptr(g), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dx),
+                                    _lib.ptr(dgamma), _lib.ptr(dbeta), N, C, HW, int(training), ws, wsb, st), 'bnorm_bwd')
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batch_norm(x, gamma=None, beta=None, run_mean=None, run_var=None, training=True, slope=-1.0, eps=1e-5, momentum=0.1):
+    """act(BN(x)); running statistics are updated in place in training mode.  slope < 0: no activation."""
+    return _BnormFn.apply(x, gamma, beta, run_mean, run_var, bool(training), float(slope), float(eps), float(momentum))
+
+
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind, slope):
+        L = _lib.lib()
+        x = _c(x)
+        out = torch.empty_like(x)
+        _lib.check(L.lsps_act_fwd(_lib.ptr(x), _lib.ptr(out), x.numel(), kind, slope, _lib.stream()), 'act_fwd')
+        ctx.kind, ctx.slope = kind, slope
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = _c(g)
+        dx = torch.empty_like(g)
+        _lib.check(_lib.lib().lsps_act_bwd(_lib.ptr(g), _lib.ptr(out), _lib.ptr(dx), g.numel(), ctx.kind, ctx.slope,
+                                           _lib.stream()), 'act_bwd')
+        return dx, None, None
+
+
+def act(x, kind, slope=0.0):
+    """Standalone activation: nn.ReLU (kind=ACT_LRELU, slope=0; common_net.py:146,361), nn.Softplus, nn.Tanh."""
+    return _ActFn.apply(x, int(kind), float(slope))
+
+
 def axpy(x, y, alpha=1.0):
     """x + alpha*y (GaussianNoiseLayer: common_net.py:39-40; reparameterisation: lsps_nets.py:78)."""
     return _AxpyFn.apply(x, y, float(alpha))

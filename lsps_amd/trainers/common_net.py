@@ -293,18 +293,230 @@ class GaussianVAE(nn.Module):
         return mu + sd * noise, mu, sd
 
 
-def _unbuilt(name, why):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("%s is not instantiated by any shipped LSPS config and has no HIP kernel here (%s)"
-                                  % (name, why))
-    return type(name, (nn.Module,), {'__init__': __init__, '__doc__': 'Placeholder for the reference class %s.' % name})
+class _BatchNorm(nn.Module):
+    """State holder for lsps_bnorm_* with torch's BatchNorm state-dict keys (weight, bias, running_mean, running_var,
+    num_batches_tracked); eps 1e-5, momentum 0.1 (the reference uses the defaults everywhere)."""
+
+    def __init__(self, num_features, affine=True):
+        super(_BatchNorm, self).__init__()
+        self.num_features, self.affine = num_features, affine
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+        else:
+            self.register_parameter('weight', None)
+            self.register_parameter('bias', None)
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, slope=-1.0, extra_bias=None):
+        """act(BN(x) [+ extra_bias]): `extra_bias` is the Bias2d that follows an affine-free BN in the "BNNS" blocks."""
+        if self.training:
+            self.num_batches_tracked += 1
+        beta = self.bias if self.affine else extra_bias
+        return ops.batch_norm(x, self.weight, beta, self.running_mean, self.running_var, self.training, slope)
 
 
-for _n, _why in (('GaussianSmoother', 'needs cv2'), ('GaussianVAE2D', 'conv + Softplus epilogue'),
-                 ('INSResBlock', 'ReLU after InstanceNorm'), ('ReLUINSConv2d', 'ReLU after InstanceNorm'),
-                 ('ReLUINSConvTranspose2d', 'ReLU after InstanceNorm'), ('LeakyReLUBNNSResBlock', 'BatchNorm'),
-                 ('LeakyReLUBNLinear', 'BatchNorm'), ('LeakyReLUBNConv2d', 'BatchNorm'),
-                 ('LeakyReLUBNConvTranspose2d', 'BatchNorm'), ('LeakyReLUBNNSConv2d', 'BatchNorm'),
-                 ('LeakyReLUBNNSConvTranspose2d', 'BatchNorm')):
-    globals()[_n] = _unbuilt(_n, _why)
-del _n, _why
+class BatchNorm2d(_BatchNorm):
+    pass
+
+
+class BatchNorm1d(_BatchNorm):
+    pass
+
+
+class LeakyReLUBNConv2d(nn.Module):
+    """LReLU(BN(conv(x))), conv without bias (common_net.py:270-281)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0):
+        super(LeakyReLUBNConv2d, self).__init__()
+        self.model = nn.Sequential(Conv2d(n_in, n_out, kernel_size, stride, padding, bias=False), BatchNorm2d(n_out),
+                                   _Fused('LeakyReLU'))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        return self.model[1](self.model[0](x), LRELU_SLOPE)
+
+
+class LeakyReLUBNConvTranspose2d(nn.Module):
+    """LReLU(BN(conv_transpose(x))) (common_net.py:283-294)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0, output_padding=0):
+        super(LeakyReLUBNConvTranspose2d, self).__init__()
+        self.model = nn.Sequential(ConvTranspose2d(n_in, n_out, kernel_size, stride, padding, output_padding, bias=False),
+                                   BatchNorm2d(n_out), _Fused('LeakyReLU'))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        return self.model[1](self.model[0](x), LRELU_SLOPE)
+
+
+class LeakyReLUBNNSConv2d(nn.Module):
+    """LReLU(BN_noaffine(conv(x)) + Bias2d) (common_net.py:296-308): the bias rides in the BN kernel as beta."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0):
+        super(LeakyReLUBNNSConv2d, self).__init__()
+        self.model = nn.Sequential(Conv2d(n_in, n_out, kernel_size, stride, padding, bias=True),
+                                   BatchNorm2d(n_out, affine=False), Bias2d(n_out), _Fused('LeakyReLU'))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        return self.model[1](self.model[0](x), LRELU_SLOPE, self.model[2].bias)
+
+
+class LeakyReLUBNNSConvTranspose2d(nn.Module):
+    """LReLU(BN_noaffine(conv_transpose(x)) + Bias2d) (common_net.py:310-322)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0):
+        super(LeakyReLUBNNSConvTranspose2d, self).__init__()
+        self.model = nn.Sequential(ConvTranspose2d(n_in, n_out, kernel_size, stride, padding, bias=True),
+                                   BatchNorm2d(n_out, affine=False), Bias2d(n_out), _Fused('LeakyReLU'))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        return self.model[1](self.model[0](x), LRELU_SLOPE, self.model[2].bias)
+
+
+class LeakyReLUBNLinear(nn.Module):
+    """LReLU(BN1d_noaffine(linear(x))) (common_net.py:233-244)."""
+
+    def __init__(self, n_in, n_out):
+        super(LeakyReLUBNLinear, self).__init__()
+        self.model = nn.Sequential(Linear(n_in, n_out), BatchNorm1d(n_out, affine=False), _Fused('LeakyReLU'))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        return self.model[1](self.model[0](x), LRELU_SLOPE)
+
+
+class LeakyReLUBNNSResBlock(nn.Module):
+    """x + BN(conv(LReLU(BN(conv(x))))), affine-free BN, convs without bias (common_net.py:183-199)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0):
+        super(LeakyReLUBNNSResBlock, self).__init__()
+        self.model = nn.Sequential(Conv2d(n_in, n_out, kernel_size, stride, padding, bias=False),
+                                   BatchNorm2d(n_out, affine=False), _Fused('LeakyReLU'),
+                                   Conv2d(n_in, n_out, kernel_size, stride, padding, bias=False),
+                                   BatchNorm2d(n_out, affine=False))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        h = self.model[1](self.model[0](x), LRELU_SLOPE)
+        return ops.axpy(self.model[4](self.model[3](h)), x, 1.0)
+
+
+class INSResBlock(nn.Module):
+    """x + [Dropout](IN(conv3x3(ReLU(IN(conv3x3(x)))))) (common_net.py:137-158).  ReLU zeroes half of the normalised
+    values, so the InstanceNorm backward cannot be computed from the activation's output as in the LeakyReLU block:
+    the normalised tensor is kept and the ReLU is a separate pass."""
+
+    def __init__(self, inplanes, planes, stride=1, dropout=0.0):
+        super(INSResBlock, self).__init__()
+        layers = [Conv2d(inplanes, planes, 3, stride, 1), _Fused('InstanceNorm2d'), _Fused('ReLU'),
+                  Conv2d(planes, planes, 3, 1, 1), _Fused('InstanceNorm2d + residual add')]
+        self.dropout = float(dropout)
+        if dropout > 0:
+            layers.append(_Fused('Dropout'))
+        self.model = nn.Sequential(*layers)
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x, drop_mask=None):
+        c1, c2 = self.model[0], self.model[3]
+        h = ops.instance_norm_(ops.conv2d(x, c1.weight, None, c1.stride, 1), None, -1.0)     # biases cancel under IN
+        h = ops.conv2d(ops.act(h, ACT_LRELU, 0.0), c2.weight, None, 1, 1)
+        if self.dropout > 0 and (self.training or drop_mask is not None):
+            h = ops.instance_norm_(h, None, -1.0)
+            if drop_mask is None:
+                drop_mask = (torch.rand_like(h) >= self.dropout).to(h.dtype) / (1.0 - self.dropout)
+            return ops.mul_add(x, h, drop_mask)
+        return ops.instance_norm_(h, x, -1.0)
+
+
+class ReLUINSConv2d(nn.Module):
+    """ReLU(IN(conv(x))) (common_net.py:354-365)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0):
+        super(ReLUINSConv2d, self).__init__()
+        self.model = nn.Sequential(Conv2d(n_in, n_out, kernel_size, stride, padding), _Fused('InstanceNorm2d'),
+                                   _Fused('ReLU'))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        c = self.model[0]
+        return ops.act(ops.instance_norm_(ops.conv2d(x, c.weight, None, c.stride, c.padding), None, -1.0), ACT_LRELU, 0.0)
+
+
+class ReLUINSConvTranspose2d(nn.Module):
+    """ReLU(IN(conv_transpose(x))) (common_net.py:367-380)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding, output_padding):
+        super(ReLUINSConvTranspose2d, self).__init__()
+        self.model = nn.Sequential(ConvTranspose2d(n_in, n_out, kernel_size, stride, padding, output_padding),
+                                   _Fused('InstanceNorm2d'), _Fused('ReLU'))
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        c = self.model[0]
+        h = ops.conv_transpose2d(x, c.weight, None, c.stride, c.padding, c.output_padding)
+        return ops.act(ops.instance_norm_(h, None, -1.0), ACT_LRELU, 0.0)
+
+
+class GaussianVAE2D(nn.Module):
+    """Convolutional mu / softplus(sd) heads (common_net.py:67-90)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0):
+        super(GaussianVAE2D, self).__init__()
+        self.en_mu = Conv2d(n_in, n_out, kernel_size, stride, padding)
+        self.en_sigma = Conv2d(n_in, n_out, kernel_size, stride, padding)
+        for m in (self.en_mu, self.en_sigma):
+            m.weight.data.normal_(0, 0.002)
+            m.bias.data.normal_(0, 0.002)
+
+    def forward(self, x):
+        return self.en_mu(x), ops.act(self.en_sigma(x), ops.ACT_SOFTPLUS)
+
+    def sample(self, x, noise=None):
+        mu, sd = self.forward(x)
+        if noise is None:
+            noise = torch.randn(mu.size(), device=mu.device, dtype=mu.dtype)
+        return mu + sd * noise, mu, sd
+
+
+def gaussian_kernel_1d(ksize):
+    """cv2.getGaussianKernel(ksize, -1) (OpenCV's published rule: fixed tables for ksize <= 7, otherwise
+    sigma = 0.3*((ksize-1)*0.5 - 1) + 0.8, normalised exp(-(i - (ksize-1)/2)^2 / (2 sigma^2)))."""
+    small = {1: [1.0], 3: [0.25, 0.5, 0.25], 5: [0.0625, 0.25, 0.375, 0.25, 0.0625],
+             7: [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125]}
+    if ksize in small:
+        return np.asarray(small[ksize], np.float64)
+    sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    i = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    k = np.exp(-(i * i) / (2.0 * sigma * sigma))
+    return k / k.sum()
+
+
+class GaussianSmoother(nn.Module):
+    """Replicate-padded Gaussian blur of a 1-channel image (common_net.py:12-30); the kernel is a constant, not a
+    parameter.  The blur itself is the single-input-channel conv kernel of the stems."""
+
+    def __init__(self, kernel_size=5):
+        super(GaussianSmoother, self).__init__()
+        self.sigma = 0.3 * ((kernel_size - 1) * 0.5 - 1) + 0.8
+        k = gaussian_kernel_1d(kernel_size)
+        self.pad = (kernel_size - 1) // 2
+        self.blur_kernel = torch.from_numpy(np.outer(k, k)).float().reshape(1, 1, kernel_size, kernel_size)
+        self._k1d = torch.from_numpy(k).float()
+
+    def forward(self, x):
+        out = nn.functional.pad(x, [self.pad, self.pad, self.pad, self.pad], mode='replicate')
+        ks = self.blur_kernel.shape[-1]
+        if ks * ks <= 49:                                 # the conv kernels take up to 49 taps
+            return ops.conv2d(out, self.blur_kernel.to(x.device), None, 1, 0)
+        k = self._k1d.to(x.device)                        # larger kernels: the blur is separable (outer product)
+        return ops.conv2d(ops.conv2d(out, k.reshape(1, 1, ks, 1).contiguous(), None, 1, 0),
+                          k.reshape(1, 1, 1, ks).contiguous(), None, 1, 0)
+
+    def cuda(self, gpu=None):
+        self.blur_kernel = self.blur_kernel.cuda(gpu)
+        return self

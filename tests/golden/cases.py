@@ -400,3 +400,68 @@ def dropout_case_inputs():
     return dict(x=noise(shape, 51), gy=noise(shape, 52), mask=keep,
                 w0=noise((DROP_CH, DROP_CH, 3, 3), 53, 0.05), b0=noise((DROP_CH,), 54, 0.05),
                 w3=noise((DROP_CH, DROP_CH, 3, 3), 55, 0.05), b3=noise((DROP_CH,), 56, 0.05))
+
+
+# ---------------------------------------------------------------------------------------------
+# the block classes of common_net.py that no shipped config instantiates (BatchNorm / ReLU / 2-D VAE variants)
+# ---------------------------------------------------------------------------------------------
+# name -> (constructor args, input shape)
+BLOCK_CASES = OrderedDict([
+    ('LeakyReLUBNConv2d', ((6, 10, 3, 2, 1), (5, 6, 12, 10))),
+    ('LeakyReLUBNConvTranspose2d', ((6, 10, 3, 2, 1, 1), (5, 6, 7, 6))),
+    ('LeakyReLUBNNSConv2d', ((6, 10, 3, 1, 1), (4, 6, 9, 8))),
+    ('LeakyReLUBNNSConvTranspose2d', ((6, 10, 4, 2, 1), (4, 6, 5, 6))),
+    ('LeakyReLUBNLinear', ((12, 20), (9, 12))),
+    ('LeakyReLUBNNSResBlock', ((8, 8, 3, 1, 1), (4, 8, 10, 9))),
+    ('INSResBlock', ((8, 8), (3, 8, 12, 12))),
+    ('ReLUINSConv2d', ((6, 10, 3, 2, 1), (3, 6, 12, 10))),
+    ('ReLUINSConvTranspose2d', ((6, 10, 3, 2, 1, 1), (3, 6, 7, 6))),
+    ('LeakyReLUResBlock', ((8, 8, 3, 1, 1), (3, 8, 10, 9))),
+    ('GaussianVAE2D', ((6, 5, 3, 1, 1), (3, 6, 8, 8))),
+])
+
+
+def run_block_case(mod, name, to_t, to_np):
+    """Builds `mod.<name>`, loads seeded parameters, runs forward + backward in training mode (twice, so that running
+    statistics move) and forward in eval mode.  Returns a flat dict of arrays."""
+    import torch
+    args, xshape = BLOCK_CASES[name]
+    blk = getattr(mod, name)(*args)
+    sd = blk.state_dict()
+    new = {}
+    for i, (k, v) in enumerate(sd.items()):
+        if k.endswith('num_batches_tracked'):
+            new[k] = v
+        elif k.endswith('running_var'):
+            new[k] = torch.as_tensor(np.abs(noise(tuple(v.shape), 700 + i, 0.3)) + 0.5)
+        elif k.endswith('running_mean'):
+            new[k] = torch.as_tensor(noise(tuple(v.shape), 700 + i, 0.2))
+        else:
+            new[k] = torch.as_tensor(noise(tuple(v.shape), 700 + i, 0.15 if v.dim() > 1 else 0.3))
+    blk.load_state_dict(new)
+    blk = to_t(blk)
+    out = OrderedDict()
+    blk.train()
+    for it in range(2):
+        x = to_t(torch.as_tensor(noise(xshape, 800 + it))).requires_grad_(True)
+        for p in blk.parameters():
+            p.grad = None
+        y = blk(x)
+        ys = y if isinstance(y, (tuple, list)) else (y,)
+        loss = sum((yy * to_t(torch.as_tensor(noise(tuple(yy.shape), 900 + it + 10 * j)))).sum() for j, yy in enumerate(ys))
+        loss.backward()
+        for j, yy in enumerate(ys):
+            out['%s/train%d/y%d' % (name, it, j)] = to_np(yy)
+        out['%s/train%d/dx' % (name, it)] = to_np(x.grad)
+        for k, p in blk.named_parameters():
+            if p.grad is not None:
+                out['%s/train%d/grad/%s' % (name, it, k)] = to_np(p.grad)
+    for k, v in blk.state_dict().items():
+        if 'running' in k:
+            out['%s/buffers/%s' % (name, k)] = to_np(v)
+    blk.eval()
+    with torch.no_grad():
+        y = blk(to_t(torch.as_tensor(noise(xshape, 810))))
+        for j, yy in enumerate(y if isinstance(y, (tuple, list)) else (y,)):
+            out['%s/eval/y%d' % (name, j)] = to_np(yy)
+    return out

@@ -211,6 +211,15 @@ def main(which):
     import torch
     torch.set_num_threads(8)
     A = RefAdapter()
+    if which in ('all', 'blocks'):
+        R = OrderedDict()
+        for name in cases.BLOCK_CASES:
+            R.update(cases.run_block_case(A.ref, name, lambda t: t, lambda t: t.detach().cpu().numpy().copy()))
+        path = os.path.join(HERE, 'golden_blocks.npz')
+        np.savez_compressed(path, **R)
+        print('block cases:', len(R), 'arrays ->', path, os.path.getsize(path) // 1024, 'KiB')
+        if which == 'blocks':
+            return
     if which in ('all', 'dropout'):
         path = os.path.join(HERE, 'golden_dropout.npz')
         np.savez_compressed(path, **run_dropout_case(A.ref))

@@ -54,8 +54,13 @@ def test_namespace_matches_reference_package():
                  'LeakyReLULinear', 'LeakyReLUResBlock', 'ReLUINSConv2d', 'ReLUINSConvTranspose2d',
                  'gaussian_weights_init', 'xavier_weights_init', 'get_model_list', 'Variable', 'torch', 'nn', 'os', 'np'):
         assert hasattr(t, name), name
-    with pytest.raises(NotImplementedError):      # BatchNorm / ReLU variants: named, but no silent torch fallback
-        t.LeakyReLUBNConv2d(1, 2, 3, 1)
+    # the BatchNorm / ReLU variants construct (state-dict keys as in the reference) but, like everything else, only run on
+    # HIP tensors: no torch fallback
+    m = t.LeakyReLUBNConv2d(1, 2, 3, 1)
+    assert list(m.state_dict().keys()) == ['model.0.weight', 'model.1.weight', 'model.1.bias', 'model.1.running_mean',
+                                           'model.1.running_var', 'model.1.num_batches_tracked']
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 1, 4, 4))
 
 
 @pytest.mark.parametrize("cfg", ["nnyu", "nicvl"])
