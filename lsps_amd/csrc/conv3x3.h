@@ -156,21 +156,21 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
     }
   }
 
-  // epilogue: wave's pixel rows wn*2 + j, column l31
+  // epilogue: wave's pixel rows wn*2 + j, column l31; channel-major so that a channel's bias is fetched once
+  float *y0 = p.Y + (long)n * p.M * HW + (long)(row0 + wn * 2) * 32 + l31;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    float *yb = p.Y + (long)n * p.M * HW + (long)(row0 + wn * 2 + j) * 32 + l31;
+  for (int i = 0; i < WM; ++i) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m < p.M) {
+        const float bv = p.bias ? p.bias[m] : 0.f;
+        float *ym = y0 + (long)m * HW;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < p.M) {
-          float v = acc[i][j][r];
-          if (p.bias) v += p.bias[m];
-          v = apply_act(v, p.act, p.slope);
-          if (p.R) v += p.R[(yb - p.Y) + (long)m * HW];
-          yb[(long)m * HW] = v;
+        for (int j = 0; j < 2; ++j) {
+          float v = apply_act(acc[i][j][r] + bv, p.act, p.slope);
+          if (p.R) v += p.R[(ym - p.Y) + j * 32];
+          ym[j * 32] = v;
         }
       }
     }
@@ -392,6 +392,165 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_split_kernel(FSParams p) {
           v = apply_act(v, p.act, p.slope);
           if (p.R) v += p.R[(yb - p.Y) + (long)m * HW];
           yb[(long)m * HW] = v;
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// bf16 MFMA kernel of the 3x3 / stride-1 / width-32 layers (math mode 1), K = 16 CHANNELS of one tap per MFMA:
+// weights packed once per call as [m tile][16-channel chunk][9 taps][128 m][16 c] bf16, input rows rounded to bf16 when
+// staged and stored [row][column][16 c], so every operand fragment is one ds_read_b128 (lanes 0-31: channels 0-7,
+// lanes 32-63: channels 8-15) and a tap costs exactly one MFMA per tile pair (the 8-channel layout of the split kernel
+// pairs taps and wastes the tenth half-tap).  16 channels per chunk also halves the barriers per reduction element.
+// -------------------------------------------------------------------------------------------
+#define FB_CC 16
+#define FB_ACH (9 * 128 * FB_CC)                     // bf16 elements of weights per (m tile, chunk): 36 KB
+
+__global__ __launch_bounds__(256) void pack_bf16_kernel(FSPack p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // over [mtile][chunk][tap][m_local][c]
+  const int chunks = p.C / FB_CC, mtiles = (p.M + 127) / 128;
+  const long total = (long)mtiles * chunks * FB_ACH;
+  if (idx >= total) return;
+  const int c = (int)(idx & 15);
+  const int ml = (int)((idx >> 4) & 127);
+  long rest = idx >> 11;
+  const int t = (int)(rest % 9);
+  rest /= 9;
+  const int chunk = (int)(rest % chunks), mt = (int)(rest / chunks);
+  const int m = mt * 128 + ml;
+  float v = 0.f;
+  if (m < p.M) v = p.W[(long)m * p.sm + (long)(chunk * FB_CC + c) * p.sc + p.tapidx[t]];
+  p.Wq[idx] = __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+
+// TR = 4: 256 threads (waves 2 x 2);  TR = 8: 512 threads (waves 2 x 4, the weight tile is reused by twice the pixels)
+template <int TR, int NTHR>
+__global__ __launch_bounds__(NTHR, 2) void igemm_f3x3_bf16_kernel(FSParams p) {
+  constexpr int ROWS = TR + 2;
+  constexpr int BEL = ROWS * F3_LDW * FB_CC;                 // bf16 elements of the staged input rows
+  constexpr int A16 = (FB_ACH / 8 + NTHR - 1) / NTHR;        // 16-byte units of weights per thread per chunk (9 or 5)
+  constexpr int WAVES_N = NTHR / 128;                        // waves along the pixel rows (2 or 4); 2 along the channels
+  constexpr int JN = TR / WAVES_N;                           // image rows per wave
+  constexpr int BP = (ROWS * 32 + NTHR - 1) / NTHR;          // staged pixels per thread
+  __shared__ __attribute__((aligned(16))) unsigned short lds[FB_ACH + BEL];
+  unsigned short *Aq = lds, *Bq = lds + FB_ACH;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile, mt;
+  xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, tile, mt);
+  const int m0 = mt * 128;
+  const int n = tile / p.tiles_per_img;
+  const int row0 = (tile - n * p.tiles_per_img) * TR;
+  const int HW = p.H * 32;
+  const float *xn = p.X + (long)n * p.Cx * HW;
+  const int nchunks = p.Cx / FB_CC;
+
+  // halo columns 0 and 33 of every staged row: zero once
+  for (int u = tid; u < ROWS * 2 * FB_CC; u += NTHR) {
+    const int c = u & 15, side = (u >> 4) & 1, r = u >> 5;
+    Bq[(r * F3_LDW + side * 33) * FB_CC + c] = 0;
+  }
+
+  bool b_use[BP], b_ok[BP];
+  int b_lds[BP];
+  long b_off[BP];
+#pragma unroll
+  for (int q = 0; q < BP; ++q) {
+    const int u = tid + NTHR * q;
+    b_use[q] = u < ROWS * 32;
+    const int b_r = u >> 5, b_col = u & 31;
+    const int img_row = row0 - 1 + b_r;
+    b_ok[q] = b_use[q] && img_row >= 0 && img_row < p.H;
+    b_lds[q] = (b_r * F3_LDW + 1 + b_col) * FB_CC;
+    b_off[q] = (long)img_row * 32 + b_col;
+  }
+
+  f32x16 acc[2][JN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 areg[A16];
+  float breg[BP][FB_CC];
+  const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+  const int l31 = lane & 31, half = lane >> 5;
+  const unsigned short *wq = p.Wq + (long)mt * nchunks * FB_ACH;
+
+  for (int ch = -1; ch < nchunks; ++ch) {
+    if (ch >= 0) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < A16; ++i)
+        if ((tid + NTHR * i) * 8 < FB_ACH) *reinterpret_cast<f32x4 *>(Aq + (tid + NTHR * i) * 8) = areg[i];
+#pragma unroll
+      for (int q = 0; q < BP; ++q)
+        if (b_use[q]) {
+#pragma unroll
+          for (int h8 = 0; h8 < 2; ++h8) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)breg[q][h8 * 8 + e];
+            *reinterpret_cast<bf16x8 *>(Bq + b_lds[q] + h8 * 8) = v;
+          }
+        }
+      __syncthreads();
+    }
+    if (ch + 1 < nchunks) {
+      const unsigned short *src = wq + (long)(ch + 1) * FB_ACH;
+#pragma unroll
+      for (int i = 0; i < A16; ++i) {
+        const int u8 = (tid + NTHR * i) * 8;
+        areg[i] = *reinterpret_cast<const f32x4 *>(src + (u8 < FB_ACH ? u8 : 0));
+      }
+      const float *xc = xn + (long)(ch + 1) * FB_CC * HW;
+#pragma unroll
+      for (int q = 0; q < BP; ++q)
+#pragma unroll
+        for (int e = 0; e < FB_CC; ++e) {
+          const float *s2 = b_ok[q] ? (xc + (long)e * HW + b_off[q]) : p.zero;
+          breg[q][e] = *s2;
+        }
+    }
+    if (ch >= 0) {
+#pragma unroll 3
+      for (int t = 0; t < 9; ++t) {                          // partial unroll: keeps the live operand fragments few
+        const int arow = t * 128 + wm * 64 + l31;
+        const int boff = (t / 3) * F3_LDW + (t % 3) + wn * JN * F3_LDW + l31;
+        bf16x8 af[2], bf[JN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(Aq + (arow + i * 32) * FB_CC + 8 * half);
+#pragma unroll
+        for (int j = 0; j < JN; ++j) bf[j] = *reinterpret_cast<const bf16x8 *>(Bq + (boff + j * F3_LDW) * FB_CC + 8 * half);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < JN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: channel-major so that a channel's bias is fetched once for all of the wave's rows
+  float *y0 = p.Y + (long)n * p.M * HW + (long)(row0 + wn * JN) * 32 + l31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m < p.M) {
+        const float bv = p.bias ? p.bias[m] : 0.f;
+        float *ym = y0 + (long)m * HW;
+#pragma unroll
+        for (int j = 0; j < JN; ++j) {
+          float v = apply_act(acc[i][j][r] + bv, p.act, p.slope);
+          if (p.R) v += p.R[(ym - p.Y) + j * 32];
+          ym[j * 32] = v;
         }
       }
     }

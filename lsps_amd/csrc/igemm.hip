@@ -173,6 +173,57 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   }
   const int RED = Cin * 9, REDp = RED;     // Cin % 8 == 0 -> RED % 72 == 0
   const int Mp = (int)align_up(M, 128);
+  if (g_math_mode == 1 && (Cin % FB_CC) == 0 && (H % 4) == 0) {      // bf16 mode: 16-channel-chunk kernel
+    const size_t wq_bytes = (size_t)(Mp / 128) * (Cin / FB_CC) * FB_ACH * sizeof(unsigned short);
+    if (256 + wq_bytes > ws_bytes) {
+      set_error("conv workspace too small: need %zu, have %zu", 256 + wq_bytes, ws_bytes);
+      return LSPS_E_WS;
+    }
+    hipError_t e = hipMemsetAsync(ws, 0, 256, st);
+    if (e != hipSuccess) {
+      set_error("hipMemsetAsync: %s", hipGetErrorString(e));
+      return LSPS_E_HIP;
+    }
+    FSPack pk;
+    pk.W = W;
+    pk.Wq = (unsigned short *)((char *)ws + 256);
+    pk.M = M;
+    pk.C = Cin;
+    pk.np = 1;
+    pk.sm = sm;
+    pk.sc = sc;
+    for (int t = 0; t < 9; ++t) pk.tapidx[t] = l.idx[t];
+    const long total = (long)(Mp / 128) * (Cin / FB_CC) * FB_ACH;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, pk);
+    LSPS_CHECK_LAUNCH("pack_bf16");
+    FSParams q;
+    memset(&q, 0, sizeof(q));
+    q.X = in;
+    q.bias = bias;
+    q.R = addend;
+    q.zero = (const float *)ws;
+    q.Wq = pk.Wq;
+    q.Y = out;
+    q.Cx = Cin;
+    q.H = H;
+    q.M = M;
+    q.act = act;
+    q.slope = slope;
+    // the bf16 MFMA outruns LDS (1 KB of operands per 32-cycle MFMA at a 64x64 wave tile = the whole 128 B/clk), so the
+    // wave tile grows with the batch: 64 ch x 4 rows (16-row tiles) needs 0.75 KB per MFMA
+    const bool huge = (H % 16) == 0 && (long)N * (H / 16) * (Mp / 128) >= 512;
+    const bool big = (H % 8) == 0 && (long)N * (H / 8) * (Mp / 128) >= 1024;
+    q.tiles_per_img = H / (huge ? 16 : (big ? 8 : 4));
+    const dim3 grid2(N * q.tiles_per_img, Mp / 128);
+    if (huge)
+      hipLaunchKernelGGL((igemm_f3x3_bf16_kernel<16, 512>), grid2, dim3(512), 0, st, q);
+    else if (big)
+      hipLaunchKernelGGL((igemm_f3x3_bf16_kernel<8, 512>), grid2, dim3(512), 0, st, q);
+    else
+      hipLaunchKernelGGL((igemm_f3x3_bf16_kernel<4, 256>), grid2, dim3(256), 0, st, q);
+    LSPS_CHECK_LAUNCH("igemm_f3x3_bf16");
+    return 0;
+  }
   if (g_math_mode != 0) {                  // bf16 / split-precision variants: weights pre-converted to bf16 limb planes
     const int np = g_math_mode == 2 ? 3 : 1;
     const size_t wq_bytes = (size_t)(Mp / 128) * (Cin / 8) * np * FS_APLANE * sizeof(unsigned short);
