@@ -445,11 +445,7 @@ __global__ __launch_bounds__(512, 2) void igemm_w3x3s2_kernel(WS2Params p) {
   const int per_img = p.Hs * p.qblocks;
 
   for (int ch = ch_begin - 1; ch < ch_end; ++ch) {
-#ifdef LSPS_ABL_WS2_NOSTAGE
-    if (ch == ch_begin) {
-#else
     if (ch >= ch_begin) {
-#endif
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -479,9 +475,6 @@ __global__ __launch_bounds__(512, 2) void igemm_w3x3s2_kernel(WS2Params p) {
       const int rem = nc - n * per_img;
       const int y = rem / p.qblocks, q0 = (rem - y * p.qblocks) * 32;
       const float *sb = p.Small + ((long)n * p.M + m0) * HWs + y * p.Ws + q0;
-#ifdef LSPS_ABL_WS2_NOLOAD
-      if (ch < ch_begin) {
-#endif
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int u = tid + 512 * i;
@@ -503,9 +496,6 @@ __global__ __launch_bounds__(512, 2) void igemm_w3x3s2_kernel(WS2Params p) {
         const float *src = (rb >= 0 && q0 > 0) ? (bb + (long)chn * HWb + (long)rb * Wb - 1) : p.zero;
         hreg = *src;
       }
-#ifdef LSPS_ABL_WS2_NOLOAD
-      }
-#endif
     }
     if (ch >= ch_begin && BF16) {
       // bf16 MFMA mode: K = 16 consecutive small pixels per MFMA (lanes 0-31: pixels 0-7 of the group, lanes 32-63:

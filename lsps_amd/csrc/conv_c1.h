@@ -91,20 +91,12 @@ __global__ __launch_bounds__(256, 2) void c1_fwd_kernel(C1Params p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#ifdef LSPS_ABL_C1_NOMFMA
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#else
 #pragma unroll
     for (int ks = 0; ks < C1_KS; ++ks) {
-#endif
       const float b = Bp[boff[ks]];
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][i], b, acc[i], 0, 0, 0);
     }
-#ifdef LSPS_ABL_C1_NOSTORE
-    if (acc[0][0] != 123.f && acc[1][3] != 77.f) continue;
-#endif
     float *yb = p.Y + ((long)n * p.K + m0) * PQ + (long)(p0 + pr) * p.Q + q0 + l31;
 #pragma unroll
     for (int i = 0; i < 2; ++i)

@@ -23,7 +23,8 @@
 //   LSPS_ABL_NOLOAD / _NOSTORE / _NOBAR / _SAMEADDR  ablations of the generic F kernel's phases
 //   LSPS_ABL_SPLIT_NOA   cache-resident weight tile in the split-precision kernel
 //   LSPS_STAGGER_PRIO, LSPS_F_LDS_PAD=<floats>       priority stagger / occupancy cap experiments
-//   LSPS_NO_F3X3, LSPS_NO_W3X3                       force the generic kernels for the 3x3 layers
+//   LSPS_NO_F3X3, LSPS_NO_W3X3, LSPS_NO_F3X3S2, LSPS_NO_T3X3S2, LSPS_NO_W3X3S2, LSPS_NO_C1
+//                                                     force the generic kernels for the respective layer class
 //
 // Reference call sites replaced: every nn.Conv2d / nn.ConvTranspose2d on the path
 // (src/trainers/common_net.py:162-163,250,262; src/trainers/lsps_nets.py:17-23,123-124,226-227)
