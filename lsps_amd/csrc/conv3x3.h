@@ -39,7 +39,27 @@ struct F3Params {
   int tiles_per_img;             // H / TR
   int act;
   float slope;
+  // small batches (the estimate modes run the generator on 4-8 samples): the channel reduction is split over
+  // blockIdx.z; each split writes raw partial sums to part[z][N][M][H][32], f3x3_ksplit_reduce_kernel finishes
+  int ksplit, chunks_per_split;
+  float *part;
 };
+
+// y = act(sum_z part[z] + bias[m]) + R   (second stage of the reduction split above)
+__global__ __launch_bounds__(256) void f3x3_ksplit_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias,
+                                                                 const float *__restrict__ R, float *__restrict__ y,
+                                                                 long total4, int ks, int M, int HW, int act, float slope) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  f32x4 s = reinterpret_cast<const f32x4 *>(part)[i];
+  for (int z = 1; z < ks; ++z) s += reinterpret_cast<const f32x4 *>(part)[(long)z * total4 + i];
+  const int m = (int)((i * 4 / HW) % M);
+  const float bv = bias ? bias[m] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s[e] = apply_act(s[e] + bv, act, slope);
+  if (R) s += reinterpret_cast<const f32x4 *>(R)[i];
+  reinterpret_cast<f32x4 *>(y)[i] = s;
+}
 
 // TR = output rows per tile: 4 (tile 128 ch x 128 px, waves 2x2, each 64 ch x 64 px) or, when that grid would
 // leave CUs idle (estimate modes run the generator on 8 samples), 2 (128 ch x 64 px, waves 4x1, each 32 ch x 64 px).
@@ -94,14 +114,16 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 areg[A4], breg[B4];
-  const int nchunks = p.Cx / F3_CC;
+  const int nchunks_all = p.Cx / F3_CC;
+  const int ch0 = p.ksplit > 1 ? blockIdx.z * p.chunks_per_split : 0;
+  const int nchunks = p.ksplit > 1 ? min(nchunks_all, ch0 + p.chunks_per_split) : nchunks_all;   // end of this split
   const int wm = TR == 4 ? (wave >> 1) : wave, wn = TR == 4 ? (wave & 1) : 0;
   const int l31 = lane & 31, half = lane >> 5;
   const float *Ap = As + half * BM + wm * WM * 32 + l31;
   const float *Bp = Bs + half * CH + wn * 2 * F3_LDW + l31;
 
-  for (int ch = -1; ch < nchunks; ++ch) {
-    if (ch >= 0) {
+  for (int ch = ch0 - 1; ch < nchunks; ++ch) {
+    if (ch >= ch0) {
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < A4; ++i) {
@@ -134,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
         breg[i] = *reinterpret_cast<const f32x4 *>(src);
       }
     }
-    if (ch >= 0) {
+    if (ch >= ch0) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int tr = t / 3, ts = t - tr * 3;
@@ -164,8 +186,14 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (m < p.M) {
-        const float bv = p.bias ? p.bias[m] : 0.f;
         float *ym = y0 + (long)m * HW;
+        if (p.ksplit > 1) {                                      // raw partial sums of this reduction split
+          float *pm = p.part + (long)blockIdx.z * p.NT * (long)(TR * 32) * p.M + (ym - p.Y);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) pm[j * 32] = acc[i][j][r];
+          continue;
+        }
+        const float bv = p.bias ? p.bias[m] : 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           float v = apply_act(acc[i][j][r] + bv, p.act, p.slope);

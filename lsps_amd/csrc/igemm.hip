@@ -305,7 +305,29 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   p.NT = N * p.tiles_per_img;
   p.act = act;
   p.slope = slope;
-  const dim3 grid(p.NT, Mp / 128);
+  dim3 grid(p.NT, Mp / 128);
+  // fewer workgroups than CUs and a long reduction (estimate modes: generator on 4-8 samples): split the channel chunks
+  const long wgs = (long)p.NT * (Mp / 128);
+  const int nchunks = Cin / F3_CC;
+  const long total = (long)N * M * H * 32;
+  if (tr == 2 && wgs <= 256 && nchunks >= 16 && Mp == M) {
+    int ks = wgs <= 128 ? (int)(1024 / wgs) : 2;            // measured: 256 workgroups gain nothing beyond 2 splits
+    if (ks > nchunks / 4) ks = nchunks / 4;
+    if (ks > 8) ks = 8;
+    const size_t part_bytes = (size_t)ks * total * sizeof(float);
+    if (ks > 1 && align_up(need, 256) + part_bytes <= ws_bytes) {
+      p.ksplit = ks;
+      p.chunks_per_split = ceil_div(nchunks, ks);
+      p.part = (float *)((char *)ws + align_up(need, 256));
+      grid.z = ks;
+      hipLaunchKernelGGL(igemm_f3x3_kernel<2>, grid, dim3(256), 0, st, p);
+      LSPS_CHECK_LAUNCH("igemm_f3x3");
+      hipLaunchKernelGGL(f3x3_ksplit_reduce_kernel, dim3(ceil_div(total / 4, 256)), dim3(256), 0, st, (const float *)p.part,
+                         bias, addend, out, total / 4, ks, M, H * 32, act, slope);
+      LSPS_CHECK_LAUNCH("f3x3_ksplit_reduce");
+      return 0;
+    }
+  }
   if (tr == 4)
     hipLaunchKernelGGL(igemm_f3x3_kernel<4>, grid, dim3(256), 0, st, p);
   else
@@ -940,7 +962,12 @@ static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int W
     if (w3 > m) m = w3;
   }
   if (Cb == 1 && Cs <= 64 && c1_wgrad_ws_bytes(Cs, R, S) > m) m = c1_wgrad_ws_bytes(Cs, R, S);
-  return 2 * BIAS_WS_BYTES + m + ((size_t)8 << 20) + 1024;   // + 8 MiB: reduction-split partials of tiny forward problems
+  size_t ksp = 0;                           // reduction-split partials of the small-batch 3x3 kernel (run_f3x3)
+  if (R == 3 && S == 3 && st_ == 1 && Wb == 32 && Hb == Hs) {
+    const int cmax = Cb > Cs ? Cb : Cs;
+    if ((long)N * (Hb / 2) * ceil_div(cmax, 128) <= 256) ksp = (size_t)8 * N * cmax * Hb * 32 * sizeof(float) + 512;
+  }
+  return 2 * BIAS_WS_BYTES + m + ksp + ((size_t)8 << 20) + 1024;   // + 8 MiB: reduction-split partials of tiny forward problems
 }
 
 static bool conv_args_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {

@@ -67,6 +67,8 @@ CONV_CASES = [
     (2, 1, 8, 128, 64, 7, 1, 3),        # single-channel: one row tile of 8, Q = 128
     (1, 128, 16, 32, 64, 3, 2, 1),      # stride 2 with 16 output columns: everything generic
     (2, 64, 16, 64, 64, 3, 2, 1),       # stride 2, M = 64: forward generic (needs M >= 128), dgrad on the BM=64 transposed kernel
+    (2, 256, 32, 32, 256, 3, 1, 1),     # 3x3 kernel at a small batch: reduction split over blockIdx.z (+ reduce with bias / act)
+    (1, 128, 8, 32, 128, 3, 1, 1),      # same, one image, 16 chunks
 ]
 
 
