@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void f3x3_ksplit_reduce_kernel(const float *__
 
 // TR = output rows per tile: 4 (tile 128 ch x 128 px, waves 2x2, each 64 ch x 64 px) or, when that grid would
 // leave CUs idle (estimate modes run the generator on 8 samples), 2 (128 ch x 64 px, waves 4x1, each 32 ch x 64 px).
-template <int TR>
+// KSPLIT is a template parameter: with a run-time split the chunk loop of the main variant lost 4 % (129 vs 135 TFLOP/s)
+template <int TR, bool KSPLIT = false>
 __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
   constexpr int BM = 128, RC = F3_CC * 9;            // 72 reduction rows per chunk
   constexpr int A4 = RC * BM / 4 / 256;              // 9 float4 of weights per thread per chunk
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
 
   f32x4 areg[A4], breg[B4];
   const int nchunks_all = p.Cx / F3_CC;
-  const int ch0 = p.ksplit > 1 ? blockIdx.z * p.chunks_per_split : 0;
-  const int nchunks = p.ksplit > 1 ? min(nchunks_all, ch0 + p.chunks_per_split) : nchunks_all;   // end of this split
+  const int ch0 = KSPLIT ? blockIdx.z * p.chunks_per_split : 0;
+  const int nchunks = KSPLIT ? min(nchunks_all, ch0 + p.chunks_per_split) : nchunks_all;   // end of this split
   const int wm = TR == 4 ? (wave >> 1) : wave, wn = TR == 4 ? (wave & 1) : 0;
   const int l31 = lane & 31, half = lane >> 5;
   const float *Ap = As + half * BM + wm * WM * 32 + l31;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3_kernel(F3Params p) {
       const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (m < p.M) {
         float *ym = y0 + (long)m * HW;
-        if (p.ksplit > 1) {                                      // raw partial sums of this reduction split
+        if (KSPLIT) {                                            // raw partial sums of this reduction split
           float *pm = p.part + (long)blockIdx.z * p.NT * (long)(TR * 32) * p.M + (ym - p.Y);
 #pragma unroll
           for (int j = 0; j < 2; ++j) pm[j * 32] = acc[i][j][r];

@@ -283,7 +283,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
 // y[n][m][p] = act(bias[m] + sum_z part[z][m][n*P + p])   (forward direction only: contiguous output lattice)
 __global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias,
                                                             float *__restrict__ y, int M, int P, long NPIX, int ksplit,
-                                                            int act, float slope) {
+                                                            int act, float slope, int PW, int HyWy, int Wy, int h0, int hs,
+                                                            int w0, int ws) {
+  // part[z][m][pix] -> Y[n][m][h0 + hs*ph][w0 + ws*pw]  (pix = n*P + ph*PW + pw; the output lattice of one parity class of
+  // the transposed direction, or the whole image with h0 = w0 = 0, hs = ws = 1)
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // over [M][NPIX]
   if (idx >= (long)M * NPIX) return;
   const int m = (int)(idx / NPIX);
@@ -291,8 +294,10 @@ __global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float *__restr
   float s = 0.f;
   for (int z = 0; z < ksplit; ++z) s += part[(long)z * M * NPIX + idx];
   if (bias) s += bias[m];
-  const long n = pix / P, pp = pix - n * P;
-  y[(n * M + m) * P + pp] = apply_act(s, act, slope);
+  const long n = pix / P;
+  const int pp = (int)(pix - n * P);
+  const int ph = pp / PW, pw = pp - ph * PW;
+  y[(n * M + m) * HyWy + (long)(h0 + hs * ph) * Wy + w0 + ws * pw] = apply_act(s, act, slope);
 }
 
 // -------------------------------------------------------------------------------------------

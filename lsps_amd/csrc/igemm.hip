@@ -150,6 +150,32 @@ static int launch_f(const FParams &p, int cfg, hipStream_t st) {
   return 0;
 }
 
+// launch_f with an optional split of the reduction over blockIdx.z: layers with few output tiles and a long reduction
+// (the late discriminator layers on small batches, the heads) otherwise leave most CUs idle for hundreds of chunks
+static int launch_f_split(FParams &p, int cfg, void *free_ws, size_t free_bytes, hipStream_t st) {
+  const long wgs = (long)ceil_div(p.NPIX, cfg_bn(cfg)) * ceil_div(p.M, cfg_bm(cfg));
+  const int nchunks = p.REDp / BK_F;
+  if (wgs <= 256 && nchunks >= 32) {
+    int ks = (int)((wgs <= 64 ? 256 : 1024) / wgs);
+    if (ks > nchunks / 4) ks = nchunks / 4;
+    if (ks > 16) ks = 16;
+    while (ks > 1 && (size_t)ks * p.M * p.NPIX * sizeof(float) > free_bytes) ks >>= 1;
+    if (ks > 1) {
+      p.ksplit = ks;
+      p.chunks_per_split = ceil_div(nchunks, ks);
+      p.part = (float *)free_ws;
+      int rc = launch_f(p, cfg, st);
+      if (rc) return rc;
+      const long total = (long)p.M * p.NPIX;
+      hipLaunchKernelGGL(ksplit_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float *)p.part, p.bias, p.Y,
+                         p.M, p.P, (long)p.NPIX, ks, p.act, p.slope, p.PW, p.HyWy, p.Wy, p.h0, p.hs, p.w0, p.ws);
+      LSPS_CHECK_LAUNCH("ksplit_reduce");
+      return 0;
+    }
+  }
+  return launch_f(p, cfg, st);
+}
+
 static size_t packed_bytes(int Cin, int taps_total, int classes, int M) {
   const int Mp = (int)align_up((size_t)M, 128);
   // sum over classes of class_bytes(REDp_c, Mp) with sum REDp_c <= Cin*taps_total + 32*classes
@@ -320,7 +346,7 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
       p.chunks_per_split = ceil_div(nchunks, ks);
       p.part = (float *)((char *)ws + align_up(need, 256));
       grid.z = ks;
-      hipLaunchKernelGGL(igemm_f3x3_kernel<2>, grid, dim3(256), 0, st, p);
+      hipLaunchKernelGGL((igemm_f3x3_kernel<2, true>), grid, dim3(256), 0, st, p);
       LSPS_CHECK_LAUNCH("igemm_f3x3");
       hipLaunchKernelGGL(f3x3_ksplit_reduce_kernel, dim3(ceil_div(total / 4, 256)), dim3(256), 0, st, (const float *)p.part,
                          bias, addend, out, total / 4, ks, M, H * 32, act, slope);
@@ -329,9 +355,9 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
     }
   }
   if (tr == 4)
-    hipLaunchKernelGGL(igemm_f3x3_kernel<4>, grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_f3x3_kernel<4, false>), grid, dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL(igemm_f3x3_kernel<2>, grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_f3x3_kernel<2, false>), grid, dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_f3x3");
   return 0;
 }
@@ -485,27 +511,7 @@ static int run_forward_dir(const float *in, const float *W, const float *bias, f
   p.act = act;
   p.slope = slope;
   fill_taps(p.taps, l, Wb);
-  const int cfg = choose_cfg(M, p.NPIX);
-  const long wgs = (long)ceil_div(p.NPIX, cfg_bn(cfg)) * ceil_div(M, cfg_bm(cfg));
-  const int nchunks = REDp / BK_F;
-  if (wgs <= 64 && nchunks >= 32) {          // a handful of workgroups with a long reduction: split it
-    int ks = (int)(256 / wgs);
-    if (ks > nchunks / 4) ks = nchunks / 4;
-    const size_t part_bytes = (size_t)ks * M * p.NPIX * sizeof(float);
-    if (ks > 1 && need + part_bytes <= ws_bytes) {
-      p.ksplit = ks;
-      p.chunks_per_split = ceil_div(nchunks, ks);
-      p.part = (float *)((char *)ws + need);
-      rc = launch_f(p, cfg, st);
-      if (rc) return rc;
-      const long total = (long)M * p.NPIX;
-      hipLaunchKernelGGL(ksplit_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float *)p.part, bias,
-                         out, M, p.P, (long)p.NPIX, ks, act, slope);
-      LSPS_CHECK_LAUNCH("ksplit_reduce");
-      return 0;
-    }
-  }
-  return launch_f(p, cfg, st);
+  return launch_f_split(p, choose_cfg(M, p.NPIX), (char *)ws + need, ws_bytes - need, st);
 }
 
 static bool t3x3s2_ok(int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad) {
@@ -640,7 +646,10 @@ static int run_transposed_dir(const float *in, const float *W, const float *bias
       p.act = act;
       p.slope = slope;
       fill_taps(p.taps, l, Ws);
-      rc = launch_f(p, choose_cfg(M, p.NPIX), st);
+      // the partial buffer sits behind the space reserved for all four classes' packed weights
+      const size_t packs = packed_bytes(Cs, R * S, st_ * st_, Cb);
+      rc = packs < ws_bytes ? launch_f_split(p, choose_cfg(M, p.NPIX), (char *)ws + packs, ws_bytes - packs, st)
+                            : launch_f(p, choose_cfg(M, p.NPIX), st);
       if (rc) return rc;
     }
   return 0;
@@ -967,7 +976,7 @@ static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int W
     const int cmax = Cb > Cs ? Cb : Cs;
     if ((long)N * (Hb / 2) * ceil_div(cmax, 128) <= 256) ksp = (size_t)8 * N * cmax * Hb * 32 * sizeof(float) + 512;
   }
-  return 2 * BIAS_WS_BYTES + m + ksp + ((size_t)8 << 20) + 1024;   // + 8 MiB: reduction-split partials of tiny forward problems
+  return 2 * BIAS_WS_BYTES + m + ksp + ((size_t)64 << 20) + 1024;  // + 64 MiB: reduction-split partials of few-tile problems
 }
 
 static bool conv_args_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
