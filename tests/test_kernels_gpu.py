@@ -69,6 +69,8 @@ CONV_CASES = [
     (2, 64, 16, 64, 64, 3, 2, 1),       # stride 2, M = 64: forward generic (needs M >= 128), dgrad on the BM=64 transposed kernel
     (2, 256, 32, 32, 256, 3, 1, 1),     # 3x3 kernel at a small batch: reduction split over blockIdx.z (+ reduce with bias / act)
     (1, 128, 8, 32, 128, 3, 1, 1),      # same, one image, 16 chunks
+    (2, 520, 5, 7, 300, 3, 2, 1),       # generic kernels with the reduction split, ragged everything, both directions
+    (3, 300, 6, 5, 520, 5, 1, 2),       # same, 5x5 stride 1
 ]
 
 
