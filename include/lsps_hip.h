@@ -38,6 +38,15 @@ int         lsps_version(void);
 const char *lsps_last_error(void);
 /* number of compute units of the current device (used by callers to size split counts) */
 int         lsps_device_cus(void);
+
+/* Scope in which packed weight panels are cached in caller-owned device memory: between two optimizer steps the weights
+ * of the reference's modules do not change, yet one update method runs the same nn.Conv2d several times (sub-batches,
+ * forward + backward layouts; lsps_trainer.py:76-262).  Inside begin/end a panel is packed once per (weight pointer,
+ * geometry, tap list); the caller promises not to modify the weights in between, and must call _end (or _begin again)
+ * before doing so.  Process-wide, like the math mode; stream-ordered (the arena is written and read on the streams of
+ * the conv calls).  Without a scope every call packs into its own workspace (stateless, as before). */
+int lsps_pack_cache_begin(void *arena, size_t bytes);
+int lsps_pack_cache_end(void);
 /* Math mode of the MFMA conv kernels (process-wide; direct HBM-bound kernels are f32 always): 0 = exact f32 MFMA (default);
  * 1 = operands rounded to bf16 in registers, v_mfma_f32_32x32x16_bf16 with f32 accumulation (BASELINE config 5:
  * "bf16 with MFMA conv path").  Tensors stay f32 in HBM in both modes.                                  */

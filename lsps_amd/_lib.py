@@ -22,6 +22,8 @@ _SIGNATURES = {
     'lsps_device_cus': (c_int, []),
     'lsps_set_math_mode': (c_int, [c_int]),
     'lsps_get_math_mode': (c_int, []),
+    'lsps_pack_cache_begin': (c_int, [_P, c_size_t]),
+    'lsps_pack_cache_end': (c_int, []),
     'lsps_conv2d_workspace_bytes': (c_size_t, [c_int] * 9),
     'lsps_conv2d_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [c_int, c_float, _P, c_size_t, _P]),
     'lsps_conv2d_dgrad': (c_int, [_P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),

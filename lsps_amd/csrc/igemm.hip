@@ -92,9 +92,54 @@ static size_t class_bytes(int REDp, int Mp) {
   return align_up((size_t)REDp * sizeof(int2), 256) + align_up(((size_t)REDp * Mp + ZERO_SLOT_FLOATS) * sizeof(float), 256);
 }
 
+// Optional cache of packed weight panels in caller-owned memory (lsps_pack_cache_begin / _end).  Between an optimizer
+// step and the next one the weights do not change, but a training step packs the same tensor up to a dozen times
+// (forward passes of several sub-batches, forward- and transposed-direction layouts): inside a begin/end scope a panel
+// is packed once and found again by (weight pointer, geometry, tap list).  The scope is the caller's promise that the
+// weights are not modified; nothing is remembered across scopes.
+struct PackKey {
+  const float *W;
+  int M, Mp, RED, REDp, T, HxWx, Wx, cc;
+  long sm, sc;
+  unsigned taphash;
+};
+struct PackEntry {
+  PackKey key;
+  void *cls;
+};
+static char *g_pc_arena = nullptr;
+static size_t g_pc_bytes = 0, g_pc_used = 0;
+static PackEntry g_pc_tab[512];
+static int g_pc_n = 0;
+
+static bool pack_key_eq(const PackKey &a, const PackKey &b) {
+  return a.W == b.W && a.M == b.M && a.Mp == b.Mp && a.RED == b.RED && a.REDp == b.REDp && a.T == b.T && a.HxWx == b.HxWx &&
+         a.Wx == b.Wx && a.cc == b.cc && a.sm == b.sm && a.sc == b.sc && a.taphash == b.taphash;
+}
+
 static int launch_pack(const float *W, void *cls, int M, int Mp, int RED, int REDp, const TapList &l, long sm, long sc,
                        int HxWx, int Wx, hipStream_t st, const float **Wp_out, const int2 **gtab_out,
                        const float **zero_out, int cc = 0) {
+  if (g_pc_arena && REDp > 0) {
+    PackKey k = {W, M, Mp, RED, REDp, l.T, HxWx, Wx, cc, sm, sc, 2166136261u};
+    for (int i = 0; i < l.T; ++i) k.taphash = (k.taphash ^ (unsigned)(l.idx[i] * 961 + (l.dh[i] + 8) * 31 + (l.dw[i] + 8))) * 16777619u;
+    for (int i = 0; i < g_pc_n; ++i)
+      if (pack_key_eq(g_pc_tab[i].key, k)) {
+        char *c = (char *)g_pc_tab[i].cls;
+        *gtab_out = (const int2 *)c;
+        *Wp_out = (const float *)(c + align_up((size_t)REDp * sizeof(int2), 256));
+        *zero_out = *Wp_out + (size_t)REDp * Mp;
+        return 0;
+      }
+    const size_t need = class_bytes(REDp, Mp);
+    if (g_pc_n < 512 && g_pc_used + need <= g_pc_bytes) {        // miss: pack into the arena and remember it
+      cls = g_pc_arena + g_pc_used;
+      g_pc_used += align_up(need, 256);
+      g_pc_tab[g_pc_n].key = k;
+      g_pc_tab[g_pc_n].cls = cls;
+      ++g_pc_n;
+    }                                                             // arena full: pack into the call's workspace as usual
+  }
   int2 *gtab = (int2 *)cls;
   float *Wp = (float *)((char *)cls + align_up((size_t)REDp * sizeof(int2), 256));
   *Wp_out = Wp;
@@ -1010,6 +1055,22 @@ int lsps_set_math_mode(int mode) {
 }
 
 int lsps_get_math_mode(void) { return lsps::g_math_mode; }
+
+int lsps_pack_cache_begin(void *arena, size_t bytes) {
+  LSPS_CHECK_ARG(arena && bytes >= ((size_t)1 << 20) && (((uintptr_t)arena) & 255) == 0, "pack_cache_begin: need a 256-byte aligned arena of >= 1 MiB");
+  g_pc_arena = (char *)arena;
+  g_pc_bytes = bytes;
+  g_pc_used = 0;
+  g_pc_n = 0;
+  return 0;
+}
+
+int lsps_pack_cache_end(void) {
+  g_pc_arena = nullptr;
+  g_pc_bytes = g_pc_used = 0;
+  g_pc_n = 0;
+  return 0;
+}
 
 int lsps_device_cus(void) {
   int dev = 0, cus = 0;

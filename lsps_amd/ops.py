@@ -603,6 +603,30 @@ def act(x, kind, slope=0.0):
     return _ActFn.apply(x, int(kind), float(slope))
 
 
+# ------------------------------------------------------------------------------------------
+# scoped cache of packed weight panels (lsps_pack_cache_begin / _end)
+# ------------------------------------------------------------------------------------------
+_pack_arenas = {}
+PACK_CACHE_BYTES = 1 << 30          # gen + dis panels in both directions are ~0.4 GB
+
+
+def weight_cache_begin(device):
+    """From here until `weight_cache_end()` the conv weights are promised not to change (one update method of the
+    trainer up to its optimizer step): packed weight panels are built once and reused."""
+    import os
+    if os.environ.get('LSPS_NO_PACK_CACHE') == '1':
+        return
+    key = (device.type, device.index)
+    buf = _pack_arenas.get(key)
+    if buf is None:
+        buf = _pack_arenas[key] = torch.empty(PACK_CACHE_BYTES, dtype=torch.uint8, device=device)
+    _lib.check(_lib.lib().lsps_pack_cache_begin(buf.data_ptr(), buf.numel()), 'pack_cache_begin')
+
+
+def weight_cache_end():
+    _lib.check(_lib.lib().lsps_pack_cache_end(), 'pack_cache_end')
+
+
 def axpy(x, y, alpha=1.0):
     """x + alpha*y (GaussianNoiseLayer: common_net.py:39-40; reparameterisation: lsps_nets.py:78)."""
     return _AxpyFn.apply(x, y, float(alpha))

@@ -39,6 +39,21 @@ def _net(spec):
     return _NETS[name](spec)
 
 
+def _weights_constant(fn):
+    """The conv weights do not change inside an update method until its optimizer step (`_step` ends the scope just
+    before it): packed weight panels are cached for that long (ops.weight_cache_begin)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, images_a, *a, **k):
+        ops.weight_cache_begin(images_a.device)
+        try:
+            return fn(self, images_a, *a, **k)
+        finally:
+            ops.weight_cache_end()
+    return wrapped
+
+
 class LSPSTrainer(nn.Module):
     def __init__(self, hyperparameters):
         super(LSPSTrainer, self).__init__()
@@ -87,8 +102,11 @@ class LSPSTrainer(nn.Module):
             ids = set(id(p) for p in expected_net)
             expected = [i for i, p in enumerate(red.arena.params) if id(p) in ids]
         red.begin(expected)
-        loss.backward()
-        red.finish()
+        try:
+            loss.backward()
+            red.finish()
+        finally:
+            ops.weight_cache_end()          # the optimizer is about to change the weights
         opt.step()
 
     def _publish(self, names, tensors):
@@ -131,6 +149,7 @@ class LSPSTrainer(nn.Module):
         return z, dec_A[:half], dec_B[half:]
 
     # ------------------------------------------------------------------ :76-141
+    @_weights_constant
     def gen_update(self, images_a, labels_a, images_b, labels_b, hyperparameters, noise=(None, None, None)):
         hp = hyperparameters
         self.gen.zero_grad()                                   # one arena: also zeroes the Mapping grads (:85)
@@ -171,6 +190,7 @@ class LSPSTrainer(nn.Module):
         return (x_aa, x_ba, x_ab, x_bb, x_aba, x_bab, decode_A, decode_B)
 
     # ------------------------------------------------------------------ :143-218
+    @_weights_constant
     def dis_update(self, images_a, labels_a, images_b, labels_b, com_a, com_b, hyperparameters, feat_mat=True,
                    noise=None):
         hp = hyperparameters
@@ -220,6 +240,7 @@ class LSPSTrainer(nn.Module):
         return
 
     # ------------------------------------------------------------------ :220-262
+    @_weights_constant
     def post_update(self, images_a, labels_a, images_b, labels_b, com_a, com_b, mode, hyperparameters, noise=None):
         hp = hyperparameters
         noise = noise or {}
