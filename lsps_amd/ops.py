@@ -116,6 +116,28 @@ def convT_out_size(h, r, stride, pad, outpad):
 # ------------------------------------------------------------------------------------------
 # Conv2d (+ fused bias and LeakyReLU/Tanh epilogue)
 # ------------------------------------------------------------------------------------------
+class _EmptyBatchFn(torch.autograd.Function):
+    """Empty batch in -> empty batch out, as torch.nn does (the kernels are never launched on zero samples); the
+    parameter gradients of an empty batch are zeros."""
+
+    @staticmethod
+    def forward(ctx, x, out_shape, *params):
+        ctx.xshape = tuple(x.shape)
+        ctx.pshapes = [None if p is None else tuple(p.shape) for p in params]
+        ctx.dev = x.device
+        return torch.empty(out_shape, dtype=torch.float32, device=x.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = torch.empty(ctx.xshape, dtype=torch.float32, device=ctx.dev)
+        gp = [None if s is None else torch.zeros(s, dtype=torch.float32, device=ctx.dev) for s in ctx.pshapes]
+        return (gx, None) + tuple(gp)
+
+
+def _empty(x, out_shape, *params):
+    return _EmptyBatchFn.apply(x, tuple(out_shape), *params)
+
+
 def _act_backward(L, dy, y, act, slope, want_db, channels, ws, wsb, st):
     """Gradient through the fused output activation of a conv / transposed conv.  When the layer's bias gradient is
     wanted too it comes out of the same pass (db = sum over n, h, w of the pre-activation gradient)."""
@@ -181,6 +203,9 @@ class _Conv2dFn(torch.autograd.Function):
 
 
 def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, slope=LRELU_SLOPE):
+    if x.shape[0] == 0:
+        return _empty(x, (0, w.shape[0], conv_out_size(x.shape[2], w.shape[2], stride, pad),
+                          conv_out_size(x.shape[3], w.shape[3], stride, pad)), w, b)
     return _Conv2dFn.apply(x, w, b, int(stride), int(pad), int(act), float(slope))
 
 
@@ -237,6 +262,9 @@ class _ConvT2dFn(torch.autograd.Function):
 
 
 def conv_transpose2d(x, w, b=None, stride=1, pad=0, outpad=0, act=ACT_NONE, slope=LRELU_SLOPE):
+    if x.shape[0] == 0:
+        return _empty(x, (0, w.shape[1], convT_out_size(x.shape[2], w.shape[2], stride, pad, outpad),
+                          convT_out_size(x.shape[3], w.shape[3], stride, pad, outpad)), w, b)
     return _ConvT2dFn.apply(x, w, b, int(stride), int(pad), int(outpad), int(act), float(slope))
 
 
@@ -352,11 +380,15 @@ class _ResBlockFn(torch.autograd.Function):
 
 def res_block(x, w1, w2):
     """x + IN(conv3x3(LReLU(IN(conv3x3(x, w1))), w2)) — LeakyINSResBlock (common_net.py:160-181), one autograd node."""
+    if x.shape[0] == 0:
+        return _empty(x, x.shape, w1, w2)
     return _ResBlockFn.apply(x, w1, w2)
 
 
 def instance_norm_(y, residual=None, slope=-1.0):
     """In-place fused InstanceNorm: y <- act(IN(y)) (+ residual).  slope < 0: no activation."""
+    if y.numel() == 0:
+        return y
     return _InormFn.apply(y, residual, float(slope))
 
 
@@ -478,6 +510,8 @@ class _LinearFn(torch.autograd.Function):
 
 
 def linear(x, w, b, act=ACT_NONE, slope=LRELU_SLOPE):
+    if x.shape[0] == 0:
+        return _empty(x, (0, w.shape[0]), w, b)
     return _LinearFn.apply(x, w, b, int(act), float(slope))
 
 
@@ -529,6 +563,8 @@ class _MulAddFn(torch.autograd.Function):
 def mul_add(x, t, m):
     """x + t*m: dropout mask (already divided by 1-p) on a residual branch, then the skip connection
     (common_net.py:171-172,180)."""
+    if x.numel() == 0:
+        return x
     return _MulAddFn.apply(x, t, m)
 
 
@@ -574,6 +610,8 @@ class _BnormFn(torch.autograd.Function):
 
 def batch_norm(x, gamma=None, beta=None, run_mean=None, run_var=None, training=True, slope=-1.0, eps=1e-5, momentum=0.1):
     """act(BN(x)); running statistics are updated in place in training mode.  slope < 0: no activation."""
+    if x.shape[0] == 0:
+        return _empty(x, x.shape, gamma, beta)
     return _BnormFn.apply(x, gamma, beta, run_mean, run_var, bool(training), float(slope), float(eps), float(momentum))
 
 
@@ -600,6 +638,8 @@ class _ActFn(torch.autograd.Function):
 
 def act(x, kind, slope=0.0):
     """Standalone activation: nn.ReLU (kind=ACT_LRELU, slope=0; common_net.py:146,361), nn.Softplus, nn.Tanh."""
+    if x.numel() == 0:
+        return x
     return _ActFn.apply(x, int(kind), float(slope))
 
 
@@ -629,4 +669,6 @@ def weight_cache_end():
 
 def axpy(x, y, alpha=1.0):
     """x + alpha*y (GaussianNoiseLayer: common_net.py:39-40; reparameterisation: lsps_nets.py:78)."""
+    if x.numel() == 0:
+        return x
     return _AxpyFn.apply(x, y, float(alpha))

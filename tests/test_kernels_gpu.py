@@ -2,6 +2,8 @@
 fp32 CPU ops — the same torch ops the oracle is made of.  Tolerance: 1e-4 relative to the
 reference tensor's abs-max for forward / dgrad, 2e-4 for weight gradients (long fp32 reductions).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -397,3 +399,37 @@ def test_conv2d_dgrad_acc(case):
     _lib.check(L.lsps_conv2d_dgrad_acc(_lib.ptr(gyd), _lib.ptr(wd), _lib.ptr(addd), _lib.ptr(dx), N, C, H, W, K, R, R, st,
                                        pad, ws, wsb, _lib.stream()), 'dgrad_acc')
     assert _rel(dx, want) < 1e-4
+
+
+def test_empty_batch_behaves_like_torch():
+    """Zero samples in -> zero samples out with the right shape; parameter gradients of an empty batch are zeros (what
+    torch.nn returns); no kernel is launched."""
+    _need_gpu()
+    from lsps_amd import ops
+    import lsps_amd.trainers as tr
+    dev = 'cuda'
+    x0 = torch.zeros(0, 8, 32, 32, device=dev, requires_grad=True)
+    w = torch.randn(16, 8, 3, 3, device=dev, requires_grad=True)
+    b = torch.randn(16, device=dev, requires_grad=True)
+    y = ops.conv2d(x0, w, b, 2, 1, ops.ACT_LRELU, 0.01)
+    assert tuple(y.shape) == (0, 16, 16, 16)
+    y.sum().backward()
+    assert tuple(x0.grad.shape) == (0, 8, 32, 32) and float(w.grad.abs().max()) == 0 and float(b.grad.abs().max()) == 0
+    wt = torch.randn(8, 4, 3, 3, device=dev)
+    assert tuple(ops.conv_transpose2d(x0.detach(), wt, None, 2, 1, 1).shape) == (0, 4, 64, 64)
+    assert tuple(ops.instance_norm_(torch.zeros(0, 8, 4, 4, device=dev), None, 0.01).shape) == (0, 8, 4, 4)
+    assert tuple(ops.linear(torch.zeros(0, 12, device=dev), torch.randn(5, 12, device=dev), torch.randn(5, device=dev)).shape) == (0, 5)
+    blk = tr.LeakyINSResBlock(128, 128).cuda()
+    assert tuple(blk(torch.zeros(0, 128, 32, 32, device=dev)).shape) == (0, 128, 32, 32)
+    hp = __import__('yaml').safe_load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                        'exps', 'nnyu.yaml')))['train']['hyperparameters']
+    from lsps_amd import synth
+    hp = synth.tiny_hyperparameters(hp)
+    gen, dis = tr.SharedResGen(hp['gen']).cuda().eval(), tr.SharedDis(hp['dis']).cuda().eval()
+    e = torch.zeros(0, 1, 128, 128, device=dev)
+    with torch.no_grad():
+        za, zb = gen.encode(e, e)               # (gen.forward itself splits by x_A.size(0) == 0: an error in the reference too)
+        assert za.shape[0] == 0 and zb.shape[0] == 0
+        oa, ob = gen.decode(za)
+        assert tuple(oa.shape) == (0, 1, 128, 128) and tuple(ob.shape) == (0, 1, 128, 128)
+        assert dis.model_S(dis.model_A(e)).shape[0] == 0
