@@ -758,5 +758,141 @@ __global__ __launch_bounds__(256, 2) void igemm_w3x3_kernel(W3Params p) {
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// bf16 MFMA weight-gradient kernel of the 3x3 / stride-1 / width-32 layers (math mode 1).  Same tiling as
+// igemm_w3x3_kernel (64 m x 64 c x 9 taps per workgroup, 64-pixel chunks, 9 accumulators per wave), but dy and the
+// input rows are rounded to bf16 when they are staged and stored pixel-contiguous, so a K = 16 operand (16 consecutive
+// pixels: lanes 0-31 pixels 0-7, lanes 32-63 pixels 8-15) is ONE aligned ds_read_b128.  The column taps s = 0 / 2 need
+// the same 8 pixels shifted by one: they are built from the aligned vector and one neighbouring dword with
+// v_alignbyte (8 VALU per row) instead of re-reading LDS — the register-conversion variant read 80 dwords per group and
+// was LDS-bound at 560 TFLOP/s.
+// -------------------------------------------------------------------------------------------
+#define WB_LDA 72                 // bf16 elements per dy row: 64 pixels + 8 pad (144 B: 8 lanes cover all banks)
+#define WB_ROW 48                 // one input row: 8 zero pad | 32 pixels | 8 zero pad
+#define WB_CH (4 * WB_ROW + 8)    // 200 bf16 per channel (400 B)
+
+__global__ __launch_bounds__(256, 2) void igemm_w3x3_bf16_kernel(W3Params p) {
+  __shared__ __attribute__((aligned(16))) unsigned short lds[64 * WB_LDA + 64 * WB_CH];
+  unsigned short *Aq = lds, *Bq = lds + 64 * WB_LDA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int c0, m0, split;                                                // XCD-aware mapping as in igemm_w3x3_kernel
+  {
+    const int tiles = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    int t;
+    if ((gridDim.z & 7) == 0) {
+      const int xcd = lin & 7, q = lin >> 3;
+      t = q % tiles;
+      split = (q / tiles) * 8 + xcd;
+    } else {
+      t = lin % tiles;
+      split = lin / tiles;
+    }
+    c0 = (t % gridDim.x) * 64;
+    m0 = (t / gridDim.x) * 64;
+  }
+  const int HW = p.H * 32, rows2 = p.H / 2;
+  const int ch_begin = split * p.chunks_per_split;
+  int ch_end = ch_begin + p.chunks_per_split;
+  if (ch_end > p.nchunks) ch_end = p.nchunks;
+
+  // the zero pads left and right of every staged input row are written once
+  for (int u = tid; u < 64 * 4 * 16; u += 256) {
+    const int line = u >> 4, e = u & 15;                            // line = channel * 4 + row
+    Bq[(line >> 2) * WB_CH + (line & 3) * WB_ROW + (e < 8 ? e : 32 + e)] = 0;
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  f32x4 areg[4], breg[8];
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const unsigned short *Ap = Aq + (wm * 32 + l31) * WB_LDA + 8 * half;
+  const unsigned short *Bp = Bq + (wn * 32 + l31) * WB_CH + 8 + 8 * half;     // + 8: skip the left pad
+
+  for (int ch = ch_begin - 1; ch < ch_end; ++ch) {
+    if (ch >= ch_begin) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int u = tid + 256 * i;
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (__bf16)areg[i][e];
+        *reinterpret_cast<bf16x4 *>(Aq + (u >> 4) * WB_LDA + (u & 15) * 4) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int u = tid + 256 * i;
+        const int line = u >> 3;
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (__bf16)breg[i][e];
+        *reinterpret_cast<bf16x4 *>(Bq + (line >> 2) * WB_CH + (line & 3) * WB_ROW + 8 + (u & 7) * 4) = v;
+      }
+      __syncthreads();
+    }
+    if (ch + 1 < ch_end) {
+      const int nc = ch + 1;
+      const int n = nc / rows2, y0 = (nc - n * rows2) * 2;
+      const float *dyb = p.DY + ((long)n * p.M + m0) * HW + y0 * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int u = tid + 256 * i;
+        areg[i] = *reinterpret_cast<const f32x4 *>(dyb + (long)(u >> 4) * HW + (u & 15) * 4);
+      }
+      const float *xb = p.X + ((long)n * p.C + c0) * HW;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int u = tid + 256 * i;
+        const int line = u >> 3;
+        const int img_row = y0 - 1 + (line & 3);
+        const bool ok = img_row >= 0 && img_row < p.H;
+        const float *src = ok ? (xb + (long)(line >> 2) * HW + img_row * 32 + (u & 7) * 4) : p.zero;
+        breg[i] = *reinterpret_cast<const f32x4 *>(src);
+      }
+    }
+    if (ch >= ch_begin) {
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {                 // 4 groups of 16 pixels: (row 0 / 1) x (columns 0-15 / 16-31)
+        const int row = q >> 1, col = (q & 1) * 16;
+        const bf16x8 af = *reinterpret_cast<const bf16x8 *>(Ap + row * 32 + col);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const unsigned short *bp = Bp + (row + r) * WB_ROW + col;
+          const u32x4 cur = *reinterpret_cast<const u32x4 *>(bp);
+          const unsigned prev = *reinterpret_cast<const unsigned *>(bp - 2);     // pixels -2, -1 of this lane's 8
+          const unsigned next = *reinterpret_cast<const unsigned *>(bp + 8);     // pixels +8, +9
+          u32x4 lft, rgt;                                                       // the 8 pixels shifted by -1 / +1
+          lft[0] = __builtin_amdgcn_alignbyte(cur[0], prev, 2);
+          lft[1] = __builtin_amdgcn_alignbyte(cur[1], cur[0], 2);
+          lft[2] = __builtin_amdgcn_alignbyte(cur[2], cur[1], 2);
+          lft[3] = __builtin_amdgcn_alignbyte(cur[3], cur[2], 2);
+          rgt[0] = __builtin_amdgcn_alignbyte(cur[1], cur[0], 2);
+          rgt[1] = __builtin_amdgcn_alignbyte(cur[2], cur[1], 2);
+          rgt[2] = __builtin_amdgcn_alignbyte(cur[3], cur[2], 2);
+          rgt[3] = __builtin_amdgcn_alignbyte(next, cur[3], 2);
+          acc[3 * r + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, lft), acc[3 * r + 0], 0, 0, 0);
+          acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, cur), acc[3 * r + 1], 0, 0, 0);
+          acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, rgt), acc[3 * r + 2], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const int c = c0 + wn * 32 + l31;
+  float *out = p.part + (long)split * p.M * p.C * 9 + (long)c * 9;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) out[(long)m * p.C * 9 + t] = acc[t][r];
+  }
+}
+
 }  // namespace lsps
 #endif

@@ -760,7 +760,7 @@ static int run_w3x3(const float *dy, const float *x, float *dW, int N, int C, in
   p.zero = zero;
   p.part = (float *)((char *)ws + 256);
   if (g_math_mode == 1)
-    hipLaunchKernelGGL(igemm_w3x3_kernel<1>, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(igemm_w3x3_bf16_kernel, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
   else if (g_math_mode == 2)
     hipLaunchKernelGGL(igemm_w3x3_kernel<2>, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
   else
