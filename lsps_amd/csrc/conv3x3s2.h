@@ -395,6 +395,166 @@ __global__ __launch_bounds__(256, 2) void igemm_t3x3s2_kernel(TS2Params p) {
 }
 
 // -------------------------------------------------------------------------------------------
+// bf16 MFMA variant of the transposed-direction stride-2 kernel (math mode 1) with K-contiguous operands, like
+// igemm_f3x3_bf16_kernel: weights packed once per call by pack_bf16_kernel ([128-row m tile][16-channel chunk][9 taps]
+// [128 m][16 c]), input rows rounded to bf16 when staged and stored [row][column][16 c]; one ds_read_b128 per operand
+// fragment, one MFMA (K = the chunk's 16 channels) per tap and tile pair.  Same tiling / classes / epilogue as
+// ts2_body.  (The f32 body's in-register conversion ran at 185 TFLOP/s.)
+// -------------------------------------------------------------------------------------------
+struct TS2BParams {
+  const float *X, *bias, *zero;
+  const unsigned short *Wq;
+  float *Y;
+  int Cx, Hs, Ws, M;
+  int qblocks, tiles_per_img;
+  int act;
+  float slope;
+};
+
+template <int APAR, int BM>
+__device__ __forceinline__ void ts2_bf16_body(const TS2BParams &p, unsigned short *lds) {
+  constexpr int NT = APAR ? 6 : 3;
+  constexpr int WAVES_M = BM / 64, WAVES_N = 4 / WAVES_M, TR = 2 * WAVES_N;
+  constexpr int ROWS = TR + 1;
+  constexpr int AEL = NT * BM * FB_CC;                       // bf16 elements of this class's weight taps
+  constexpr int A16 = (AEL / 8 + 255) / 256;                 // 16-byte units per thread per chunk (6 / 3 / 3 / 2)
+  constexpr int NPIX = ROWS * 33;                            // staged pixels (33 columns: the right neighbour too)
+  constexpr int BP = (NPIX + 255) / 256;
+  unsigned short *Aq = lds, *Bq = lds + AEL;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = blockIdx.y;                                 // BM-row tile; lives in 128-row tile mt*BM/128 of the pack
+  const int m0 = mt * BM;
+  const int n = blockIdx.x / p.tiles_per_img;
+  const int rem = blockIdx.x - n * p.tiles_per_img;
+  const int p0 = (rem / p.qblocks) * TR, q0 = (rem - (rem / p.qblocks) * p.qblocks) * 32;
+  const int HWs = p.Hs * p.Ws;
+  const float *xn = p.X + (long)n * p.Cx * HWs;
+  const int nchunks = p.Cx / FB_CC;
+
+  bool b_use[BP], b_ok[BP];
+  int b_lds[BP], b_off[BP];
+#pragma unroll
+  for (int q = 0; q < BP; ++q) {
+    const int u = tid + 256 * q;
+    b_use[q] = u < NPIX;
+    const int r = u / 33, col = u - r * 33;
+    b_ok[q] = b_use[q] && (p0 + r) < p.Hs && (q0 + col) < p.Ws;
+    b_lds[q] = (r * 34 + col) * FB_CC;
+    b_off[q] = (p0 + r) * p.Ws + q0 + col;
+  }
+
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][c][r] = 0.f;
+
+  f32x4 areg[A16];
+  float breg[BP][FB_CC];
+  const int wm = WAVES_M == 2 ? (wave >> 1) : 0, wn = WAVES_M == 2 ? (wave & 1) : wave;
+  const int l31 = lane & 31, half = lane >> 5;
+  // this class's taps inside a packed chunk: taps 3..5 (a = 0) or 0..2 and 6..8 (a = 1); rows m0 % 128 .. + BM
+  const unsigned short *wq = p.Wq + (long)(m0 / 128) * nchunks * FB_ACH + (long)(m0 % 128) * FB_CC;
+
+  for (int ch = -1; ch < nchunks; ++ch) {
+    if (ch >= 0) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < A16; ++i)
+        if ((tid + 256 * i) * 8 < AEL) *reinterpret_cast<f32x4 *>(Aq + (tid + 256 * i) * 8) = areg[i];
+#pragma unroll
+      for (int q = 0; q < BP; ++q)
+        if (b_use[q]) {
+#pragma unroll
+          for (int h8 = 0; h8 < 2; ++h8) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)breg[q][h8 * 8 + e];
+            *reinterpret_cast<bf16x8 *>(Bq + b_lds[q] + h8 * 8) = v;
+          }
+        }
+      __syncthreads();
+    }
+    if (ch + 1 < nchunks) {
+      const unsigned short *src = wq + (long)(ch + 1) * FB_ACH;
+#pragma unroll
+      for (int i = 0; i < A16; ++i) {
+        int u8 = (tid + 256 * i) * 8;                        // element index inside [NT][BM][16]
+        if (u8 >= AEL) u8 = 0;                               // (odd thread counts: the surplus lanes re-read element 0)
+        const int lt = u8 / (BM * FB_CC), rest = u8 - lt * (BM * FB_CC);
+        const int t = APAR ? (lt < 3 ? lt : lt + 3) : lt + 3;
+        areg[i] = *reinterpret_cast<const f32x4 *>(src + (long)t * 128 * FB_CC + rest);
+      }
+      const float *xc = xn + (long)(ch + 1) * FB_CC * HWs;
+#pragma unroll
+      for (int q = 0; q < BP; ++q)
+#pragma unroll
+        for (int e = 0; e < FB_CC; ++e) {
+          const float *s2 = b_ok[q] ? (xc + (long)e * HWs + b_off[q]) : p.zero;
+          breg[q][e] = *s2;
+        }
+    }
+    if (ch >= 0) {
+#pragma unroll
+      for (int lt = 0; lt < NT; ++lt) {
+        const int s = lt % 3;
+        const int dh = (APAR && lt < 3) ? 1 : 0;
+        const int dw = s == 0 ? 1 : 0, cls = s == 1 ? 0 : 1;
+        bf16x8 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          af[i] = *reinterpret_cast<const bf16x8 *>(Aq + ((lt * BM) + wm * 64 + i * 32 + l31) * FB_CC + 8 * half);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bf[j] = *reinterpret_cast<const bf16x8 *>(Bq + ((wn * 2 + j + dh) * 34 + l31 + dw) * FB_CC + 8 * half);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j][cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j][cls], 0, 0, 0);
+      }
+    }
+  }
+
+  const int Wb = 2 * p.Ws;
+  const long HWb = 4L * HWs;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int orow = 2 * (p0 + wn * 2 + j) + APAR;
+    float *yb = p.Y + (long)n * p.M * HWb + (long)orow * Wb + 2 * (q0 + l31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < p.M) {
+          const float bv = p.bias ? p.bias[m] : 0.f;
+          f32x2 o;
+          o[0] = apply_act(acc[i][j][0][r] + bv, p.act, p.slope);
+          o[1] = apply_act(acc[i][j][1][r] + bv, p.act, p.slope);
+          *reinterpret_cast<f32x2 *>(yb + (long)m * HWb) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int BM>
+__global__ __launch_bounds__(256, 2) void igemm_t3x3s2_bf16_kernel(TS2BParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned short lds[6 * BM * FB_CC + (BM == 128 ? 5 : 9) * 34 * FB_CC];
+  if (blockIdx.z == 0)
+    ts2_bf16_body<0, BM>(p, lds);
+  else
+    ts2_bf16_body<1, BM>(p, lds);
+}
+
+// -------------------------------------------------------------------------------------------
 // W kernel specialised for 3x3 / STRIDE 2 / pad 1 (the down-sampling convs and the up-sampling transposed convs:
 // "small" image [N][M][Hs][Ws], "big" image [N][C][2Hs][2Ws], Ws % 32 == 0):
 //   dW[m][c][r][s] = sum_{n,p,q} small[n][m][p][q] * big[n][c][2p + r - 1][2q + s - 1]

@@ -577,6 +577,49 @@ static int run_t3x3s2(const float *in, const float *W, const float *bias, float 
   }
   const int RED = Cs * 9;
   const int Mp = (int)align_up(M, 128);
+  if (g_math_mode == 1 && M >= 128) {        // bf16 mode, 128-channel tiles: K-contiguous bf16 operands (Cs % 16 == 0 by
+                                             // t3x3s2_ok); the 64-channel variant spills and stays on the in-register conversion
+    const size_t wq_bytes = (size_t)(Mp / 128) * (Cs / FB_CC) * FB_ACH * sizeof(unsigned short);
+    if (256 + wq_bytes > ws_bytes) {
+      set_error("conv workspace too small: need %zu, have %zu", 256 + wq_bytes, ws_bytes);
+      return LSPS_E_WS;
+    }
+    hipError_t e = hipMemsetAsync(ws, 0, 256, st);
+    if (e != hipSuccess) {
+      set_error("hipMemsetAsync: %s", hipGetErrorString(e));
+      return LSPS_E_HIP;
+    }
+    FSPack pk;
+    pk.W = W;
+    pk.Wq = (unsigned short *)((char *)ws + 256);
+    pk.M = M;
+    pk.C = Cs;
+    pk.np = 1;
+    pk.sm = sm;
+    pk.sc = sc;
+    for (int t = 0; t < 9; ++t) pk.tapidx[t] = t;
+    const long total = (long)(Mp / 128) * (Cs / FB_CC) * FB_ACH;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, pk);
+    LSPS_CHECK_LAUNCH("pack_bf16");
+    TS2BParams q;
+    memset(&q, 0, sizeof(q));
+    q.X = in;
+    q.bias = bias;
+    q.zero = (const float *)ws;
+    q.Wq = pk.Wq;
+    q.Y = out;
+    q.Cx = Cs;
+    q.Hs = Hs;
+    q.Ws = Ws;
+    q.M = M;
+    q.qblocks = Ws / 32;
+    q.act = act;
+    q.slope = slope;
+    q.tiles_per_img = (Hs / 4) * q.qblocks;
+    hipLaunchKernelGGL(igemm_t3x3s2_bf16_kernel<128>, dim3(N * q.tiles_per_img, ceil_div(M, 128), 2), dim3(256), 0, st, q);
+    LSPS_CHECK_LAUNCH("igemm_t3x3s2_bf16");
+    return 0;
+  }
   const size_t need = class_bytes(RED, Mp);
   if (need > ws_bytes) {
     set_error("conv workspace too small: need %zu, have %zu", need, ws_bytes);
