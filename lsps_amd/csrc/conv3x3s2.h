@@ -555,6 +555,128 @@ __global__ __launch_bounds__(256, 2) void igemm_t3x3s2_bf16_kernel(TS2BParams p)
 }
 
 // -------------------------------------------------------------------------------------------
+// bf16 MFMA variant of the forward-direction stride-2 kernel (math mode 1), K-contiguous operands as in
+// igemm_f3x3_bf16_kernel: packed bf16 weights [m tile][16-channel chunk][9 taps][128 m][16 c]; the 9 input rows of the
+// tile are rounded to bf16 when staged and stored [row][O'(33) | E(32)][16 c] (column-parity de-interleaved like the f32
+// kernel), one ds_read_b128 per fragment, one MFMA per tap and tile pair.
+// -------------------------------------------------------------------------------------------
+#define FS2B_ROW 66                                    // pixels per staged row: O'[0..32], E[33..64], one pad
+
+__global__ __launch_bounds__(256, 2) void igemm_f3x3s2_bf16_kernel(TS2BParams p) {
+  // TS2BParams reused: Hs / Ws are the OUTPUT (small) image here, the input is [2 Hs][2 Ws]
+  constexpr int A16 = FB_ACH / 8 / 256;                              // 9
+  constexpr int NPIX = FS2_ROWS * 65;                                // 585 staged pixels
+  constexpr int BP = (NPIX + 255) / 256;                             // 3
+  __shared__ __attribute__((aligned(16))) unsigned short lds[FB_ACH + FS2_ROWS * FS2B_ROW * FB_CC];
+  unsigned short *Aq = lds, *Bq = lds + FB_ACH;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = blockIdx.y, m0 = mt * 128;
+  const int n = blockIdx.x / p.tiles_per_img;
+  const int rem = blockIdx.x - n * p.tiles_per_img;
+  const int p0 = (rem / p.qblocks) * 4, q0 = (rem - (rem / p.qblocks) * p.qblocks) * 32;
+  const int Hx = 2 * p.Hs, Wx = 2 * p.Ws, HWx = Hx * Wx;
+  const float *xn = p.X + (long)n * p.Cx * HWx;
+  const int nchunks = p.Cx / FB_CC;
+
+  bool b_use[BP], b_ok[BP];
+  int b_lds[BP], b_off[BP];
+#pragma unroll
+  for (int q = 0; q < BP; ++q) {
+    const int u = tid + 256 * q;
+    b_use[q] = u < NPIX;
+    const int r = u / 65, x = u - r * 65;                           // x: input column 2 q0 - 1 + x
+    const int ih = 2 * p0 - 1 + r, iw = 2 * q0 - 1 + x;
+    b_ok[q] = b_use[q] && ih >= 0 && iw >= 0;                       // ih < 2P, iw < 2Q always
+    // odd input columns (x even) -> O'[x / 2], even input columns (x odd) -> E[(x - 1) / 2] at 33 + ...
+    b_lds[q] = (r * FS2B_ROW + ((x & 1) ? 33 + (x >> 1) : (x >> 1))) * FB_CC;
+    b_off[q] = ih * Wx + iw;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 areg[A16];
+  float breg[BP][FB_CC];
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const unsigned short *wq = p.Wq + (long)mt * nchunks * FB_ACH;
+
+  for (int ch = -1; ch < nchunks; ++ch) {
+    if (ch >= 0) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < A16; ++i) *reinterpret_cast<f32x4 *>(Aq + (tid + 256 * i) * 8) = areg[i];
+#pragma unroll
+      for (int q = 0; q < BP; ++q)
+        if (b_use[q]) {
+#pragma unroll
+          for (int h8 = 0; h8 < 2; ++h8) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)breg[q][h8 * 8 + e];
+            *reinterpret_cast<bf16x8 *>(Bq + b_lds[q] + h8 * 8) = v;
+          }
+        }
+      __syncthreads();
+    }
+    if (ch + 1 < nchunks) {
+      const unsigned short *src = wq + (long)(ch + 1) * FB_ACH;
+#pragma unroll
+      for (int i = 0; i < A16; ++i) areg[i] = *reinterpret_cast<const f32x4 *>(src + (tid + 256 * i) * 8);
+      const float *xc = xn + (long)(ch + 1) * FB_CC * HWx;
+#pragma unroll
+      for (int q = 0; q < BP; ++q)
+#pragma unroll
+        for (int e = 0; e < FB_CC; ++e) {
+          const float *s2 = b_ok[q] ? (xc + (long)e * HWx + b_off[q]) : p.zero;
+          breg[q][e] = *s2;
+        }
+    }
+    if (ch >= 0) {
+#pragma unroll 3
+      for (int t = 0; t < 9; ++t) {
+        const int tr = t / 3, ts = t - tr * 3;
+        const int coff = ts == 1 ? 33 : (ts == 2 ? 1 : 0);
+        bf16x8 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(Aq + (t * 128 + wm * 64 + i * 32 + l31) * FB_CC + 8 * half);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bf[j] = *reinterpret_cast<const bf16x8 *>(Bq + ((2 * (wn * 2 + j) + tr) * FS2B_ROW + coff + l31) * FB_CC + 8 * half);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  const long PQ = (long)p.Hs * p.Ws;
+  float *y0 = p.Y + (long)n * p.M * PQ + (long)(p0 + wn * 2) * p.Ws + q0 + l31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m < p.M) {
+        const float bv = p.bias ? p.bias[m] : 0.f;
+        float *ym = y0 + (long)m * PQ;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ym[(long)j * p.Ws] = apply_act(acc[i][j][r] + bv, p.act, p.slope);
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
 // W kernel specialised for 3x3 / STRIDE 2 / pad 1 (the down-sampling convs and the up-sampling transposed convs:
 // "small" image [N][M][Hs][Ws], "big" image [N][C][2Hs][2Ws], Ws % 32 == 0):
 //   dW[m][c][r][s] = sum_{n,p,q} small[n][m][p][q] * big[n][c][2p + r - 1][2q + s - 1]

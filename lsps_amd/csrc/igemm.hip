@@ -422,6 +422,49 @@ static int run_f3x3s2(const float *in, const float *W, const float *bias, float 
     l.dw[t] = 0;
     l.idx[t] = t;
   }
+  if (g_math_mode == 1 && (Cb % FB_CC) == 0) {       // bf16 mode: K-contiguous bf16 operands
+    const int Mp2 = (int)align_up(M, 128);
+    const size_t wq_bytes = (size_t)(Mp2 / 128) * (Cb / FB_CC) * FB_ACH * sizeof(unsigned short);
+    if (256 + wq_bytes > ws_bytes) {
+      set_error("conv workspace too small: need %zu, have %zu", 256 + wq_bytes, ws_bytes);
+      return LSPS_E_WS;
+    }
+    hipError_t e = hipMemsetAsync(ws, 0, 256, st);
+    if (e != hipSuccess) {
+      set_error("hipMemsetAsync: %s", hipGetErrorString(e));
+      return LSPS_E_HIP;
+    }
+    FSPack pk;
+    pk.W = W;
+    pk.Wq = (unsigned short *)((char *)ws + 256);
+    pk.M = M;
+    pk.C = Cb;
+    pk.np = 1;
+    pk.sm = sm;
+    pk.sc = sc;
+    for (int t = 0; t < 9; ++t) pk.tapidx[t] = t;
+    const long total = (long)(Mp2 / 128) * (Cb / FB_CC) * FB_ACH;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, pk);
+    LSPS_CHECK_LAUNCH("pack_bf16");
+    TS2BParams q;
+    memset(&q, 0, sizeof(q));
+    q.X = in;
+    q.bias = bias;
+    q.zero = (const float *)ws;
+    q.Wq = pk.Wq;
+    q.Y = out;
+    q.Cx = Cb;
+    q.Hs = Hs;
+    q.Ws = Ws;
+    q.M = M;
+    q.qblocks = Ws / 32;
+    q.tiles_per_img = (Hs / 4) * q.qblocks;
+    q.act = act;
+    q.slope = slope;
+    hipLaunchKernelGGL(igemm_f3x3s2_bf16_kernel, dim3(N * q.tiles_per_img, Mp2 / 128), dim3(256), 0, st, q);
+    LSPS_CHECK_LAUNCH("igemm_f3x3s2_bf16");
+    return 0;
+  }
   const int RED = Cb * 9;
   const int Mp = (int)align_up(M, 128);
   const size_t need = class_bytes(RED, Mp);
