@@ -78,8 +78,8 @@ def cpu_baseline(hp, target_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=128, help='samples per domain per GPU')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="'bf16': bf16 MFMA operands (f32 accumulate) in the 3x3 residual-conv kernels (BASELINE config 5)")
