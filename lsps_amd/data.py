@@ -172,16 +172,27 @@ def plan_augmentation(cam, gt3Dcrop, com, cube, M, aug_modes, rng, dsize=(128, 1
             prm[7:13] = _cv_rotation_inverse((W // 2, H // 2), -rot)
             com3D = cam.to_3d(com)
             alpha = rot * np.pi / 180.
-            joints = np.zeros_like(gt3Dcrop)
-            for k in range(gt3Dcrop.shape[0]):
-                p = cam.to_img(gt3Dcrop[k] + com3D)
-                p[0:2] -= com[0:2]
-                r = np.zeros_like(p)
-                r[0] = p[0] * np.cos(alpha) - p[1] * np.sin(alpha)
-                r[1] = p[0] * np.sin(alpha) + p[1] * np.cos(alpha)
-                r[2] = p[2]
-                r[0:2] += com[0:2]
-                joints[k] = cam.to_3d(r)
+            # all joints at once; every elementwise step has the operand types of the per-joint reference code
+            # (float32 arrays with python-float intrinsics stay float32; products with the float64 cos / sin are float64
+            # and round once when stored), so the result is bit-identical to the joint-by-joint loop
+            q = (gt3Dcrop + com3D).astype(np.float32)
+            pj = np.zeros_like(q)
+            zero = q[:, 2] == 0.
+            qz = np.where(zero, np.float32(1), q[:, 2])
+            pj[:, 0] = q[:, 0] / qz * cam.fx + cam.ux
+            pj[:, 1] = (cam.uy - q[:, 1] / qz * cam.fy) if cam.flip_y else (q[:, 1] / qz * cam.fy + cam.uy)
+            pj[:, 2] = q[:, 2]
+            pj[zero, 0], pj[zero, 1], pj[zero, 2] = cam.ux, cam.uy, 0.
+            pj[:, 0:2] -= com[0:2]
+            rj = np.zeros_like(pj)
+            rj[:, 0] = pj[:, 0] * np.cos(alpha) - pj[:, 1] * np.sin(alpha)
+            rj[:, 1] = pj[:, 0] * np.sin(alpha) + pj[:, 1] * np.cos(alpha)
+            rj[:, 2] = pj[:, 2]
+            rj[:, 0:2] += com[0:2]
+            joints = np.zeros_like(rj)
+            joints[:, 0] = (rj[:, 0] - cam.ux) * rj[:, 2] / cam.fx
+            joints[:, 1] = ((cam.uy - rj[:, 1]) if cam.flip_y else (rj[:, 1] - cam.uy)) * rj[:, 2] / cam.fy
+            joints[:, 2] = rj[:, 2]
             joints = joints - com3D
     elif name == 'sc':                                            # HandDetector.scaleHand (handdetector.py:755-784)
         rot = 0.

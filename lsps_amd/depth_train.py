@@ -29,13 +29,35 @@ class NetConfig(object):
                     setattr(self, k, v)
 
 
-def synthetic_loader(batch_size, label_dim, device, seed, to_tensor):
-    """Endless stream of seeded NYU-shape batches (stands in for get_data_loader, common.py:16-17)."""
+def synthetic_loader(batch_size, label_dim, device, seed, to_tensor, augment=False):
+    """Endless stream of seeded NYU-shape batches (stands in for get_data_loader, common.py:16-17).
+    `augment`: run the reference's per-sample augmentation (dataset_hand2.py:331-364, modes none / com / rot) on every
+    batch — geometry planned on the host in the dataset's RNG order, pixels warped on the GPU in one launch
+    (lsps_amd/data.py)."""
     from . import synth
+    pipe = cam = rng = None
+    if augment:
+        from . import data as ldata
+        pipe = ldata.CropPipeline(device)
+        cam = ldata.NYU_CAMERA if label_dim == 108 else ldata.ICVL_CAMERA
+        cube = np.full((3,), 300.0 if label_dim == 108 else 250.0, np.float32)
+        rng = np.random.RandomState(seed)                                                # dataset_hand2.py:264
     i = 0
     while True:
         x, l, c = synth.make_batch(batch_size, seed + 7919 * i, label_dim)
-        yield to_tensor(x, device), to_tensor(l, device), to_tensor(c, device)
+        if augment:
+            plans = []
+            for k in range(batch_size):
+                com2d = cam.to_img(c[k])
+                M = np.asarray(ldata.crop_transform(cam, com2d, cube, (x.shape[3], x.shape[2])), 'float32')
+                plans.append(ldata.plan_augmentation(cam, l[k].reshape(-1, 3) * (cube[2] / 2.), com2d, cube, M,
+                                                     list(ldata.DEFAULT_AUG_MODES), rng, (x.shape[3], x.shape[2])))
+            xt = pipe.augment(to_tensor(x, device), plans)
+            l = np.stack([p.label.reshape(-1) for p in plans])
+            c = np.stack([p.com3D for p in plans])
+            yield xt, to_tensor(l, device), to_tensor(c, device)
+        else:
+            yield to_tensor(x, device), to_tensor(l, device), to_tensor(c, device)
         i += 1
 
 
@@ -99,8 +121,9 @@ def run(opts, trainer_factory=None, loader_a=None, loader_b=None, test_batches=N
         seed_shift = 0
     label_dim = hp['vae']['input_dim']
     seed = config.datasets['train_a']['seed'] if hasattr(config, 'datasets') else 23455
-    loader_a = loader_a or synthetic_loader(batch_size, label_dim, device, seed + seed_shift, to_tensor)
-    loader_b = loader_b or synthetic_loader(batch_size, label_dim, device, seed + 1 + seed_shift, to_tensor)
+    aug = bool(getattr(opts, 'augment', False)) and trainer_factory is None
+    loader_a = loader_a or synthetic_loader(batch_size, label_dim, device, seed + seed_shift, to_tensor, aug)
+    loader_b = loader_b or synthetic_loader(batch_size, label_dim, device, seed + 1 + seed_shift, to_tensor, aug)
     os.makedirs(os.path.dirname(config.snapshot_prefix) or '.', exist_ok=True)
     if opts.log:
         os.makedirs(opts.log, exist_ok=True)
@@ -156,6 +179,7 @@ def build_parser():
     p.add_argument('--batch_size', type=int, default=0, help="override (reference: 1 in pretrain, YAML in estimate)")
     p.add_argument('--iterations', type=int, default=0, help="stop after this many iterations (default: YAML max_iterations)")
     p.add_argument('--data', type=str, default='synthetic', choices=['synthetic'])
+    p.add_argument('--augment', action='store_true', help="augment every batch as the datasets do (geometry on the host, pixels on the GPU)")
     return p
 
 

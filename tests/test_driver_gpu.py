@@ -89,3 +89,19 @@ def test_pose_train_stage1_save_load(tmp_path):
     # the read-out of the reloaded VAE is the same number
     m2, x2 = pose_train.reconstruction_error(fresh, tb)
     assert abs(m2 - readouts[0][1]) < 1e-4 and abs(x2 - readouts[0][2]) < 1e-3
+
+
+def test_pretrain_with_gpu_augmentation(tmp_path):
+    """`--augment`: every synthetic batch goes through plan_augmentation (host) + lsps_crop_augment (GPU) before the
+    trainer sees it; images stay in [-1, 1] with a +1 background, labels follow the augmentation, training runs."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    cfgp = _config(tmp_path, display=2, snapshot_save_iterations=1000, image_save_iterations=1000)
+    P = depth_train.build_parser().parse_args
+    dev = torch.device('cuda', 0)
+    plain = next(depth_train.synthetic_loader(8, 108, dev, 5, lambda a, d: torch.as_tensor(a).to(d)))
+    aug = next(depth_train.synthetic_loader(8, 108, dev, 5, lambda a, d: torch.as_tensor(a).to(d), augment=True))
+    assert aug[0].shape == plain[0].shape and float(aug[0].max()) == 1.0 and float(aug[0].min()) >= -1.0
+    assert not torch.equal(aug[0], plain[0]) and not torch.equal(aug[1], plain[1])
+    tr, hist = depth_train.run(P(['--config', cfgp, '--mode', 'pretrain', '--batch_size', '4', '--iterations', '4', '--augment']))
+    assert len(hist) == 2 and all(np.isfinite(v) for v in hist[-1].values())
