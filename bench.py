@@ -26,17 +26,17 @@ F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 
 
-def load_hp():
+def load_hp(exp='nnyu'):
     import yaml
-    with open(os.path.join(REPO, 'exps', 'nnyu.yaml')) as f:
+    with open(os.path.join(REPO, 'exps', exp + '.yaml')) as f:
         return yaml.safe_load(f)['train']['hyperparameters']
 
 
-def make_device_batch(n, device, seed_offset=0):
+def make_device_batch(n, device, seed_offset=0, label_dim=108):
     import torch
     from lsps_amd import synth
-    xa, la, ca = synth.make_batch(n, synth.YAML_SEED + 10 * seed_offset)
-    xb, lb, cb = synth.make_batch(n, synth.YAML_SEED + 10 * seed_offset + 1)
+    xa, la, ca = synth.make_batch(n, synth.YAML_SEED + 10 * seed_offset, label_dim)
+    xb, lb, cb = synth.make_batch(n, synth.YAML_SEED + 10 * seed_offset + 1, label_dim)
     t = lambda a: torch.as_tensor(a).to(device)   # noqa: E731
     return dict(xa=t(xa), la=t(la), ca=t(ca), xb=t(xb), lb=t(lb), cb=t(cb))
 
@@ -83,6 +83,8 @@ def main():
     ap.add_argument('--batch', type=int, default=128, help='samples per domain per GPU')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="'bf16': bf16 MFMA operands (f32 accumulate) in the 3x3 residual-conv kernels (BASELINE config 5)")
+    ap.add_argument('--exp', default='nnyu', choices=['nnyu', 'nicvl'],
+                    help="exps/<exp>.yaml: 'nicvl' with --dtype bf16 --batch 256 is BASELINE config 5 on one GPU")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary workloads (estimate3, fwd-only)')
     args = ap.parse_args()
@@ -104,7 +106,7 @@ def main():
     import lsps_amd.trainers as trainers
     from lsps_amd import ops, synth
 
-    hp = load_hp()
+    hp = load_hp(args.exp)
     tr = trainers.LSPSTrainer(hp)
     tr.cuda(local_rank)
     for net, seed in ((tr.gen, 1), (tr.dis, 2), (tr.vae, 3)):      # seeded weights, shapes from the nets' own state dicts
@@ -113,7 +115,7 @@ def main():
     tr.gen.train()
     tr.dis.train()
     ops.set_math_mode(args.dtype)
-    b = make_device_batch(args.batch, dev, seed_offset=rank)
+    b = make_device_batch(args.batch, dev, seed_offset=rank, label_dim=hp['vae']['input_dim'])
 
     def pretrain_step():
         tr.dis_update(b['xa'], b['la'], b['xb'], b['lb'], b['ca'], b['cb'], hp)
@@ -208,7 +210,7 @@ def main():
             'unit': 'steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'pretrain step = LSPSTrainer.dis_update + gen_update (enc+dec+disc+KL), exps/nnyu.yaml nets '
+            'config': {'workload': 'pretrain step = LSPSTrainer.dis_update + gen_update (enc+dec+disc+KL), exps/%s.yaml nets ' % args.exp +
                                    '(gen.ch=64, dis.ch=64), synthetic NYU-shape 128x128x1 depth crops',
                        'batch_per_domain_per_gpu': args.batch, 'global_batch_per_domain': args.batch * world,
                        'parallelism': 'dp%d' % world,
