@@ -501,9 +501,11 @@ __device__ __forceinline__ void ts2_bf16_body(const TS2BParams &p, unsigned shor
         }
     }
     if (ch >= 0) {
+#pragma unroll 1
+      for (int l3 = 0; l3 < NT; l3 += 3) {                   // row tap groups stay rolled: few live operand fragments
 #pragma unroll
-      for (int lt = 0; lt < NT; ++lt) {
-        const int s = lt % 3;
+      for (int s = 0; s < 3; ++s) {
+        const int lt = l3 + s;
         const int dh = (APAR && lt < 3) ? 1 : 0;
         const int dw = s == 0 ? 1 : 0, cls = s == 1 ? 0 : 1;
         bf16x8 af[2], bf[2];
@@ -518,6 +520,7 @@ __device__ __forceinline__ void ts2_bf16_body(const TS2BParams &p, unsigned shor
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[i][j][cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j][cls], 0, 0, 0);
+      }
       }
     }
   }

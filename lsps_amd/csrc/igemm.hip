@@ -620,8 +620,7 @@ static int run_t3x3s2(const float *in, const float *W, const float *bias, float 
   }
   const int RED = Cs * 9;
   const int Mp = (int)align_up(M, 128);
-  if (g_math_mode == 1 && M >= 128) {        // bf16 mode, 128-channel tiles: K-contiguous bf16 operands (Cs % 16 == 0 by
-                                             // t3x3s2_ok); the 64-channel variant spills and stays on the in-register conversion
+  if (g_math_mode == 1) {                    // bf16 mode: K-contiguous bf16 operands (Cs % 16 == 0 by t3x3s2_ok)
     const size_t wq_bytes = (size_t)(Mp / 128) * (Cs / FB_CC) * FB_ACH * sizeof(unsigned short);
     if (256 + wq_bytes > ws_bytes) {
       set_error("conv workspace too small: need %zu, have %zu", 256 + wq_bytes, ws_bytes);
@@ -658,8 +657,13 @@ static int run_t3x3s2(const float *in, const float *W, const float *bias, float 
     q.qblocks = Ws / 32;
     q.act = act;
     q.slope = slope;
-    q.tiles_per_img = (Hs / 4) * q.qblocks;
-    hipLaunchKernelGGL(igemm_t3x3s2_bf16_kernel<128>, dim3(N * q.tiles_per_img, ceil_div(M, 128), 2), dim3(256), 0, st, q);
+    if (M >= 128) {
+      q.tiles_per_img = (Hs / 4) * q.qblocks;
+      hipLaunchKernelGGL(igemm_t3x3s2_bf16_kernel<128>, dim3(N * q.tiles_per_img, ceil_div(M, 128), 2), dim3(256), 0, st, q);
+    } else {
+      q.tiles_per_img = (Hs / 8) * q.qblocks;
+      hipLaunchKernelGGL(igemm_t3x3s2_bf16_kernel<64>, dim3(N * q.tiles_per_img, ceil_div(M, 64), 2), dim3(256), 0, st, q);
+    }
     LSPS_CHECK_LAUNCH("igemm_t3x3s2_bf16");
     return 0;
   }
