@@ -335,9 +335,11 @@ __device__ __forceinline__ void ts2_body(const TS2Params &p, float *lds) {
       }
     }
     if (ch >= 0 && !BF16) {
+#pragma unroll 1
+      for (int l3 = 0; l3 < NT; l3 += 3)                     // the row-tap groups stay rolled (register pressure)
 #pragma unroll
-      for (int lt = 0; lt < NT; ++lt) {
-        const int s = lt % 3;
+      for (int s = 0; s < 3; ++s) {
+        const int lt = l3 + s;
         const int dh = (APAR && lt < 3) ? 1 : 0;             // a = 1: r = 0 reads the next input row
         const int dw = s == 0 ? 1 : 0, cls = s == 1 ? 0 : 1;
 #pragma unroll
