@@ -54,6 +54,13 @@ int lsps_pack_cache_end(void);
 #define LSPS_MATH_BF16 1
 int         lsps_set_math_mode(int mode);
 int         lsps_get_math_mode(void);
+/* Algorithm of the f32 3x3 / stride-1 / width-32 convs (the residual blocks: common_net.py:162-163, forward and dgrad):
+ * 0 = direct implicit GEMM; 1 = Winograd F(2x2,3x3) when the grid fills the chip (default; initial value from the
+ * environment variable LSPS_WINO); 2 = Winograd for every eligible shape (H % 8 == 0, C % 16 == 0, K % 64 == 0).
+ * Winograd results differ from the direct kernel by f32 round-off (~5e-7 relative, same size as the direct kernel's
+ * own distance from an f64 convolution); bf16 / split math modes are not affected.                      */
+int         lsps_set_winograd(int mode);
+int         lsps_get_winograd(void);
 
 /* ---- Conv2d: replaces nn.Conv2d forward + autograd's convolution_backward -----------------
  * call sites: common_net.py:250 (LeakyReLUConv2d), :162-163 (LeakyINSResBlock.conv3x3),

@@ -21,6 +21,8 @@ _SIGNATURES = {
     'lsps_last_error': (c_char_p, []),
     'lsps_device_cus': (c_int, []),
     'lsps_set_math_mode': (c_int, [c_int]),
+    'lsps_set_winograd': (c_int, [c_int]),
+    'lsps_get_winograd': (c_int, []),
     'lsps_get_math_mode': (c_int, []),
     'lsps_pack_cache_begin': (c_int, [_P, c_size_t]),
     'lsps_pack_cache_end': (c_int, []),

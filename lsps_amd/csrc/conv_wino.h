@@ -1,0 +1,342 @@
+// Winograd F(2x2, 3x3) form of the 3x3 / stride 1 / pad 1 / width 32 kernel (forward and dgrad of the residual convs).
+#ifndef LSPS_CONV_WINO_H
+#define LSPS_CONV_WINO_H
+#include "conv_types.h"
+#include "conv3x3.h"
+
+namespace lsps {
+
+// -------------------------------------------------------------------------------------------
+// The direct kernel (igemm_f3x3_kernel) runs at what the f32 matrix pipe sustains, so the only way down is fewer
+// multiplies: F(2x2,3x3) computes a 2x2 output tile from a 4x4 input tile with 16 multiplies per (k, c) pair instead
+// of 36, i.e. 16 independent [K x C] x [C x tiles] GEMMs, one per position of the transformed 4x4 tile.
+//
+// Everything is fused in one kernel, nothing transformed ever goes to HBM:
+//   U = G g G^T        once per weight tensor by wino_pack_kernel (cached with the other packed panels)
+//   V = B^T d B        per lane, in registers, from the raw input rows staged in LDS (the same "raw rows + zero halo"
+//                      staging as the direct kernel): 16 LDS floats -> 32 add/sub -> the B operands of 16 MFMAs
+//   M_p += U_p V_p     v_mfma_f32_32x32x2_f32, one accumulator tile (32 k x 32 tiles) per position p: 256 accumulator
+//                      registers per lane, so one wave per SIMD (launch bounds 256,1) with the accumulators in AGPRs
+//   Y = A^T M A        in registers in the epilogue (a lane holds all 16 positions of its (k, tile) pairs)
+//
+// Workgroup: 64 output channels x 64 tiles (8 output rows x 32 columns), waves 2 (k) x 2 (tile rows); a wave's 32
+// tiles are 2 tile rows x 16 tile columns.  MFMA operand layout (32x32x2): lane l holds A[k = l%32][c = l/32] and
+// B[c = l/32][tile = l%32], so lane l transforms ONE tile of ONE channel per k-step and feeds all 16 positions.
+// LDS per k-step and wave: 4 ds_read_b128 (U) + 8 ds_read_b64 (raw rows) for 16 MFMAs (1024 matrix-pipe cycles).
+// Row stride 48 floats: two tile rows apart = 96 floats = 32 banks, so the 32 lanes of a half-wave (2 tile rows x
+// 16 tile columns x 8 B) cover all 64 banks exactly once.
+// -------------------------------------------------------------------------------------------
+#define WN_CC 8                          // channels per U chunk (4 k-steps)
+#define WN_RC 8                          // channels per staged row chunk (4 k-steps between two barriers; 16 measured 2 % slower)
+#define WN_LDW 48                        // floats per staged row: [halo][32 pixels][halo][pad]
+#define WN_ROWS 10                       // 8 output rows + 2 halo rows
+#define WN_CH (WN_ROWS * WN_LDW)         // floats per staged channel
+#define WN_UCH (WN_CC * 16 * 64)         // floats of U per (k-slice, chunk): [8 c][4 position quads][64 k][4]
+#define WN_BUF (WN_RC * WN_CH)           // floats per LDS buffer (input rows only: U goes global -> registers)
+#define WN_LDS_BYTES (64 * 1024)         // 2 row buffers in the main loop; 64 KB for the epilogue exchange
+
+struct WinoPack {
+  const float *W;
+  float *U;                      // [M/64][C/8][8 c][4 quads][64 k][4]
+  int M, C;
+  long sm, sc;
+  int tapidx[9];
+};
+
+// one thread per (m, c): U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ __launch_bounds__(256) void wino_pack_kernel(WinoPack p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)p.M * p.C) return;
+  const int kl = (int)(idx & 63);
+  long rest = idx >> 6;
+  const int cl = (int)(rest & 7);
+  rest >>= 3;
+  const int chunks = p.C / WN_CC;
+  const int chunk = (int)(rest % chunks), ks = (int)(rest / chunks);
+  const int m = ks * 64 + kl, c = chunk * WN_CC + cl;
+  float g[3][3], t[4][3], u[4][4];
+  const float *w = p.W + (long)m * p.sm + (long)c * p.sc;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) g[r][s] = w[p.tapidx[r * 3 + s]];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    t[0][s] = g[0][s];
+    t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+    t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+    t[3][s] = g[2][s];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u[i][0] = t[i][0];
+    u[i][1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+    u[i][2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+    u[i][3] = t[i][2];
+  }
+  float *dst = p.U + ((long)ks * chunks + chunk) * WN_UCH + (long)cl * (16 * 64) + kl * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    *reinterpret_cast<f32x4 *>(dst + i * 256) = f32x4{u[i][0], u[i][1], u[i][2], u[i][3]};
+}
+
+// Packed f32 VALU ops of the data transform, spelled out: hipcc scalarises the float2 form of the column stage
+// (element shuffles become v_mov + scalar adds: 187 moves per chunk pair), and every VALU issue slot here is time the
+// matrix pipe does not get.  op_sel / op_sel_hi pick the half of each 64-bit source for the low / high result.
+// The two column ops feed MFMA operands: a VALU result needs 2 wait states before an MFMA may read it, and the
+// hazard recognizer does not look inside inline asm, hence the s_nop 1 in their strings (without it: wrong results).
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {                 // (a.x - b.x, a.y - b.y)
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {        // a * b + c
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_col01(f32x2 lo, f32x2 hi) {             // (lo.x - hi.x, lo.y + hi.x)
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]\n\ts_nop 1" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_col23(f32x2 lo, f32x2 hi) {             // (hi.x - lo.y, lo.y - hi.y)
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\ts_nop 1" : "=v"(r) : "v"(hi), "v"(lo));
+  return r;
+}
+
+struct WinoParams {
+  const float *X, *U, *bias;
+  const float *R;                // optional addend with Y's layout
+  float *Y;
+  int Cx, H, M, NT;              // NT = N * (H/8) pixel tiles
+  int tiles_per_img;             // H / 8
+  int act;
+  float slope;
+};
+
+__global__ __launch_bounds__(512, 1) void wino_f3x3_kernel(WinoParams p) {
+  extern __shared__ __attribute__((aligned(16))) float wn_lds[];
+  constexpr int NB4 = WN_RC * WN_ROWS * 8;                      // 16-B segments of input rows per row chunk
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave & 1, wt = (wave >> 1) & 1, wk = wave >> 2;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int tr = l31 >> 4, tc = l31 & 15;
+
+  // workgroup -> (pixel tile, k slice).  With 4 k slices each XCD keeps ONE 64-channel slice of U (1 MB per layer) in
+  // its L2 for the whole launch and streams half of the pixel tiles; otherwise plain order.
+  const int lin = blockIdx.x, MT = p.M >> 6;
+  int tile, mt;
+  if (MT == 4 && (p.NT & 1) == 0) {
+    const int xcd = lin & 7, q = lin >> 3;
+    mt = xcd & 3;
+    tile = (xcd >> 2) * (p.NT >> 1) + q;
+  } else {
+    tile = lin % p.NT;
+    mt = lin / p.NT;
+  }
+  const int n = tile / p.tiles_per_img;
+  const int row0 = (tile - n * p.tiles_per_img) * 8;
+  const int HW = p.H * 32;
+  const float *xn = p.X + (long)n * p.Cx * HW;
+  const int nchunks = p.Cx / WN_CC;
+  // this lane's A operands: U[chunk][c = 2s + half][quad = 2 wp + q][k = wk*32 + l31][4]: uniform base + lane offset
+  const float *ubase = p.U + (long)mt * nchunks * WN_UCH;
+  const unsigned u_lane = (half * (16 * 64) + 2 * wp * 256 + (wk * 32 + l31) * 4) * 4;   // bytes (32-bit: scalar base + offset addressing)
+
+  // Zero both row buffers once: the halo columns (index 0 and 33) are never written again, and neither are the rows
+  // that fall outside the image (their owners skip the store below), so the padding costs nothing in the loop.
+  for (int u = tid; u < 2 * WN_BUF / 4; u += 512) reinterpret_cast<f32x4 *>(wn_lds)[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging of the input rows: NB4 16-B segments per row chunk, NSEG per thread (the last one only for the first waves)
+  constexpr int NSEG = (NB4 + 511) / 512;
+  int b_lds[NSEG];
+  unsigned b_off[NSEG];
+  bool b_ok[NSEG];
+#pragma unroll
+  for (int i = 0; i < NSEG; ++i) {
+    const int u = min(tid + 512 * i, NB4 - 1);
+    const int line = u >> 3, c4 = u & 7;
+    const int ch = line / WN_ROWS, r = line - ch * WN_ROWS;
+    const int img_row = row0 - 1 + r;
+    b_ok[i] = img_row >= 0 && img_row < p.H;
+    b_lds[i] = ch * WN_CH + r * WN_LDW + 1 + c4 * 4;
+    b_off[i] = (ch * HW + min(max(img_row, 0), p.H - 1) * 32 + c4 * 4) * 4;   // bytes; out-of-image rows: load a valid row, never store it
+  }
+  const bool last_seg = wave < (NB4 - 512 * (NSEG - 1)) / 64;   // wave-uniform
+
+  // positions (i, 0..3) for i = 2 wp, 2 wp + 1: 8 accumulator tiles of 32 k x 32 tiles
+  f32x16 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  f32x4 breg[NSEG];
+  auto load_rows = [&](int rc) {
+    const char *xc = reinterpret_cast<const char *>(xn + (long)rc * WN_RC * HW);   // uniform
+#pragma unroll
+    for (int i = 0; i < NSEG; ++i)
+      if (i < NSEG - 1 || last_seg) breg[i] = *reinterpret_cast<const f32x4 *>(xc + b_off[i]);
+  };
+  auto store_seg = [&](float *buf, int i) {
+    if (b_ok[i]) {
+      float *d = buf + b_lds[i];
+      d[0] = breg[i][0];
+      *reinterpret_cast<f32x2 *>(d + 1) = f32x2{breg[i][1], breg[i][2]};
+      d[3] = breg[i][3];
+    }
+  };
+  auto store_rows = [&](float *buf) {
+#pragma unroll
+    for (int i = 0; i < NSEG; ++i)
+      if (i < NSEG - 1 || last_seg) store_seg(buf, i);
+  };
+
+  // The transform rows a wave needs, in the order (e0, e1, e2) that makes both position halves the same arithmetic:
+  //   wp = 0 reads d rows (0, 2, 1): t0 = e0 - e1 = d0 - d2,  t1 = e1 + e2 = d2 + d1
+  //   wp = 1 reads d rows (2, 1, 3): t2 = e0 - e1 = d2 - d1,  t3 = e1 - e2 = d1 - d3        (t_hi = e1 + sgn * e2)
+  const float sgn = wp ? -1.f : 1.f;
+  const f32x2 sgn2 = {sgn, sgn};
+  const int er0 = wp ? 2 : 0, er1 = wp ? 1 : 2, er2 = wp ? 3 : 1;
+  const int b_base = half * WN_CH + (wt * 4 + 2 * tr) * WN_LDW + 2 * tc;   // + 2s channels, + row
+  const float *rd0 = wn_lds + b_base + er0 * WN_LDW, *rd1 = wn_lds + b_base + er1 * WN_LDW, *rd2 = wn_lds + b_base + er2 * WN_LDW;
+
+  // A operands (U) come straight from global memory / L2 into registers, one k-step = 2 x 16 B per lane, fetched a
+  // whole chunk (4 k-steps) ahead: a[s] is reloaded for the next chunk right after step s has consumed it.  U never
+  // passes through LDS, which leaves LDS and the per-chunk barrier with the input rows only (5 KB instead of 47 KB).
+  f32x4 a[4][2];
+  auto load_u = [&](int ch, int s) {
+    const float *us = ubase + (long)ch * WN_UCH + 2 * s * (16 * 64);   // uniform
+    a[s][0] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(us) + u_lane);
+    a[s][1] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(us + 256) + u_lane);
+  };
+  // B operands: raw rows of one k-step (channels 2s + half), double-buffered in registers.  `bo` = compile-time
+  // float offset of the row buffer (the chunk loop is unrolled over both buffers so that every LDS address is a
+  // loop-invariant register + immediate)
+  f32x2 e[2][3][2];
+  auto read_step = [&](int bo, int s, int slot) {              // s = channel pair 0..7 of the row chunk
+    // volatile: keeps six ds_read_b64 with 16-bit immediate offsets; merged into ds_read2_b64 (8-bit offsets) every
+    // read needs a VALU add for its base, and a read2_b64 costs 8 LDS cycles against 2 x 2
+    typedef const volatile f32x2 __attribute__((address_space(3))) *vp;
+    e[slot][0][0] = *(vp)(rd0 + bo + 2 * s * WN_CH);
+    e[slot][0][1] = *(vp)(rd0 + bo + 2 * s * WN_CH + 2);
+    e[slot][1][0] = *(vp)(rd1 + bo + 2 * s * WN_CH);
+    e[slot][1][1] = *(vp)(rd1 + bo + 2 * s * WN_CH + 2);
+    e[slot][2][0] = *(vp)(rd2 + bo + 2 * s * WN_CH);
+    e[slot][2][1] = *(vp)(rd2 + bo + 2 * s * WN_CH + 2);
+  };
+  // one k-step: two rows of V = B^T d B and 8 MFMAs.  The transform is the only VALU work of the loop and VALU issue
+  // is not hidden behind the matrix pipe (measured: 16 scalar ops per 8 MFMAs cost 20 %), so it is written on
+  // float2 values for v_pk_add_f32 / v_pk_fma_f32: columns (v0, v1) = (t0, t1) + (-t2, t2), (v2, v3) = (t2, t1) - (t1, t3)
+  auto mma_step = [&](int s, int slot) {
+    f32x2 t[2][2], v[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      t[0][h] = pk_sub(e[slot][0][h], e[slot][1][h]);
+      t[1][h] = pk_fma(sgn2, e[slot][2][h], e[slot][1][h]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      v[i][0] = pk_col01(t[i][0], t[i][1]);
+      v[i][1] = pk_col23(t[i][0], t[i][1]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][q >> 2][q & 3], v[q >> 2][(q >> 1) & 1][q & 1], acc[q], 0, 0, 0);
+  };
+
+  // one row chunk (WN_RC channels = S k-steps) out of row buffer `bo`, staging row chunk `rn` into row buffer `nbo`.
+  // Issue order is pinned with sched_barrier: the LDS reads of step g+1 go out BEFORE the transform + MFMAs of step g
+  // (left alone, the scheduler sinks them to just before their use).
+  auto rowchunk = [&](int bo, int nbo, int rc, int rn) {
+    constexpr int S = WN_RC / 2;
+    load_rows(rn);
+#pragma unroll
+    for (int g = 0; g < S; ++g) {
+      if (g < S - 1) {
+        read_step(bo, g + 1, (g + 1) & 1);
+      } else {
+        store_rows(wn_lds + nbo);
+        __syncthreads();
+        read_step(nbo, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(g & 3, g & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // a[g & 3] is free: fetch it for k-step g + 4 (of this row chunk or of the next one)
+      load_u(g + 4 < S ? rc * (S / 4) + (g + 4) / 4 : rn * (S / 4) + (g + 4 - S) / 4, g & 3);
+    }
+  };
+
+  load_rows(0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) load_u(0, s);
+  __syncthreads();                               // zero fill done
+  store_rows(wn_lds);
+  __syncthreads();
+  read_step(0, 0, 0);
+
+  // Cx % (2 WN_RC) == 0: an even number of row chunks; the last one's prefetches are redundant reloads nobody consumes
+  const int nrc = p.Cx / WN_RC;
+  for (int rc = 0; rc < nrc; rc += 2) {
+    rowchunk(0, WN_BUF, rc, rc + 1);
+    rowchunk(WN_BUF, 0, rc + 1, min(rc + 2, nrc - 1));
+  }
+  __syncthreads();                               // the LDS buffers are free: reuse them for the exchange below
+
+  // Epilogue: Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]].  A lane holds rows (x, y) = (M[2wp], M[2wp+1]) of its
+  // (channel, tile) pairs; the row transform is s0 = m0 + m1 + m2, s1 = m1 - m2 - m3, so each half contributes
+  //   wp = 0: (x + y, y)      wp = 1: (x, -(x + y))
+  // and after the (linear) column transform the two halves' 2x2 partial tiles are added.  Each wave finishes 8 of its
+  // 16 channels: it hands the partial tiles of the other 8 to its partner through LDS and adds the partner's to its own.
+  f32x4 *xch = reinterpret_cast<f32x4 *>(wn_lds) + ((wk * 2 + wt) * 2) * 8 * 64 + lane;   // [pair][owner wp][8][64 lanes]
+  const int orow = row0 + wt * 4 + 2 * tr;
+  float *y0 = p.Y + (long)n * p.M * HW + (long)orow * 32 + 2 * tc;
+  // partial 2x2 tile of accumulator register r (compile-time) for position half W (compile-time)
+  auto part_of = [&](int r, int W) {
+    float p0[4], p1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = acc[j][r], y = acc[4 + j][r];
+      p0[j] = W ? x : x + y;
+      p1[j] = W ? -(x + y) : y;
+    }
+    return f32x4{p0[0] + p0[1] + p0[2], p0[1] - p0[2] - p0[3], p1[0] + p1[1] + p1[2], p1[1] - p1[2] - p1[3]};
+  };
+  auto finish = [&](int r, f32x4 o) {
+    const int m = mt * 64 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const float bv = p.bias ? p.bias[m] : 0.f;
+    f32x2 o0 = {apply_act(o[0] + bv, p.act, p.slope), apply_act(o[1] + bv, p.act, p.slope)};
+    f32x2 o1 = {apply_act(o[2] + bv, p.act, p.slope), apply_act(o[3] + bv, p.act, p.slope)};
+    float *ym = y0 + (long)m * HW;
+    if (p.R) {
+      const float *rm = p.R + (ym - p.Y);
+      o0 += *reinterpret_cast<const f32x2 *>(rm);
+      o1 += *reinterpret_cast<const f32x2 *>(rm + 32);
+    }
+    *reinterpret_cast<f32x2 *>(ym) = o0;
+    *reinterpret_cast<f32x2 *>(ym + 32) = o1;
+  };
+  if (wp == 0) {                                 // wave-uniform: wp = 0 owns registers 0..7, hands over 8..15
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) xch[(8 + rr) * 64] = part_of(8 + rr, 0);
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) xch[rr * 64] = part_of(rr, 1);
+  }
+  __syncthreads();
+  if (wp == 0) {
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) finish(rr, part_of(rr, 0) + xch[rr * 64]);
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) finish(8 + rr, part_of(8 + rr, 1) + xch[(8 + rr) * 64]);
+  }
+}
+
+}  // namespace lsps
+#endif

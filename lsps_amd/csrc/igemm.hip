@@ -38,6 +38,7 @@
 #include "conv3x3.h"
 #include "conv3x3s2.h"
 #include "conv_c1.h"
+#include "conv_wino.h"
 
 namespace lsps {
 
@@ -117,28 +118,41 @@ static bool pack_key_eq(const PackKey &a, const PackKey &b) {
          a.Wx == b.Wx && a.cc == b.cc && a.sm == b.sm && a.sc == b.sc && a.taphash == b.taphash;
 }
 
+// scope lookup: the cached panel for key k (*hit = true), a fresh arena slot of `need` bytes that the caller fills and
+// that is remembered under k (*hit = false), or nullptr (no scope open / arena full: use the call's workspace)
+static void *pack_cache_find(const PackKey &k, size_t need, bool *hit) {
+  *hit = false;
+  if (!g_pc_arena) return nullptr;
+  for (int i = 0; i < g_pc_n; ++i)
+    if (pack_key_eq(g_pc_tab[i].key, k)) {
+      *hit = true;
+      return g_pc_tab[i].cls;
+    }
+  if (g_pc_n >= 512 || g_pc_used + need > g_pc_bytes) return nullptr;
+  void *cls = g_pc_arena + g_pc_used;
+  g_pc_used += align_up(need, 256);
+  g_pc_tab[g_pc_n].key = k;
+  g_pc_tab[g_pc_n].cls = cls;
+  ++g_pc_n;
+  return cls;
+}
+
 static int launch_pack(const float *W, void *cls, int M, int Mp, int RED, int REDp, const TapList &l, long sm, long sc,
                        int HxWx, int Wx, hipStream_t st, const float **Wp_out, const int2 **gtab_out,
                        const float **zero_out, int cc = 0) {
   if (g_pc_arena && REDp > 0) {
     PackKey k = {W, M, Mp, RED, REDp, l.T, HxWx, Wx, cc, sm, sc, 2166136261u};
     for (int i = 0; i < l.T; ++i) k.taphash = (k.taphash ^ (unsigned)(l.idx[i] * 961 + (l.dh[i] + 8) * 31 + (l.dw[i] + 8))) * 16777619u;
-    for (int i = 0; i < g_pc_n; ++i)
-      if (pack_key_eq(g_pc_tab[i].key, k)) {
-        char *c = (char *)g_pc_tab[i].cls;
-        *gtab_out = (const int2 *)c;
-        *Wp_out = (const float *)(c + align_up((size_t)REDp * sizeof(int2), 256));
-        *zero_out = *Wp_out + (size_t)REDp * Mp;
-        return 0;
-      }
-    const size_t need = class_bytes(REDp, Mp);
-    if (g_pc_n < 512 && g_pc_used + need <= g_pc_bytes) {        // miss: pack into the arena and remember it
-      cls = g_pc_arena + g_pc_used;
-      g_pc_used += align_up(need, 256);
-      g_pc_tab[g_pc_n].key = k;
-      g_pc_tab[g_pc_n].cls = cls;
-      ++g_pc_n;
-    }                                                             // arena full: pack into the call's workspace as usual
+    bool hit;
+    void *slot = pack_cache_find(k, class_bytes(REDp, Mp), &hit);
+    if (hit) {
+      char *c = (char *)slot;
+      *gtab_out = (const int2 *)c;
+      *Wp_out = (const float *)(c + align_up((size_t)REDp * sizeof(int2), 256));
+      *zero_out = *Wp_out + (size_t)REDp * Mp;
+      return 0;
+    }
+    if (slot) cls = slot;                                         // miss: pack into the arena (full: the call's workspace)
   }
   int2 *gtab = (int2 *)cls;
   float *Wp = (float *)((char *)cls + align_up((size_t)REDp * sizeof(int2), 256));
@@ -230,6 +244,83 @@ static size_t packed_bytes(int Cin, int taps_total, int classes, int M) {
 
 static bool f3x3_ok(int Cin, int H, int W, int R, int S, int st_, int pad) {
   return R == 3 && S == 3 && st_ == 1 && pad == 1 && W == 32 && (H % 4) == 0 && (Cin % F3_CC) == 0;
+}
+
+// Winograd F(2x2,3x3) path of run_f3x3 (f32 mode): conv_wino.h.  Mode (lsps_set_winograd, initial value from LSPS_WINO):
+// 0 = never (direct kernel), 1 = grids that fill the chip (default), 2 = every eligible shape.
+static int g_wino_mode = -1;
+static int wino_mode() {
+  if (g_wino_mode < 0) {
+    const char *e = getenv("LSPS_WINO");
+    g_wino_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+  }
+  return g_wino_mode;
+}
+// one workgroup per CU (512 threads, 226 VGPRs): below two full rounds of workgroups the direct kernel's 2-row tiles
+// and reduction split use the chip better
+static bool wino_ok(int N, int Cin, int H, int M) {
+  const int mode = wino_mode();
+  if (mode == 0 || (H % 8) != 0 || (M % 64) != 0 || (Cin % (2 * WN_RC)) != 0) return false;
+  return mode == 2 || (long)N * (H / 8) * (M / 64) >= 512;
+}
+
+static size_t wino_bytes(int Cin, int M) { return (size_t)16 * Cin * M * sizeof(float); }   // U: 16 positions x [M][Cin]
+
+static int run_wino(const float *in, const float *W, const float *bias, float *out, int N, int Cin, int H, int M, long sm,
+                    long sc, const TapList &l, int act, float slope, void *ws, size_t ws_bytes, hipStream_t st,
+                    const float *addend) {
+  static bool attr_set = false;
+  if (!attr_set) {                        // 94 KB of LDS: dynamic + opt-in
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_f3x3_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(wino_f3x3): %s", hipGetErrorString(e));
+      return LSPS_E_HIP;
+    }
+    attr_set = true;
+  }
+  const size_t need = wino_bytes(Cin, M);
+  PackKey k = {W, M, M, Cin * 16, Cin * 16, 9, H * 32, 32, /*cc: marks the Winograd layout*/ 1 << 20, sm, sc, 2166136261u};
+  for (int i = 0; i < 9; ++i) k.taphash = (k.taphash ^ (unsigned)(l.idx[i] * 961 + i)) * 16777619u;
+  bool hit;
+  void *slot = pack_cache_find(k, need, &hit);
+  if (!slot) {
+    if (need > ws_bytes) {
+      set_error("conv workspace too small: need %zu, have %zu", need, ws_bytes);
+      return LSPS_E_WS;
+    }
+    slot = ws;
+  }
+  float *U = (float *)slot;
+  if (!hit) {
+    WinoPack pk;
+    pk.W = W;
+    pk.U = U;
+    pk.M = M;
+    pk.C = Cin;
+    pk.sm = sm;
+    pk.sc = sc;
+    for (int t = 0; t < 9; ++t) pk.tapidx[t] = l.idx[t];
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(ceil_div((long)M * Cin, 256)), dim3(256), 0, st, pk);
+    LSPS_CHECK_LAUNCH("wino_pack");
+  }
+  WinoParams p;
+  memset(&p, 0, sizeof(p));
+  p.X = in;
+  p.U = U;
+  p.bias = bias;
+  p.R = addend;
+  p.Y = out;
+  p.Cx = Cin;
+  p.H = H;
+  p.M = M;
+  p.tiles_per_img = H / 8;
+  p.NT = N * p.tiles_per_img;
+  p.act = act;
+  p.slope = slope;
+  hipLaunchKernelGGL(wino_f3x3_kernel, dim3(p.NT * (M / 64)), dim3(512), WN_LDS_BYTES, st, p);
+  LSPS_CHECK_LAUNCH("wino_f3x3");
+  return 0;
 }
 
 // in [N][Cin][H][32] -> out [N][M][H][32]; tapidx maps kernel tap t=(dh+1)*3+(dw+1) to the weight's r*3+s
@@ -353,6 +444,8 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
     LSPS_CHECK_LAUNCH("igemm_f3x3_split");
     return 0;
   }
+  if (wino_ok(N, Cin, H, M))
+    return run_wino(in, W, bias, out, N, Cin, H, M, sm, sc, l, act, slope, ws, ws_bytes, st, addend);
   const size_t need = class_bytes(REDp, Mp);
   if (need > ws_bytes) {
     set_error("conv workspace too small: need %zu, have %zu", need, ws_bytes);
@@ -1096,6 +1189,7 @@ static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int W
     const size_t cmax = Cb > Cs ? Cb : Cs;
     const size_t sp = 256 + (align_up(cmax, 128) / 128) * (cmax / 8 + 1) * FS_ACHUNK * sizeof(unsigned short);
     if (sp > m) m = sp;
+    if (wino_bytes((int)cmax, (int)cmax) > m) m = wino_bytes((int)cmax, (int)cmax);
   }
   if (w3x3_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, R == 3 ? 1 : -1)) {
     const size_t w3 = w3x3_ws_bytes(N, Cs, Cb, Hb);
@@ -1145,6 +1239,17 @@ int lsps_set_math_mode(int mode) {
 }
 
 int lsps_get_math_mode(void) { return lsps::g_math_mode; }
+
+int lsps_set_winograd(int mode) {
+  if (mode < 0 || mode > 2) {
+    set_error("set_winograd: mode must be 0 (off), 1 (grids that fill the chip) or 2 (every eligible shape)");
+    return LSPS_E_ARG;
+  }
+  lsps::g_wino_mode = mode;
+  return 0;
+}
+
+int lsps_get_winograd(void) { return lsps::wino_mode(); }
 
 int lsps_pack_cache_begin(void *arena, size_t bytes) {
   LSPS_CHECK_ARG(arena && bytes >= ((size_t)1 << 20) && (((uintptr_t)arena) & 255) == 0, "pack_cache_begin: need a 256-byte aligned arena of >= 1 MiB");

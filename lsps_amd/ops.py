@@ -45,10 +45,14 @@ class Profiler(object):
         self.records = []
 
     @staticmethod
-    def f_kernel(M, cin=0, h=0, w=0, r=0, stride=0, pad=0, transposed=False):
+    def f_kernel(M, cin=0, h=0, w=0, r=0, stride=0, pad=0, transposed=False, n=0):
         """Name of the kernel the C library dispatches to (mirrors igemm.hip: f3x3_ok / t3x3s2_ok / choose_cfg).
         `h`, `w`: the kernel's INPUT image; `transposed`: conv dgrad / convT forward (small image -> big image)."""
         if r == 3 and stride == 1 and pad == 1 and w == 32 and h % 4 == 0 and cin % 8 == 0 and M >= 128:
+            if h % 8 == 0 and M % 64 == 0 and cin % 16 == 0 and get_math_mode() == 'f32':      # wino_ok (igemm.hip)
+                mode = get_winograd()
+                if mode == 'always' or (mode == 'auto' and n * (h // 8) * (M // 64) >= 512):
+                    return 'wino_f3x3_kernel'
             return 'igemm_f3x3_kernel'
         if transposed and r == 3 and stride == 2 and pad == 1 and w % 32 == 0 and h % (4 if M >= 128 else 8) == 0 \
                 and cin % 16 == 0 and M >= 64:
@@ -103,6 +107,17 @@ def set_math_mode(mode):
 
 def get_math_mode():
     return ('f32', 'bf16', 'f32_split')[_lib.lib().lsps_get_math_mode()]
+
+
+def set_winograd(mode):
+    """Algorithm of the f32 3x3 / stride-1 / width-32 convs: 'off' (direct implicit GEMM), 'auto' (Winograd F(2x2,3x3)
+    when the grid fills the chip; default) or 'always' (every eligible shape).  Process-wide."""
+    code = {'off': 0, 'auto': 1, 'always': 2}[mode]
+    _lib.check(_lib.lib().lsps_set_winograd(code), 'set_winograd')
+
+
+def get_winograd():
+    return ('off', 'auto', 'always')[_lib.lib().lsps_get_winograd()]
 
 
 def conv_out_size(h, r, stride, pad):
@@ -166,7 +181,7 @@ class _Conv2dFn(torch.autograd.Function):
         P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
         y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
         ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, R, S, stride, pad), x.device)
-        with profiler.span(Profiler.f_kernel(K, C, H, W, R if R == S else 0, stride, pad), 2.0 * N * K * P * Q * C * R * S, 1):
+        with profiler.span(Profiler.f_kernel(K, C, H, W, R if R == S else 0, stride, pad, n=N), 2.0 * N * K * P * Q * C * R * S, 1):
             _lib.check(L.lsps_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, C, H, W, K, R, S,
                                          stride, pad, act, slope, ws, wsb, _lib.stream()), 'conv2d_fwd')
         ctx.geom = (N, C, H, W, K, R, S, stride, pad, act, slope)
@@ -187,7 +202,7 @@ class _Conv2dFn(torch.autograd.Function):
         dy, db = _act_backward(L, dy, y, act, slope, ctx.has_bias and ctx.needs_input_grad[2], K, ws, wsb, st)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            kname = Profiler.f_kernel(C, K, dy.shape[2], dy.shape[3], R if R == S else 0, stride, pad, True)
+            kname = Profiler.f_kernel(C, K, dy.shape[2], dy.shape[3], R if R == S else 0, stride, pad, True, n=dy.shape[0])
             with profiler.span(kname, flops, 1 if 't3x3s2' in kname else stride * stride):
                 _lib.check(L.lsps_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, C, H, W, K, R, S, stride,
                                                pad, ws, wsb, st), 'conv2d_dgrad')
@@ -324,7 +339,7 @@ class _ResBlockFn(torch.autograd.Function):
         y = torch.empty_like(a1)
         r1 = torch.empty(N * K, dtype=torch.float32, device=x.device)
         r2 = torch.empty_like(r1)
-        kname = Profiler.f_kernel(K, C, H, W, 3, 1, 1)
+        kname = Profiler.f_kernel(K, C, H, W, 3, 1, 1, n=N)
         with profiler.span(kname, flops, 1):
             _lib.check(L.lsps_conv2d_fwd(_lib.ptr(x), _lib.ptr(w1), None, _lib.ptr(a1), N, C, H, W, K, 3, 3, 1, 1, ACT_NONE,
                                          1.0, ws, wsb, st), 'conv2d_fwd')
@@ -348,7 +363,7 @@ class _ResBlockFn(torch.autograd.Function):
         st = _lib.stream()
         ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, 3, 3, 1, 1), x.device)
         flops = 2.0 * N * K * H * W * C * 9
-        fk, wk = Profiler.f_kernel(C, K, H, W, 3, 1, 1, True), Profiler.w_kernel(C, H, W, K, 3, 1, 1)
+        fk, wk = Profiler.f_kernel(C, K, H, W, 3, 1, 1, True, n=N), Profiler.w_kernel(C, H, W, K, 3, 1, 1)
         dh2 = torch.empty_like(y)
         _lib.check(L.lsps_inorm_bwd(_lib.ptr(g), _lib.ptr(y), _lib.ptr(x), _lib.ptr(r2), _lib.ptr(dh2), N * K, H * W, -1.0,
                                     st), 'inorm_bwd')

@@ -433,3 +433,99 @@ def test_empty_batch_behaves_like_torch():
         oa, ob = gen.decode(za)
         assert tuple(oa.shape) == (0, 1, 128, 128) and tuple(ob.shape) == (0, 1, 128, 128)
         assert dis.model_S(dis.model_A(e)).shape[0] == 0
+
+
+# (N, C, H, K): Winograd F(2x2,3x3) path of the 3x3 / stride-1 / width-32 convs (forced for every eligible shape)
+WINO_CASES = [
+    (3, 256, 32, 256),     # the residual conv; odd N * 4 tiles: 12 pixel tiles, 4 k slices (XCD mapping)
+    (1, 32, 8, 64),        # one pixel tile, one k slice, two row chunks: top AND bottom halo rows in one workgroup
+    (5, 64, 8, 128),       # odd pixel-tile count: plain workgroup order
+    (2, 96, 16, 192),      # 3 k slices, 6 row-chunk pairs
+    (2, 48, 24, 64),       # H = 24: three tiles per image
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("act", ["none", "lrelu"])
+def test_conv3x3_winograd(case, act):
+    """Winograd kernel vs an f64 convolution: forward (bias, activation), dgrad (flipped taps) and the fused
+    dgrad + addend; same tolerance class as the direct kernel (both are f32 MFMA accumulations)."""
+    _need_gpu()
+    from lsps_amd import _lib, ops
+    N, C, H, K = case
+    L = _lib.lib()
+    prev = ops.get_winograd()
+    ops.set_winograd('always')
+    try:
+        x = _rand(N, C, H, 32, seed=1).double().requires_grad_(True)
+        w = _rand(K, C, 3, 3, seed=2, scale=0.1).double().requires_grad_(True)
+        b = _rand(K, seed=3, scale=0.1).double().requires_grad_(True)
+        y_ref = F.conv2d(x, w, b, padding=1)
+        if act == 'lrelu':
+            y_ref = F.leaky_relu(y_ref, 0.01)
+        gy = _rand(*y_ref.shape, seed=4)
+        y_ref.backward(gy.double())
+        xd, wd, bd = (t.detach().float().cuda().requires_grad_(True) for t in (x, w, b))
+        y = ops.conv2d(xd, wd, bd, 1, 1, ops.ACT_LRELU if act == 'lrelu' else ops.ACT_NONE, 0.01)
+        y.backward(gy.cuda())
+        errs = dict(y=_rel(y, y_ref), dx=_rel(xd.grad, x.grad), dw=_rel(wd.grad, w.grad), db=_rel(bd.grad, b.grad))
+        tol = LRELU_BWD_TOL if act == 'lrelu' else 2e-5
+        assert errs['y'] < 2e-5 and errs['dx'] < tol and errs['dw'] < 1e-4 and errs['db'] < 1e-4, errs
+        # against the direct kernel: round-off only
+        ops.set_winograd('off')
+        y_dir = ops.conv2d(xd.detach(), wd.detach(), bd.detach(), 1, 1, ops.ACT_LRELU if act == 'lrelu' else ops.ACT_NONE, 0.01)
+        assert _rel(y, y_dir) < 2e-5
+        ops.set_winograd('always')
+        if act == 'none' and C % 64 == 0 and K % 32 == 0:
+            # fused dgrad + addend (residual block backward): dgrad's "input channels" are K, its outputs C
+            add = _rand(N, C, H, 32, seed=9)
+            gyd, wdd, addd = gy.cuda().contiguous(), wd.detach().contiguous(), add.cuda().contiguous()
+            dx = torch.empty(N, C, H, 32, device='cuda')
+            ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, 32, K, 3, 3, 1, 1), dx.device)
+            _lib.check(L.lsps_conv2d_dgrad_acc(_lib.ptr(gyd), _lib.ptr(wdd), _lib.ptr(addd), _lib.ptr(dx), N, C, H, 32, K,
+                                               3, 3, 1, 1, ws, wsb, _lib.stream()), 'dgrad_acc')
+            assert _rel(dx, x.grad.float() + add) < 2e-5
+    finally:
+        ops.set_winograd(prev)
+
+
+def test_winograd_mode_switch():
+    _need_gpu()
+    from lsps_amd import _lib, ops
+    prev = ops.get_winograd()
+    try:
+        for m in ('off', 'always', 'auto'):
+            ops.set_winograd(m)
+            assert ops.get_winograd() == m
+        assert _lib.lib().lsps_set_winograd(3) != 0
+    finally:
+        ops.set_winograd(prev)
+
+
+def test_winograd_inside_weight_cache_scope():
+    """The transformed weights are cached with the other packed panels: two forwards and a dgrad inside one scope give
+    the same results as outside it, and a weight update between scopes is seen."""
+    _need_gpu()
+    from lsps_amd import ops
+    prev = ops.get_winograd()
+    ops.set_winograd('always')
+    try:
+        x = _rand(2, 64, 16, 32, seed=1).cuda()
+        w = _rand(64, 64, 3, 3, seed=2, scale=0.1).cuda()
+        y0 = ops.conv2d(x, w, None, 1, 1)
+        ops.weight_cache_begin(x.device)
+        try:
+            y1 = ops.conv2d(x, w, None, 1, 1)
+            y2 = ops.conv2d(x, w, None, 1, 1)
+        finally:
+            ops.weight_cache_end()
+        assert torch.equal(y0, y1) and torch.equal(y0, y2)
+        w.mul_(2.0)
+        ops.weight_cache_begin(x.device)
+        try:
+            y3 = ops.conv2d(x, w, None, 1, 1)
+        finally:
+            ops.weight_cache_end()
+        assert _rel(y3, 2.0 * y0) < 1e-6
+    finally:
+        ops.set_winograd(prev)
