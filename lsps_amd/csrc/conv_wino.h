@@ -338,5 +338,250 @@ __global__ __launch_bounds__(512, 1) void wino_f3x3_kernel(WinoParams p) {
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// Weight gradient of the same conv in Winograd form.  With Y = A^T [U . V] A the gradient of g is
+//   dg = G^T [ (A dY A^T) . (B^T d B) ] G      summed over tiles and images,
+// i.e. again 16 independent GEMMs, M_p[k][c] += sum_tiles T_p[k][tile] V_p[c][tile], now with the reduction over
+// tiles (MFMA k-dimension = 2 tiles), 16 multiplies per (k, c, tile) instead of 36.
+//   T = A dY A^T (2x2 -> 4x4) and V = B^T d B (4x4 -> 4x4): per lane, in registers, from raw dy / x rows in LDS
+//   M_p accumulates in registers over the workgroup's share of the tile rows; partial sums go to the workspace
+//   dg = G^T M G and the sum over workgroups: wino_w3x3_reduce_kernel
+// Signs: A's last row / column is (0, -1); the kernel uses (0, +1) (T' = s s^T . T, s = (1,1,1,-1)), which costs
+// nothing and is undone in the reduce kernel by G' = diag(s) G.
+// Workgroup: 64 k x 64 c, 8 waves = 2 (k) x 2 (c) x 2 (position halves: rows 2wp, 2wp+1 of the 4x4 grid); one chunk
+// = one tile row of one image (16 tiles = 8 k-steps): x rows 2tr-1 .. 2tr+2 of 64 channels, dy rows 2tr, 2tr+1 of 64.
+// LDS channel strides are 2 * odd floats: the 32 lanes of a ds_read_b64 group hold 32 different channels at the
+// same pixel, so their 8-byte words land on 32 different bank pairs.
+// -------------------------------------------------------------------------------------------
+#define WW_XS 138                        // floats per x channel: 4 rows x 34 + 2
+#define WW_DS 66                         // floats per dy channel: 2 rows x 32 + 2
+#define WW_XBUF (64 * WW_XS)
+#define WW_BUF (WW_XBUF + 64 * WW_DS)    // floats per LDS buffer
+#define WW_LDS_BYTES (2 * WW_BUF * 4)    // double-buffered: 102 KB
+
+struct WinoWParams {
+  const float *DY, *X;
+  float *part;                   // [split][16 positions][M][C]
+  int N, M, C, H;
+  int ntr, per_split;            // tile rows in total (N * H/2) and per split
+};
+
+__device__ __forceinline__ f32x2 pk_fma_n(f32x2 a, f32x2 b, f32x2 c) {      // a * b + c, result feeds an MFMA
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_sumdiff(f32x2 a) {                      // (a.x + a.y, a.x - a.y), result feeds an MFMA
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(a));
+  return r;
+}
+
+__global__ __launch_bounds__(512, 1) void wino_w3x3_kernel(WinoWParams p) {
+  extern __shared__ __attribute__((aligned(16))) float ww_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave & 1, wc = (wave >> 1) & 1, wk = wave >> 2;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int cb = blockIdx.x, kb = blockIdx.y, z = blockIdx.z;
+  const int H = p.H, trows = H >> 1;                   // tile rows per image
+  const int t0 = z * p.per_split, t1 = min(p.ntr, t0 + p.per_split);
+
+  // staging assignment: x 64 c x 4 rows x 8 segments = 4 per thread, dy 64 k x 2 rows x 8 segments = 2 per thread.
+  // Byte offsets relative to the chunk's scalar base (image n, tile row tr); the first / last tile row of an image
+  // has its row -1 / H outside the image: those lanes load a clamped (valid) row and store zeros.
+  unsigned xo_mid[4], xo_top[4], xo_bot[4], dyo[2];
+  int x_lds[4], d_lds[2];
+  int x_r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = tid + 512 * i, line = u >> 3, seg = u & 7;
+    const int c = line >> 2, r = line & 3;
+    x_r[i] = r;
+    x_lds[i] = c * WW_XS + r * 34 + 1 + seg * 4;
+    const unsigned cbase = (unsigned)(cb * 64 + c) * H * 32 + seg * 4;   // relative to row 2tr-1 of channel 0 of image n
+    xo_mid[i] = (cbase + r * 32) * 4;
+    xo_top[i] = (cbase + max(r, 1) * 32) * 4;          // tr = 0: row -1 is outside, load row 0 instead (stored as zeros)
+    xo_bot[i] = (cbase + min(r, 2) * 32) * 4;          // last tile row: row H is outside
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = tid + 512 * i, line = u >> 3, seg = u & 7;
+    const int k = line >> 1, r = line & 1;
+    d_lds[i] = WW_XBUF + k * WW_DS + r * 32 + seg * 4;
+    dyo[i] = ((unsigned)(kb * 64 + k) * H * 32 + r * 32 + seg * 4) * 4;
+  }
+  // halo columns of the x rows (index 0 and 33): zero once in both buffers
+  for (int u = tid; u < 2 * 64 * 4 * 2; u += 512) {
+    const int b = u >> 9, rr = (u & 511) >> 1;
+    ww_lds[b * WW_BUF + (rr >> 2) * WW_XS + (rr & 3) * 34 + (u & 1) * 33] = 0.f;
+  }
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  f32x4 xreg[4], dreg[2];
+  bool xz[4];                                          // store zeros instead of the loaded row
+  auto load_chunk = [&](int trow) {
+    const int n = trow / trows, tr = trow - n * trows;
+    const char *xb = reinterpret_cast<const char *>(p.X + ((long)n * p.C * H + 2 * tr - 1) * 32);   // uniform
+    const char *db = reinterpret_cast<const char *>(p.DY + ((long)n * p.M * H + 2 * tr) * 32);
+    if (tr == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xreg[i] = *reinterpret_cast<const f32x4 *>(xb + xo_top[i]), xz[i] = x_r[i] == 0;
+    } else if (tr == trows - 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xreg[i] = *reinterpret_cast<const f32x4 *>(xb + xo_bot[i]), xz[i] = x_r[i] == 3;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xreg[i] = *reinterpret_cast<const f32x4 *>(xb + xo_mid[i]), xz[i] = false;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dreg[i] = *reinterpret_cast<const f32x4 *>(db + dyo[i]);
+  };
+  auto store_chunk = [&](float *buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float *d = buf + x_lds[i];
+      if (xz[i]) {
+        d[0] = 0.f;
+        *reinterpret_cast<f32x2 *>(d + 1) = f32x2{0.f, 0.f};
+        d[3] = 0.f;
+      } else {
+        d[0] = xreg[i][0];
+        *reinterpret_cast<f32x2 *>(d + 1) = f32x2{xreg[i][1], xreg[i][2]};
+        d[3] = xreg[i][3];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float *d = buf + d_lds[i];
+      *reinterpret_cast<f32x2 *>(d) = f32x2{dreg[i][0], dreg[i][1]};
+      *reinterpret_cast<f32x2 *>(d + 2) = f32x2{dreg[i][2], dreg[i][3]};
+    }
+  };
+
+  // B side (x -> V rows 2wp, 2wp+1), as in the forward kernel: wp = 0 reads d rows (0, 2, 1), wp = 1 reads (2, 1, 3);
+  // slot 0 = e0 - e1, slot 1 = e1 + sgn * e2.
+  // A side (dy -> T' rows 2wp, 2wp+1) from the tile's two dy rows D0, D1 (2 pixels each):
+  //   wp = 0: rows 0, 1 = D0, D0 + D1      wp = 1: rows 2, 3' = D0 - D1, D1      -> slot 0 = D0 + b0 D1, slot 1 = a1 D0 + D1
+  // and per row (x, y) the four columns are x, x + y, x - y, y.
+  const float sgn = wp ? -1.f : 1.f, b0 = wp ? -1.f : 0.f, a1 = wp ? 0.f : 1.f;
+  const f32x2 sgn2 = {sgn, sgn}, b02 = {b0, b0}, a12 = {a1, a1};
+  const int er0 = wp ? 2 : 0, er1 = wp ? 1 : 2, er2 = wp ? 3 : 1;
+  const int xl = (wc * 32 + l31) * WW_XS + 2 * half;             // + 4 s (tile 2s + half), + row * 34
+  const float *rd0 = ww_lds + xl + er0 * 34, *rd1 = ww_lds + xl + er1 * 34, *rd2 = ww_lds + xl + er2 * 34;
+  const float *rdd = ww_lds + WW_XBUF + (wk * 32 + l31) * WW_DS + 2 * half;   // + 4 s, + row * 32
+
+  f32x2 e[2][3][2], dd[2][2];
+  typedef const volatile f32x2 __attribute__((address_space(3))) *vp;
+  auto read_step = [&](int bo, int s, int slot) {
+    e[slot][0][0] = *(vp)(rd0 + bo + 4 * s);
+    e[slot][0][1] = *(vp)(rd0 + bo + 4 * s + 2);
+    e[slot][1][0] = *(vp)(rd1 + bo + 4 * s);
+    e[slot][1][1] = *(vp)(rd1 + bo + 4 * s + 2);
+    e[slot][2][0] = *(vp)(rd2 + bo + 4 * s);
+    e[slot][2][1] = *(vp)(rd2 + bo + 4 * s + 2);
+    dd[slot][0] = *(vp)(rdd + bo + 4 * s);
+    dd[slot][1] = *(vp)(rdd + bo + 4 * s + 32);
+  };
+  auto mma_step = [&](int slot) {
+    f32x2 t[2][2], v[2][2], sr[2], sd[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      t[0][h] = pk_sub(e[slot][0][h], e[slot][1][h]);
+      t[1][h] = pk_fma(sgn2, e[slot][2][h], e[slot][1][h]);
+    }
+    sr[0] = pk_fma_n(b02, dd[slot][1], dd[slot][0]);
+    sr[1] = pk_fma_n(a12, dd[slot][0], dd[slot][1]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      v[i][0] = pk_col01(t[i][0], t[i][1]);
+      v[i][1] = pk_col23(t[i][0], t[i][1]);
+      sd[i] = pk_sumdiff(sr[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      acc[i * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[i][0], v[i][0][0], acc[i * 4 + 0], 0, 0, 0);
+      acc[i * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[i][0], v[i][0][1], acc[i * 4 + 1], 0, 0, 0);
+      acc[i * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[i][1], v[i][1][0], acc[i * 4 + 2], 0, 0, 0);
+      acc[i * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[i][1], v[i][1][1], acc[i * 4 + 3], 0, 0, 0);
+    }
+  };
+  // one tile row out of buffer `bo`, staging tile row `nt` into buffer `nbo`; the LDS reads of step s+1 are issued
+  // before the transforms + MFMAs of step s (order pinned with sched_barrier, see the forward kernel)
+  auto chunk = [&](int bo, int nbo, int nt) {
+    load_chunk(nt);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < 7) {
+        read_step(bo, s + 1, (s + 1) & 1);
+      } else {
+        store_chunk(ww_lds + nbo);
+        __syncthreads();
+        read_step(nbo, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(s & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  if (t0 < t1) {
+    load_chunk(t0);
+    __syncthreads();                             // halo zero fill done
+    store_chunk(ww_lds);
+    __syncthreads();
+    read_step(0, 0, 0);
+    // the last chunk prefetches a clamped (valid) tile row that nobody consumes
+    int t = t0;
+    for (; t + 1 < t1; t += 2) {
+      chunk(0, WW_BUF, t + 1);
+      chunk(WW_BUF, 0, min(t + 2, t1 - 1));
+    }
+    if (t < t1) chunk(0, WW_BUF, t);
+  }
+
+  // partial sums: part[z][(2wp + i) * 4 + j][k][c]
+  float *pz = p.part + (long)z * 16 * p.M * p.C + (long)(2 * wp) * 4 * p.M * p.C +
+              (long)(kb * 64 + wk * 32 + 4 * half) * p.C + cb * 64 + wc * 32 + l31;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pz[(long)q * p.M * p.C + (long)((r & 3) + 8 * (r >> 2)) * p.C] = acc[q][r];
+}
+
+// dW[k][c][3][3] = G'^T (sum_z M'_z) G',  G' = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,-1]]
+__global__ __launch_bounds__(256) void wino_w3x3_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, int MC,
+                                                               int splits) {
+  const int i = blockIdx.x * 256 + threadIdx.x;        // k * C + c
+  if (i >= MC) return;
+  float m[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) m[q] = 0.f;
+  for (int z = 0; z < splits; ++z)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) m[q] += part[((long)z * 16 + q) * MC + i];
+  // columns first: w[i][s] = sum_j m[i][j] G'[j][s]
+  float w[4][3];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const float m0 = m[a * 4], m1 = m[a * 4 + 1], m2 = m[a * 4 + 2], m3 = m[a * 4 + 3];
+    w[a][0] = m0 + 0.5f * (m1 + m2);
+    w[a][1] = 0.5f * (m1 - m2);
+    w[a][2] = 0.5f * (m1 + m2) - m3;
+  }
+  float *o = dW + (long)i * 9;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    o[0 * 3 + s] = w[0][s] + 0.5f * (w[1][s] + w[2][s]);
+    o[1 * 3 + s] = 0.5f * (w[1][s] - w[2][s]);
+    o[2 * 3 + s] = 0.5f * (w[1][s] + w[2][s]) - w[3][s];
+  }
+}
+
 }  // namespace lsps
 #endif

@@ -917,8 +917,61 @@ static size_t w3x3_ws_bytes(int N, int M, int C, int H) {
   return 256 + (size_t)w3x3_splits(M, C, N * H / 2) * 9 * M * C * sizeof(float);
 }
 
+// Winograd form of the 3x3 weight gradient (conv_wino.h): one 512-thread workgroup per CU, so the tile rows are split
+// over 256 / (64x64 blocks) workgroups
+static int wino_w_splits(int M, int C, int ntr) {
+  int s = 256 / ((M / 64) * (C / 64));
+  if (s > ntr) s = ntr;
+  return s < 1 ? 1 : s;
+}
+static size_t wino_w_ws_bytes(int N, int M, int C, int H) {
+  return (size_t)wino_w_splits(M, C, N * H / 2) * 16 * M * C * sizeof(float);
+}
+static bool wino_w_ok(int N, int C, int H, int M) {
+  const int mode = wino_mode();
+  if (mode == 0 || g_math_mode != 0 || H < 4) return false;
+  return mode == 2 || (long)N * (H / 8) * (M / 64) >= 512;
+}
+
+static int run_wino_w(const float *dy, const float *x, float *dW, int N, int C, int H, int M, void *ws, size_t ws_bytes,
+                      hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {                        // 102 KB of LDS: dynamic + opt-in
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_w3x3_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)WW_LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(wino_w3x3): %s", hipGetErrorString(e));
+      return LSPS_E_HIP;
+    }
+    attr_set = true;
+  }
+  if (wino_w_ws_bytes(N, M, C, H) > ws_bytes) {
+    set_error("wgrad workspace too small: need %zu, have %zu", wino_w_ws_bytes(N, M, C, H), ws_bytes);
+    return LSPS_E_WS;
+  }
+  WinoWParams p;
+  memset(&p, 0, sizeof(p));
+  p.DY = dy;
+  p.X = x;
+  p.part = (float *)ws;
+  p.N = N;
+  p.M = M;
+  p.C = C;
+  p.H = H;
+  p.ntr = N * H / 2;
+  const int splits = wino_w_splits(M, C, p.ntr);
+  p.per_split = ceil_div(p.ntr, splits);
+  hipLaunchKernelGGL(wino_w3x3_kernel, dim3(C / 64, M / 64, splits), dim3(512), WW_LDS_BYTES, st, p);
+  LSPS_CHECK_LAUNCH("wino_w3x3");
+  hipLaunchKernelGGL(wino_w3x3_reduce_kernel, dim3(ceil_div((long)M * C, 256)), dim3(256), 0, st, (const float *)p.part, dW,
+                     M * C, splits);
+  LSPS_CHECK_LAUNCH("wino_w3x3_reduce");
+  return 0;
+}
+
 static int run_w3x3(const float *dy, const float *x, float *dW, int N, int C, int H, int M, void *ws, size_t ws_bytes,
                     hipStream_t st) {
+  if (wino_w_ok(N, C, H, M)) return run_wino_w(dy, x, dW, N, C, H, M, ws, ws_bytes, st);
   W3Params p;
   memset(&p, 0, sizeof(p));
   p.DY = dy;
@@ -1194,6 +1247,7 @@ static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int W
   if (w3x3_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, R == 3 ? 1 : -1)) {
     const size_t w3 = w3x3_ws_bytes(N, Cs, Cb, Hb);
     if (w3 > m) m = w3;
+    if (wino_w_ws_bytes(N, Cs, Cb, Hb) > m) m = wino_w_ws_bytes(N, Cs, Cb, Hb);
   }
   if (w3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, 1)) {
     const size_t w3 = w3x3s2_ws_bytes(N, Cs, Cb, Hs, Ws);

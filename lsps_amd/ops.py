@@ -65,8 +65,12 @@ class Profiler(object):
         return 'igemm_f_kernel<2,2,2,2>' if M >= 128 else ('igemm_f_kernel<2,2,1,4>' if M >= 64 else 'igemm_f_kernel<1,2,1,4>')
 
     @staticmethod
-    def w_kernel(cb, hb, wb, cs, r, stride, pad):
+    def w_kernel(cb, hb, wb, cs, r, stride, pad, n=0):
         if r == 3 and stride == 1 and pad == 1 and wb == 32 and hb % 2 == 0 and cb % 64 == 0 and cs % 64 == 0:
+            if hb >= 4 and get_math_mode() == 'f32':                                           # wino_w_ok (igemm.hip)
+                mode = get_winograd()
+                if mode == 'always' or (mode == 'auto' and n * (hb // 8) * (cs // 64) >= 512):
+                    return 'wino_w3x3_kernel'
             return 'igemm_w3x3_kernel'
         if r == 3 and stride == 2 and pad == 1 and cb % 64 == 0 and cs % 128 == 0 and wb % 64 == 0 and hb % 2 == 0:
             return 'igemm_w3x3s2_kernel'
@@ -211,7 +215,7 @@ class _Conv2dFn(torch.autograd.Function):
             db_here = None                  # the bias gradient, unless the fused act_bwd pass already produced it
             if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
                 db = db_here = torch.empty(K, dtype=torch.float32, device=x.device)
-            with profiler.span(Profiler.w_kernel(C, H, W, K, R if R == S else 0, stride, pad), flops, 1):
+            with profiler.span(Profiler.w_kernel(C, H, W, K, R if R == S else 0, stride, pad, n=N), flops, 1):
                 _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db_here), N, C, H, W, K,
                                                R, S, stride, pad, ws, wsb, st), 'conv2d_wgrad')
         return dx, dw, db, None, None, None, None
@@ -363,7 +367,7 @@ class _ResBlockFn(torch.autograd.Function):
         st = _lib.stream()
         ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, 3, 3, 1, 1), x.device)
         flops = 2.0 * N * K * H * W * C * 9
-        fk, wk = Profiler.f_kernel(C, K, H, W, 3, 1, 1, True, n=N), Profiler.w_kernel(C, H, W, K, 3, 1, 1)
+        fk, wk = Profiler.f_kernel(C, K, H, W, 3, 1, 1, True, n=N), Profiler.w_kernel(C, H, W, K, 3, 1, 1, n=N)
         dh2 = torch.empty_like(y)
         _lib.check(L.lsps_inorm_bwd(_lib.ptr(g), _lib.ptr(y), _lib.ptr(x), _lib.ptr(r2), _lib.ptr(dh2), N * K, H * W, -1.0,
                                     st), 'inorm_bwd')

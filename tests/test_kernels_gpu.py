@@ -442,6 +442,9 @@ WINO_CASES = [
     (5, 64, 8, 128),       # odd pixel-tile count: plain workgroup order
     (2, 96, 16, 192),      # 3 k slices, 6 row-chunk pairs
     (2, 48, 24, 64),       # H = 24: three tiles per image
+    (2, 64, 4, 64),        # wgrad: two tile rows per image (first AND last), one 64x64 block
+    (3, 128, 6, 64),       # wgrad: 9 tile rows (odd chunk count per split)
+    (1, 64, 32, 128),      # wgrad: a single image over 16 splits
 ]
 
 

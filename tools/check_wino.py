@@ -24,11 +24,11 @@ def t_ms(fn, iters=10):
 def main():
     dev = torch.device('cuda')
     torch.manual_seed(0)
-    for N, C, K, H in [(8, 256, 256, 32), (3, 64, 128, 16), (128, 256, 256, 32), (256, 256, 256, 32)]:
+    ops.set_winograd(os.environ.get('LSPS_WINO_MODE', 'always'))
+    for N, C, K, H in [(8, 256, 256, 32), (3, 64, 128, 16), (2, 64, 64, 4), (128, 256, 256, 32), (256, 256, 256, 32)]:
         x = torch.randn(N, C, H, 32, device=dev)
         w = torch.randn(K, C, 3, 3, device=dev) * 0.02
         b = torch.randn(K, device=dev)
-        os.environ['LSPS_WINO_MIN_WGS'] = '1'
         y = ops.conv2d(x, w, b, 1, 1)
         if N <= 8:
             ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
@@ -38,6 +38,23 @@ def main():
         ms = t_ms(lambda: ops.conv2d(x, w, b, 1, 1))
         fl = 2.0 * N * H * 32 * C * K * 9
         print('N=%d C=%d K=%d H=%d  rel err %.2e  %.3f ms  %.1f TFLOP/s (direct-equivalent)' % (N, C, K, H, err, ms, fl / ms / 1e9))
+        # weight gradient (C-ABI call: no bias gradient pass in the timing)
+        from lsps_amd import _lib
+        L = _lib.lib()
+        g = torch.randn(N, K, H, 32, device=dev)
+        dw = torch.empty_like(w)
+        ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, 32, K, 3, 3, 1, 1), dev)
+
+        def wg():
+            _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(g), _lib.ptr(dw), None, N, C, H, 32, K, 3, 3, 1, 1, ws, wsb,
+                                           _lib.stream()), 'wgrad')
+        ms = t_ms(wg)
+        werr = float('nan')
+        if N <= 8:
+            wr = w.double().clone().requires_grad_(True)
+            F.conv2d(x.double(), wr, None, padding=1).backward(g.double())
+            werr = ((dw.double() - wr.grad).abs().max() / wr.grad.abs().max()).item()
+        print('   wgrad rel err %.2e  %.3f ms  %.1f TFLOP/s' % (werr, ms, fl / ms / 1e9))
         # dgrad through autograd
         if N <= 8:
             xg = x.clone().requires_grad_(True)
