@@ -256,12 +256,13 @@ static int wino_mode() {
   }
   return g_wino_mode;
 }
-// one workgroup per CU (512 threads, 226 VGPRs): below two full rounds of workgroups the direct kernel's 2-row tiles
-// and reduction split use the chip better
+// One workgroup per CU (512 threads, 226 VGPRs) and no reduction split: a single workgroup takes ~75 us for 256 input
+// channels, so below ~96 workgroups the direct kernel with its 2-row tiles and channel split is faster (measured on
+// 256 -> 256 @ 32x32, tools/sweep_wino.py: N = 4: 0.063 vs 0.079 ms, N = 6: 0.089 vs 0.078, N = 16: 0.158 vs 0.081)
 static bool wino_ok(int N, int Cin, int H, int M) {
   const int mode = wino_mode();
   if (mode == 0 || (H % 8) != 0 || (M % 64) != 0 || (Cin % (2 * WN_RC)) != 0) return false;
-  return mode == 2 || (long)N * (H / 8) * (M / 64) >= 512;
+  return mode == 2 || (long)N * (H / 8) * (M / 64) >= 96;
 }
 
 static size_t wino_bytes(int Cin, int M) { return (size_t)16 * Cin * M * sizeof(float); }   // U: 16 positions x [M][Cin]
@@ -930,7 +931,7 @@ static size_t wino_w_ws_bytes(int N, int M, int C, int H) {
 static bool wino_w_ok(int N, int C, int H, int M) {
   const int mode = wino_mode();
   if (mode == 0 || g_math_mode != 0 || H < 4) return false;
-  return mode == 2 || (long)N * (H / 8) * (M / 64) >= 512;
+  return mode == 2 || (long)N * (H / 2) >= 32;     // tile rows; the reduction is split, so small batches gain too (N = 2: 0.037 vs 0.055 ms)
 }
 
 static int run_wino_w(const float *dy, const float *x, float *dW, int N, int C, int H, int M, void *ws, size_t ws_bytes,

@@ -51,7 +51,7 @@ class Profiler(object):
         if r == 3 and stride == 1 and pad == 1 and w == 32 and h % 4 == 0 and cin % 8 == 0 and M >= 128:
             if h % 8 == 0 and M % 64 == 0 and cin % 16 == 0 and get_math_mode() == 'f32':      # wino_ok (igemm.hip)
                 mode = get_winograd()
-                if mode == 'always' or (mode == 'auto' and n * (h // 8) * (M // 64) >= 512):
+                if mode == 'always' or (mode == 'auto' and n * (h // 8) * (M // 64) >= 96):
                     return 'wino_f3x3_kernel'
             return 'igemm_f3x3_kernel'
         if transposed and r == 3 and stride == 2 and pad == 1 and w % 32 == 0 and h % (4 if M >= 128 else 8) == 0 \
@@ -69,7 +69,7 @@ class Profiler(object):
         if r == 3 and stride == 1 and pad == 1 and wb == 32 and hb % 2 == 0 and cb % 64 == 0 and cs % 64 == 0:
             if hb >= 4 and get_math_mode() == 'f32':                                           # wino_w_ok (igemm.hip)
                 mode = get_winograd()
-                if mode == 'always' or (mode == 'auto' and n * (hb // 8) * (cs // 64) >= 512):
+                if mode == 'always' or (mode == 'auto' and n * (hb // 2) >= 32):
                     return 'wino_w3x3_kernel'
             return 'igemm_w3x3_kernel'
         if r == 3 and stride == 2 and pad == 1 and cb % 64 == 0 and cs % 128 == 0 and wb % 64 == 0 and hb % 2 == 0:
