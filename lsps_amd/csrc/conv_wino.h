@@ -33,7 +33,7 @@ namespace lsps {
 #define WN_CH (WN_ROWS * WN_LDW)         // floats per staged channel
 #define WN_UCH (WN_CC * 16 * 64)         // floats of U per (k-slice, chunk): [8 c][4 position quads][64 k][4]
 #define WN_BUF (WN_RC * WN_CH)           // floats per LDS buffer (input rows only: U goes global -> registers)
-#define WN_LDS_BYTES (64 * 1024)         // 2 row buffers in the main loop; 64 KB for the epilogue exchange
+#define WN_LDS_BYTES(NWK) (32 * 1024 * (NWK))   // 2 row buffers (30 KB) in the main loop; 16 KB per wave pair for the epilogue exchange
 
 struct WinoPack {
   const float *W;
@@ -116,7 +116,12 @@ struct WinoParams {
   float slope;
 };
 
-__global__ __launch_bounds__(512, 1) void wino_f3x3_kernel(WinoParams p) {
+// NWK = waves along the output channels: 2 -> 512 threads, 64 channels x 64 tiles, one workgroup per CU;
+// 1 -> 256 threads, 32 channels x 64 tiles, TWO workgroups per CU (same 2 waves per SIMD), so that one workgroup's
+// barriers, prologue and epilogue overlap with the other one's MFMAs.
+template <int NWK>
+__global__ __launch_bounds__(256 * NWK, 2 / NWK) void wino_f3x3_kernel(WinoParams p) {
+  constexpr int NT_ = 256 * NWK;
   extern __shared__ __attribute__((aligned(16))) float wn_lds[];
   constexpr int NB4 = WN_RC * WN_ROWS * 8;                      // 16-B segments of input rows per row chunk
 
@@ -128,12 +133,15 @@ __global__ __launch_bounds__(512, 1) void wino_f3x3_kernel(WinoParams p) {
 
   // workgroup -> (pixel tile, k slice).  With 4 k slices each XCD keeps ONE 64-channel slice of U (1 MB per layer) in
   // its L2 for the whole launch and streams half of the pixel tiles; otherwise plain order.
-  const int lin = blockIdx.x, MT = p.M >> 6;
+  const int lin = blockIdx.x, MT = p.M / (32 * NWK);
   int tile, mt;
   if (MT == 4 && (p.NT & 1) == 0) {
     const int xcd = lin & 7, q = lin >> 3;
     mt = xcd & 3;
     tile = (xcd >> 2) * (p.NT >> 1) + q;
+  } else if (MT == 8) {                          // one slice per XCD, every XCD streams all pixel tiles
+    mt = lin & 7;
+    tile = lin >> 3;
   } else {
     tile = lin % p.NT;
     mt = lin / p.NT;
@@ -144,21 +152,22 @@ __global__ __launch_bounds__(512, 1) void wino_f3x3_kernel(WinoParams p) {
   const float *xn = p.X + (long)n * p.Cx * HW;
   const int nchunks = p.Cx / WN_CC;
   // this lane's A operands: U[chunk][c = 2s + half][quad = 2 wp + q][k = wk*32 + l31][4]: uniform base + lane offset
-  const float *ubase = p.U + (long)mt * nchunks * WN_UCH;
-  const unsigned u_lane = (half * (16 * 64) + 2 * wp * 256 + (wk * 32 + l31) * 4) * 4;   // bytes (32-bit: scalar base + offset addressing)
+  const int k0 = mt * 32 * NWK + wk * 32;        // first output channel of this wave
+  const float *ubase = p.U + (long)(k0 >> 6) * nchunks * WN_UCH;
+  const unsigned u_lane = (half * (16 * 64) + 2 * wp * 256 + ((k0 & 63) + l31) * 4) * 4;   // bytes (32-bit: scalar base + offset addressing)
 
   // Zero both row buffers once: the halo columns (index 0 and 33) are never written again, and neither are the rows
   // that fall outside the image (their owners skip the store below), so the padding costs nothing in the loop.
-  for (int u = tid; u < 2 * WN_BUF / 4; u += 512) reinterpret_cast<f32x4 *>(wn_lds)[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = tid; u < 2 * WN_BUF / 4; u += NT_) reinterpret_cast<f32x4 *>(wn_lds)[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // staging of the input rows: NB4 16-B segments per row chunk, NSEG per thread (the last one only for the first waves)
-  constexpr int NSEG = (NB4 + 511) / 512;
+  constexpr int NSEG = (NB4 + NT_ - 1) / NT_;
   int b_lds[NSEG];
   unsigned b_off[NSEG];
   bool b_ok[NSEG];
 #pragma unroll
   for (int i = 0; i < NSEG; ++i) {
-    const int u = min(tid + 512 * i, NB4 - 1);
+    const int u = min(tid + NT_ * i, NB4 - 1);
     const int line = u >> 3, c4 = u & 7;
     const int ch = line / WN_ROWS, r = line - ch * WN_ROWS;
     const int img_row = row0 - 1 + r;
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(512, 1) void wino_f3x3_kernel(WinoParams p) {
     b_lds[i] = ch * WN_CH + r * WN_LDW + 1 + c4 * 4;
     b_off[i] = (ch * HW + min(max(img_row, 0), p.H - 1) * 32 + c4 * 4) * 4;   // bytes; out-of-image rows: load a valid row, never store it
   }
-  const bool last_seg = wave < (NB4 - 512 * (NSEG - 1)) / 64;   // wave-uniform
+  const bool last_seg = wave < (NB4 - NT_ * (NSEG - 1)) / 64;   // wave-uniform
 
   // positions (i, 0..3) for i = 2 wp, 2 wp + 1: 8 accumulator tiles of 32 k x 32 tiles
   f32x16 acc[8];
@@ -175,25 +184,27 @@ __global__ __launch_bounds__(512, 1) void wino_f3x3_kernel(WinoParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
-  f32x4 breg[NSEG];
-  auto load_rows = [&](int rc) {
+  // input rows travel global -> registers -> LDS and are fetched TWO row chunks ahead (two register sets): they come
+  // from HBM, not from L2 like U, and one chunk (4 k-steps ~ 2 us) does not cover that latency under load
+  f32x4 breg[2][NSEG];
+  auto load_rows = [&](int rc, int set) {
     const char *xc = reinterpret_cast<const char *>(xn + (long)rc * WN_RC * HW);   // uniform
 #pragma unroll
     for (int i = 0; i < NSEG; ++i)
-      if (i < NSEG - 1 || last_seg) breg[i] = *reinterpret_cast<const f32x4 *>(xc + b_off[i]);
+      if (i < NSEG - 1 || last_seg) breg[set][i] = *reinterpret_cast<const f32x4 *>(xc + b_off[i]);
   };
-  auto store_seg = [&](float *buf, int i) {
+  auto store_seg = [&](float *buf, int i, int set) {
     if (b_ok[i]) {
       float *d = buf + b_lds[i];
-      d[0] = breg[i][0];
-      *reinterpret_cast<f32x2 *>(d + 1) = f32x2{breg[i][1], breg[i][2]};
-      d[3] = breg[i][3];
+      d[0] = breg[set][i][0];
+      *reinterpret_cast<f32x2 *>(d + 1) = f32x2{breg[set][i][1], breg[set][i][2]};
+      d[3] = breg[set][i][3];
     }
   };
-  auto store_rows = [&](float *buf) {
+  auto store_rows = [&](float *buf, int set) {
 #pragma unroll
     for (int i = 0; i < NSEG; ++i)
-      if (i < NSEG - 1 || last_seg) store_seg(buf, i);
+      if (i < NSEG - 1 || last_seg) store_seg(buf, i, set);
   };
 
   // The transform rows a wave needs, in the order (e0, e1, e2) that makes both position halves the same arithmetic:
@@ -249,18 +260,19 @@ __global__ __launch_bounds__(512, 1) void wino_f3x3_kernel(WinoParams p) {
       acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][q >> 2][q & 3], v[q >> 2][(q >> 1) & 1][q & 1], acc[q], 0, 0, 0);
   };
 
-  // one row chunk (WN_RC channels = S k-steps) out of row buffer `bo`, staging row chunk `rn` into row buffer `nbo`.
+  // one row chunk (WN_RC channels = S k-steps; parity `par` = rc & 1, compile-time) out of row buffer `bo`: stores row
+  // chunk rc+1 (register set 1-par) into row buffer `nbo`, fetches row chunk `r2` = rc+2 into register set par.
   // Issue order is pinned with sched_barrier: the LDS reads of step g+1 go out BEFORE the transform + MFMAs of step g
   // (left alone, the scheduler sinks them to just before their use).
-  auto rowchunk = [&](int bo, int nbo, int rc, int rn) {
+  auto rowchunk = [&](int bo, int nbo, int rc, int rn, int r2, int par) {
     constexpr int S = WN_RC / 2;
-    load_rows(rn);
+    load_rows(r2, par);
 #pragma unroll
     for (int g = 0; g < S; ++g) {
       if (g < S - 1) {
         read_step(bo, g + 1, (g + 1) & 1);
       } else {
-        store_rows(wn_lds + nbo);
+        store_rows(wn_lds + nbo, 1 - par);
         __syncthreads();
         read_step(nbo, 0, 0);
       }
@@ -272,19 +284,20 @@ __global__ __launch_bounds__(512, 1) void wino_f3x3_kernel(WinoParams p) {
     }
   };
 
-  load_rows(0);
+  // Cx % (2 WN_RC) == 0: an even number of row chunks; past the end the prefetches are redundant reloads nobody consumes
+  const int nrc = p.Cx / WN_RC;
+  load_rows(0, 0);
 #pragma unroll
   for (int s = 0; s < 4; ++s) load_u(0, s);
   __syncthreads();                               // zero fill done
-  store_rows(wn_lds);
+  store_rows(wn_lds, 0);
+  load_rows(1, 1);
   __syncthreads();
   read_step(0, 0, 0);
 
-  // Cx % (2 WN_RC) == 0: an even number of row chunks; the last one's prefetches are redundant reloads nobody consumes
-  const int nrc = p.Cx / WN_RC;
   for (int rc = 0; rc < nrc; rc += 2) {
-    rowchunk(0, WN_BUF, rc, rc + 1);
-    rowchunk(WN_BUF, 0, rc + 1, min(rc + 2, nrc - 1));
+    rowchunk(0, WN_BUF, rc, rc + 1, min(rc + 2, nrc - 1), 0);
+    rowchunk(WN_BUF, 0, rc + 1, min(rc + 2, nrc - 1), min(rc + 3, nrc - 1), 1);
   }
   __syncthreads();                               // the LDS buffers are free: reuse them for the exchange below
 
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(512, 1) void wino_f3x3_kernel(WinoParams p) {
     return f32x4{p0[0] + p0[1] + p0[2], p0[1] - p0[2] - p0[3], p1[0] + p1[1] + p1[2], p1[1] - p1[2] - p1[3]};
   };
   auto finish = [&](int r, f32x4 o) {
-    const int m = mt * 64 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int m = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
     const float bv = p.bias ? p.bias[m] : 0.f;
     f32x2 o0 = {apply_act(o[0] + bv, p.act, p.slope), apply_act(o[1] + bv, p.act, p.slope)};
     f32x2 o1 = {apply_act(o[2] + bv, p.act, p.slope), apply_act(o[3] + bv, p.act, p.slope)};
