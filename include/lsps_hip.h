@@ -56,7 +56,8 @@ int         lsps_set_math_mode(int mode);
 int         lsps_get_math_mode(void);
 /* Algorithm of the f32 3x3 / stride-1 / width-32 convs (the residual blocks: common_net.py:162-163, forward and dgrad):
  * 0 = direct implicit GEMM; 1 = Winograd F(2x2,3x3) when the grid fills the chip (default; initial value from the
- * environment variable LSPS_WINO); 2 = Winograd for every eligible shape (H % 8 == 0, C % 16 == 0, K % 64 == 0).
+ * environment variable LSPS_WINO); 2 = Winograd for every eligible shape (forward / dgrad: H % 8 == 0, C % 16 == 0, K % 64 == 0; weight gradient: H >= 4 even,
+ * C % 64 == 0, K % 64 == 0).
  * Winograd results differ from the direct kernel by f32 round-off (~5e-7 relative, same size as the direct kernel's
  * own distance from an f64 convolution); bf16 / split math modes are not affected.                      */
 int         lsps_set_winograd(int mode);

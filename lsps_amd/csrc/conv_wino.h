@@ -256,8 +256,9 @@ __global__ __launch_bounds__(256 * NWK, 2 / NWK) void wino_f3x3_kernel(WinoParam
       v[i][1] = pk_col23(t[i][0], t[i][1]);
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < 8; ++q) {
       acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][q >> 2][q & 3], v[q >> 2][(q >> 1) & 1][q & 1], acc[q], 0, 0, 0);
+    }
   };
 
   // one row chunk (WN_RC channels = S k-steps; parity `par` = rc & 1, compile-time) out of row buffer `bo`: stores row
