@@ -131,11 +131,18 @@ __global__ __launch_bounds__(256 * NWK, 2 / NWK) void wino_f3x3_kernel(WinoParam
   const int l31 = lane & 31, half = lane >> 5;
   const int tr = l31 >> 4, tc = l31 & 15;
 
-  // workgroup -> (pixel tile, k slice).  With 4 k slices each XCD keeps ONE 64-channel slice of U (1 MB per layer) in
-  // its L2 for the whole launch and streams half of the pixel tiles; otherwise plain order.
+  // workgroup -> (pixel tile, k slice).  Workgroups go to the 8 XCDs round-robin in launch order and each XCD has its
+  // own 4 MB L2: an XCD keeps a fixed part of U resident for the whole launch and streams its share of the pixel tiles
+  // (measured HBM fetch per N=256 launch: one slice per XCD 1.21 GB, two slices 0.81 GB, same speed).
   const int lin = blockIdx.x, MT = p.M / (32 * NWK);
   int tile, mt;
-  if (MT == 4 && (p.NT & 1) == 0) {
+  if (MT == 4 && (p.NT & 3) == 0) {
+    // two slices per XCD (2 MB of U in its L2), a quarter of the pixel tiles, the two slices of a tile adjacent in
+    // time: the second read of the tile's input rows hits L2
+    const int xcd = lin & 7, q = lin >> 3;
+    mt = 2 * (xcd & 1) + (q & 1);
+    tile = (xcd >> 1) * (p.NT >> 2) + (q >> 1);
+  } else if (MT == 4 && (p.NT & 1) == 0) {
     const int xcd = lin & 7, q = lin >> 3;
     mt = xcd & 3;
     tile = (xcd >> 2) * (p.NT >> 1) + q;
@@ -397,7 +404,17 @@ __global__ __launch_bounds__(512, 1) void wino_w3x3_kernel(WinoWParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = wave & 1, wc = (wave >> 1) & 1, wk = wave >> 2;
   const int l31 = lane & 31, half = lane >> 5;
-  const int cb = blockIdx.x, kb = blockIdx.y, z = blockIdx.z;
+  // XCD-aware mapping (workgroups go to the 8 XCDs round-robin in launch order): all (k, c) blocks of one split of the
+  // tile rows sit on ONE XCD, so its dy / x rows come from HBM once and from that XCD's L2 for the other blocks
+  int cb = blockIdx.x, kb = blockIdx.y, z = blockIdx.z;
+  if ((gridDim.z & 7) == 0) {
+    const int nb = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int xcd = lin & 7, q = lin >> 3, b = q % nb;
+    z = xcd + 8 * (q / nb);
+    cb = b % gridDim.x;
+    kb = b / gridDim.x;
+  }
   const int H = p.H, trows = H >> 1;                   // tile rows per image
   const int t0 = z * p.per_split, t1 = min(p.ntr, t0 + p.per_split);
 
