@@ -445,6 +445,8 @@ WINO_CASES = [
     (2, 64, 4, 64),        # wgrad: two tile rows per image (first AND last), one 64x64 block
     (3, 128, 6, 64),       # wgrad: 9 tile rows (odd chunk count per split)
     (1, 64, 32, 128),      # wgrad: a single image over 16 splits
+    (17, 32, 32, 256),     # 272 workgroups of 64 channels: the 512-thread forward kernel, two-slices-per-XCD mapping
+    (33, 16, 16, 256),     # 264 workgroups, pixel-tile count 66 (not a multiple of 4): one-slice-per-XCD mapping
 ]
 
 
