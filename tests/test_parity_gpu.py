@@ -42,6 +42,25 @@ def test_steps_match_reference_golden(config, golden):
     assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
 
 
+@pytest.mark.parametrize("mode", ["always", "off"])
+def test_full_steps_match_reference_golden_per_conv_algorithm(mode, golden):
+    """The `full` config's update steps against the REAL reference's golden vectors with the residual convs forced
+    onto the Winograd kernels (forward, dgrad and weight gradient, also at this small batch) and onto the direct ones:
+    both sit inside the same tolerances ('auto', the default, is what the test above runs)."""
+    A = _adapter()
+    from lsps_amd import ops
+    prev = ops.get_winograd()
+    ops.set_winograd(mode)
+    try:
+        R = cases.run_step_cases(A, 'full', lsps_ref)
+    finally:
+        ops.set_winograd(prev)
+    g = {k: v for k, v in golden('full').items() if k.split('/')[0] in R}
+    bad, worst = cases.compare(R, g, RTOL, grad_rtol=2e-2)
+    print("worst rel err", worst)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
+
+
 def test_resnext_generator_matches_reference_golden(golden):
     A = _adapter()
     R = cases.run_resx_cases(A, lsps_ref)
