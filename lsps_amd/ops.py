@@ -48,6 +48,8 @@ class Profiler(object):
     def f_kernel(M, cin=0, h=0, w=0, r=0, stride=0, pad=0, transposed=False, n=0):
         """Name of the kernel the C library dispatches to (mirrors igemm.hip: f3x3_ok / t3x3s2_ok / choose_cfg).
         `h`, `w`: the kernel's INPUT image; `transposed`: conv dgrad / convT forward (small image -> big image)."""
+        if not profiler.enabled:
+            return ''                             # the key is only used while spans are recorded
         if r == 3 and stride == 1 and pad == 1 and w == 32 and h % 4 == 0 and cin % 8 == 0 and M >= 128:
             if h % 8 == 0 and M % 64 == 0 and cin % 16 == 0 and get_math_mode() == 'f32':      # wino_ok (igemm.hip)
                 mode = get_winograd()
@@ -66,6 +68,8 @@ class Profiler(object):
 
     @staticmethod
     def w_kernel(cb, hb, wb, cs, r, stride, pad, n=0):
+        if not profiler.enabled:
+            return ''
         if r == 3 and stride == 1 and pad == 1 and wb == 32 and hb % 2 == 0 and cb % 64 == 0 and cs % 64 == 0:
             if hb >= 4 and get_math_mode() == 'f32':                                           # wino_w_ok (igemm.hip)
                 mode = get_winograd()
