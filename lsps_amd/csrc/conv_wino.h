@@ -163,10 +163,6 @@ __global__ __launch_bounds__(256 * NWK, 2 / NWK) void wino_f3x3_kernel(WinoParam
   const float *ubase = p.U + (long)(k0 >> 6) * nchunks * WN_UCH;
   const unsigned u_lane = (half * (16 * 64) + 2 * wp * 256 + ((k0 & 63) + l31) * 4) * 4;   // bytes (32-bit: scalar base + offset addressing)
 
-  // Zero both row buffers once: the halo columns (index 0 and 33) are never written again, and neither are the rows
-  // that fall outside the image (their owners skip the store below), so the padding costs nothing in the loop.
-  for (int u = tid; u < 2 * WN_BUF / 4; u += NT_) reinterpret_cast<f32x4 *>(wn_lds)[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   // staging of the input rows: NB4 16-B segments per row chunk, NSEG per thread (the last one only for the first waves)
   constexpr int NSEG = (NB4 + NT_ - 1) / NT_;
   int b_lds[NSEG];
@@ -186,10 +182,6 @@ __global__ __launch_bounds__(256 * NWK, 2 / NWK) void wino_f3x3_kernel(WinoParam
 
   // positions (i, 0..3) for i = 2 wp, 2 wp + 1: 8 accumulator tiles of 32 k x 32 tiles
   f32x16 acc[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
   // input rows travel global -> registers -> LDS and are fetched TWO row chunks ahead (two register sets): they come
   // from HBM, not from L2 like U, and one chunk (4 k-steps ~ 2 us) does not cover that latency under load
@@ -294,9 +286,18 @@ __global__ __launch_bounds__(256 * NWK, 2 / NWK) void wino_f3x3_kernel(WinoParam
 
   // Cx % (2 WN_RC) == 0: an even number of row chunks; past the end the prefetches are redundant reloads nobody consumes
   const int nrc = p.Cx / WN_RC;
+  // prologue: the first loads go out before everything that does not depend on them (LDS zero fill, accumulator init)
   load_rows(0, 0);
 #pragma unroll
   for (int s = 0; s < 4; ++s) load_u(0, s);
+  __builtin_amdgcn_sched_barrier(0);
+  // Zero both row buffers once: the halo columns (index 0 and 33) are never written again, and neither are the rows
+  // that fall outside the image (their owners skip the store below), so the padding costs nothing in the loop.
+  for (int u = tid; u < 2 * WN_BUF / 4; u += NT_) reinterpret_cast<f32x4 *>(wn_lds)[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
   __syncthreads();                               // zero fill done
   store_rows(wn_lds, 0);
   load_rows(1, 1);
