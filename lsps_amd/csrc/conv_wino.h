@@ -146,6 +146,10 @@ __global__ __launch_bounds__(256 * NWK, 2 / NWK) void wino_f3x3_kernel(WinoParam
     const int xcd = lin & 7, q = lin >> 3;
     mt = xcd & 3;
     tile = (xcd >> 2) * (p.NT >> 1) + q;
+  } else if (MT == 8 && (p.NT & 3) == 0) {       // 32-channel slices: four per XCD (2 MB of U), a quarter of the tiles
+    const int xcd = lin & 7, q = lin >> 3;
+    mt = 4 * (xcd & 1) + (q & 3);
+    tile = (xcd >> 1) * (p.NT >> 2) + (q >> 2);
   } else if (MT == 8) {                          // one slice per XCD, every XCD streams all pixel tiles
     mt = lin & 7;
     tile = lin >> 3;

@@ -321,7 +321,7 @@ static int run_wino(const float *in, const float *W, const float *bias, float *o
   p.slope = slope;
   // 64-channel workgroups (512 threads, one per CU) when they fill the chip; otherwise 32-channel ones (256 threads,
   // two per CU): twice the workgroups, and a workgroup's barriers / prologue / epilogue overlap with its neighbour's
-  // MFMAs (N = 8: 0.067 vs 0.095 ms; at N = 256 the wide one wins 1.276 vs 1.295: half the input re-reads)
+  // MFMAs (N = 8: 0.067 vs 0.095 ms; at N = 256 the wide one wins, 1.27 vs 1.31 ms)
   if ((long)p.NT * (M / 64) > 256)
     hipLaunchKernelGGL(wino_f3x3_kernel<2>, dim3(p.NT * (M / 64)), dim3(512), WN_LDS_BYTES(2), st, p);
   else
