@@ -59,7 +59,9 @@ int         lsps_get_math_mode(void);
  * environment variable LSPS_WINO); 2 = Winograd for every eligible shape (forward / dgrad: H % 8 == 0, C % 16 == 0, K % 64 == 0; weight gradient: H >= 4 even,
  * C % 64 == 0, K % 64 == 0).
  * Winograd results differ from the direct kernel by f32 round-off (~5e-7 relative, same size as the direct kernel's
- * own distance from an f64 convolution); bf16 / split math modes are not affected.                      */
+ * own distance from an f64 convolution); bf16 / split math modes are not affected.  Non-finite inputs: the transforms
+ * add and subtract neighbouring pixels before multiplying, so an Inf in a tile can surface as NaN in that tile's
+ * outputs where the direct kernel would give Inf (finite data are unaffected).                            */
 int         lsps_set_winograd(int mode);
 int         lsps_get_winograd(void);
 
