@@ -14,16 +14,19 @@ namespace lsps {
 // Everything is fused in one kernel, nothing transformed ever goes to HBM:
 //   U = G g G^T        once per weight tensor by wino_pack_kernel (cached with the other packed panels)
 //   V = B^T d B        per lane, in registers, from the raw input rows staged in LDS (the same "raw rows + zero halo"
-//                      staging as the direct kernel): 16 LDS floats -> 32 add/sub -> the B operands of 16 MFMAs
-//   M_p += U_p V_p     v_mfma_f32_32x32x2_f32, one accumulator tile (32 k x 32 tiles) per position p: 256 accumulator
-//                      registers per lane, so one wave per SIMD (launch bounds 256,1) with the accumulators in AGPRs
-//   Y = A^T M A        in registers in the epilogue (a lane holds all 16 positions of its (k, tile) pairs)
+//                      staging as the direct kernel), on packed f32 VALU ops
+//   M_p += U_p V_p     v_mfma_f32_32x32x2_f32, one accumulator tile (32 k x 32 tiles) per position p; the A operands
+//                      (U) go global / L2 -> registers, fetched 4 k-steps ahead, and never pass through LDS
+//   Y = A^T M A        in registers in the epilogue
 //
-// Workgroup: 64 output channels x 64 tiles (8 output rows x 32 columns), waves 2 (k) x 2 (tile rows); a wave's 32
-// tiles are 2 tile rows x 16 tile columns.  MFMA operand layout (32x32x2): lane l holds A[k = l%32][c = l/32] and
-// B[c = l/32][tile = l%32], so lane l transforms ONE tile of ONE channel per k-step and feeds all 16 positions.
-// LDS per k-step and wave: 4 ds_read_b128 (U) + 8 ds_read_b64 (raw rows) for 16 MFMAs (1024 matrix-pipe cycles).
-// Row stride 48 floats: two tile rows apart = 96 floats = 32 banks, so the 32 lanes of a half-wave (2 tile rows x
+// Workgroup: 64 output channels x 64 tiles (8 output rows x 32 columns), 8 waves = 2 (k) x 2 (tile rows) x 2 (halves of
+// the 16 positions: rows 2wp, 2wp+1 of the 4x4 grid).  All 16 positions in one wave would need 256 accumulator
+// registers = one wave per SIMD, and with a single in-order wave every non-MFMA instruction costs its issue time
+// (first version: 187 TFLOP/s); 8 positions = 128 accumulators leave two waves per SIMD.  The two halves' partial 2x2
+// output tiles are added through LDS in the epilogue.  A wave's 32 tiles are 2 tile rows x 16 tile columns.
+// MFMA operand layout (32x32x2): lane l holds A[k = l%32][c = l/32] and B[c = l/32][tile = l%32], so lane l transforms
+// ONE tile of ONE channel per k-step.  LDS per k-step and wave: six ds_read_b64 (three raw rows) for 8 MFMAs.
+// Row stride 48 floats: two tile rows apart = 96 floats = 32 banks, so the 32 lanes of a ds_read_b64 group (2 tile rows x
 // 16 tile columns x 8 B) cover all 64 banks exactly once.
 // -------------------------------------------------------------------------------------------
 #define WN_CC 8                          // channels per U chunk (4 k-steps)
