@@ -534,3 +534,42 @@ def test_winograd_inside_weight_cache_scope():
         assert _rel(y3, 2.0 * y0) < 1e-6
     finally:
         ops.set_winograd(prev)
+
+
+def test_conv3x3_winograd_random_shapes_against_direct():
+    """Seeded random eligible shapes: Winograd forward, dgrad and weight gradient against the direct kernels
+    (both through the C-ABI; round-off apart they compute the same thing)."""
+    _need_gpu()
+    from lsps_amd import _lib, ops
+    L = _lib.lib()
+    st = _lib.stream()
+    rng = np.random.RandomState(1234)
+    prev = ops.get_winograd()
+    try:
+        for it in range(16):
+            N = int(rng.randint(1, 12))
+            C = 64 * int(rng.randint(1, 4))
+            K = 64 * int(rng.randint(1, 4))
+            H = 8 * int(rng.randint(1, 5))
+            x = _rand(N, C, H, 32, seed=100 + it).cuda()
+            w = _rand(K, C, 3, 3, seed=200 + it, scale=0.1).cuda()
+            b = _rand(K, seed=300 + it, scale=0.1).cuda()
+            gy = _rand(N, K, H, 32, seed=400 + it).cuda()
+            ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, 32, K, 3, 3, 1, 1), x.device)
+            res = {}
+            for mode in ('off', 'always'):
+                ops.set_winograd(mode)
+                y = torch.empty(N, K, H, 32, device='cuda')
+                dx = torch.empty_like(x)
+                dw = torch.empty_like(w)
+                _lib.check(L.lsps_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, C, H, 32, K, 3, 3, 1, 1,
+                                             ops.ACT_LRELU, 0.2, ws, wsb, st), 'fwd')
+                _lib.check(L.lsps_conv2d_dgrad(_lib.ptr(gy), _lib.ptr(w), _lib.ptr(dx), N, C, H, 32, K, 3, 3, 1, 1, ws, wsb,
+                                               st), 'dgrad')
+                _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), None, N, C, H, 32, K, 3, 3, 1, 1, ws,
+                                               wsb, st), 'wgrad')
+                res[mode] = (y, dx, dw)
+            for a, d, name in zip(res['always'], res['off'], ('y', 'dx', 'dw')):
+                assert _rel(a, d) < 3e-5, (it, N, C, K, H, name, _rel(a, d))
+    finally:
+        ops.set_winograd(prev)
