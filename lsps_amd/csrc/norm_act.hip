@@ -202,9 +202,19 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float *__restri
   if (e1 > total) e1 = total;
   float s = 0.f;
   if ((HW & 3) == 0) {
-    for (long e = e0 + (long)threadIdx.x * 4; e < e1; e += 1024) {
-      const long n = e / HW;
-      const long off = (n * C + c) * HW + (e - n * HW);
+    // (n, p) = (e / HW, e % HW) advanced incrementally: one 64-bit division per thread instead of one per float4
+    long e = e0 + (long)threadIdx.x * 4;
+    long n = e / HW;
+    int p = (int)(e - n * HW);
+    const int dn = 1024 / HW, dp = 1024 - dn * HW;
+    for (; e < e1; e += 1024) {
+      const long off = (n * C + c) * HW + p;
+      n += dn;
+      p += dp;
+      if (p >= HW) {
+        p -= HW;
+        ++n;
+      }
       const float4 d = *reinterpret_cast<const float4 *>(dy + off);
       const float4 o = *reinterpret_cast<const float4 *>(out + off);
       float4 r;
