@@ -202,12 +202,13 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float *__restri
   if (e1 > total) e1 = total;
   float s = 0.f;
   if ((HW & 3) == 0) {
-    // (n, p) = (e / HW, e % HW) advanced incrementally: one 64-bit division per thread instead of one per float4
+    // (n, p) = (e / HW, e % HW) advanced incrementally: one 64-bit division per thread instead of one per float4;
+    // two float4 per iteration so that four loads are in flight per thread (four per iteration measured slower: 4.9 vs 5.1 TB/s)
     long e = e0 + (long)threadIdx.x * 4;
     long n = e / HW;
     int p = (int)(e - n * HW);
     const int dn = 1024 / HW, dp = 1024 - dn * HW;
-    for (; e < e1; e += 1024) {
+    auto next_off = [&]() {
       const long off = (n * C + c) * HW + p;
       n += dn;
       p += dp;
@@ -215,8 +216,9 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float *__restri
         p -= HW;
         ++n;
       }
-      const float4 d = *reinterpret_cast<const float4 *>(dy + off);
-      const float4 o = *reinterpret_cast<const float4 *>(out + off);
+      return off;
+    };
+    auto bwd = [&](float4 d, float4 o) {
       float4 r;
       if (kind == LSPS_ACT_LRELU) {
         r.x = o.x > 0.f ? d.x : d.x * slope;
@@ -229,6 +231,21 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float *__restri
         r.z = d.z * (1.f - o.z * o.z);
         r.w = d.w * (1.f - o.w * o.w);
       }
+      return r;
+    };
+    for (; e + 1024 < e1; e += 2048) {
+      const long off0 = next_off(), off1 = next_off();
+      const float4 d0 = *reinterpret_cast<const float4 *>(dy + off0), o0 = *reinterpret_cast<const float4 *>(out + off0);
+      const float4 d1 = *reinterpret_cast<const float4 *>(dy + off1), o1 = *reinterpret_cast<const float4 *>(out + off1);
+      const float4 r0 = bwd(d0, o0), r1 = bwd(d1, o1);
+      *reinterpret_cast<float4 *>(dx + off0) = r0;
+      *reinterpret_cast<float4 *>(dx + off1) = r1;
+      s += (r0.x + r0.y) + (r0.z + r0.w);          // same summation order as one float4 per iteration
+      s += (r1.x + r1.y) + (r1.z + r1.w);
+    }
+    if (e < e1) {
+      const long off = next_off();
+      const float4 r = bwd(*reinterpret_cast<const float4 *>(dy + off), *reinterpret_cast<const float4 *>(out + off));
       *reinterpret_cast<float4 *>(dx + off) = r;
       s += (r.x + r.y) + (r.z + r.w);
     }
