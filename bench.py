@@ -4,8 +4,9 @@
 A "step" = one pretrain iteration of depth_train.py's hot loop (reference
 src/depth_train.py:152-160): `dis_update` then `gen_update` of LSPSTrainer on one synthetic
 NYU-shape batch of 128 depth crops per domain (enc + dec + discriminator + KL / L1 / GAN losses,
-forward + dgrad + wgrad + Adam), all through the HIP kernels.  With --gpus N (launched by
-torch.distributed.run, one process per GPU) every rank runs 128 samples per domain (weak
+forward + dgrad + wgrad + Adam), all through the HIP kernels.  With --gpus N (one process per GPU: started by
+torch.distributed.run, or by this script itself when it is run as plain `python bench.py --gpus N`)
+every rank runs 128 samples per domain (weak
 scaling: global batch 128*N) and gradients are all-reduced over RCCL.  The unit of work is ONE
 bs=128 step; `value` = units all ranks processed / time = N * K / elapsed (whole-job aggregate,
 grows with N under weak scaling); `ms_per_step` = wall time of one global iteration.
@@ -41,38 +42,95 @@ def make_device_batch(n, device, seed_offset=0, label_dim=108):
     return dict(xa=t(xa), la=t(la), ca=t(ca), xb=t(xb), lb=t(lb), cb=t(cb))
 
 
-def cpu_baseline(hp, target_seconds=15.0):
-    """The oracle (CPU restatement of the reference, literal backward scope) timed on this host's cores
-    on a bounded sample of the same workload: one pretrain step at a reduced batch, scaled per sample."""
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(hp, pretrain_batch=16, timed=3):
+    """The oracle (CPU restatement of the reference, literal backward scope: it back-propagates into the generator in
+    dis_update / post_update and computes the discriminator weight gradients in gen_update exactly like the reference)
+    timed on this host's physical cores, as BASELINE.md section 3 prescribes: 1 warm-up + `timed` steps, min and median;
+      * pretrain step (dis_update + gen_update, the headline workload) at a reduced batch, scaled linearly to bs=128
+        (flagged as an extrapolation: bs=128 needs ~50 GB and ~3 min per step on 8 cores);
+      * the literal estimate3 step, post_update(mode=3), at bs=128 DIRECTLY (no extrapolation)."""
+    import statistics
     import torch
     from oracle import lsps_ref
     from lsps_amd import synth
-    threads = max(1, (os.cpu_count() or 2) // 2)          # physical cores
+    threads = max(1, (os.cpu_count() or 2) // 2)          # physical cores (SMT siblings do not help oneDNN convs)
     torch.set_num_threads(threads)
     tr = lsps_ref.RefTrainer(hp, literal=True)
     for net, shapes, seed in ((tr.gen, lsps_ref.gen_shapes(hp['gen']), 1), (tr.dis, lsps_ref.dis_shapes(hp['dis']), 2),
                               (tr.vae, lsps_ref.vae_shapes(hp['vae']), 3)):
         net.load_state_dict(synth.make_state_dict(shapes, seed))
+    T = torch.as_tensor
+    dim = hp['vae']['input_dim']
 
-    def step(n):
-        xa, la, ca = synth.make_batch(n, synth.YAML_SEED)
-        xb, lb, cb = synth.make_batch(n, synth.YAML_SEED + 1)
-        T = torch.as_tensor
+    def batch(n):
+        xa, la, ca = synth.make_batch(n, synth.YAML_SEED, dim)
+        xb, lb, cb = synth.make_batch(n, synth.YAML_SEED + 1, dim)
+        return [T(v) for v in (xa, la, xb, lb, ca, cb)]
+
+    def pretrain(b):
         t0 = time.time()
-        tr.dis_update(T(xa), T(la), T(xb), T(lb), T(ca), T(cb), hp)
-        tr.gen_update(T(xa), T(la), T(xb), T(lb), hp)
+        tr.dis_update(b[0], b[1], b[2], b[3], b[4], b[5], hp)
+        tr.gen_update(b[0], b[1], b[2], b[3], hp)
         return time.time() - t0
 
-    step(2)                                                # warm-up (thread pools, oneDNN primitives)
-    t4 = step(4)
-    n = int(max(4, min(32, 4 * round(target_seconds / max(t4, 1e-3) / 1.0))))
-    n = max(4, (n // 4) * 4)
-    times = [step(n) for _ in range(2)] if n > 4 else [t4, step(4)]
-    t = min(times)
-    return dict(value=(1.0 / t) * (n / 128.0), unit='steps/s', cores=threads, kind='port',
-                sample='1 warm-up + %d timed pretrain steps (dis_update+gen_update, literal reference backward scope) at '
-                       'bs=%d per domain, %.2f s/step min; scaled linearly to bs=128 (x %d/128); torch %s CPU, %d threads'
-                       % (len(times), n, t, n, torch.__version__, threads))
+    def estimate3(b):
+        t0 = time.time()
+        tr.post_update(b[0], b[1], b[2], b[3], b[4], b[5], 3, hp)
+        return time.time() - t0
+
+    small = batch(2)
+    pretrain(small)                                        # warm-up (thread pools, oneDNN primitives)
+    estimate3(small)
+    n = pretrain_batch
+    b = batch(n)
+    t_first = pretrain(b)                                  # warm-up at the timed shape
+    if t_first > 12.0:                                     # slow host: keep the whole leg within ~1 minute
+        n, b = 8, batch(8)
+        pretrain(b)
+    tp = [pretrain(b) for _ in range(timed)]
+    b128 = batch(128)
+    estimate3(b128)
+    te = [estimate3(b128) for _ in range(timed)]
+    return dict(value=(1.0 / min(tp)) * (n / 128.0), unit='steps/s', cores=threads, kind='port', cpu_model=_cpu_model(),
+                extrapolated=True,
+                pretrain={'batch_per_domain': n, 'timed_steps': len(tp), 'min_s': min(tp), 'median_s': statistics.median(tp),
+                          'steps_per_s_at_bs128_linear_extrapolation': (1.0 / min(tp)) * (n / 128.0)},
+                estimate3_bs128={'timed_steps': len(te), 'min_s': min(te), 'median_s': statistics.median(te),
+                                 'steps_per_s': 1.0 / min(te), 'extrapolated': False},
+                sample='oracle/lsps_ref.py RefTrainer(literal=True), torch %s CPU, %d threads on %s: 1 warm-up + %d timed '
+                       'pretrain steps (dis_update+gen_update) at bs=%d per domain, min %.2f s / median %.2f s, scaled '
+                       'linearly to bs=128 (x %d/128) = `value` (EXTRAPOLATED); plus 1 warm-up + %d timed estimate3 steps '
+                       '(post_update mode 3) at bs=128 directly, min %.2f s / median %.2f s'
+                       % (torch.__version__, threads, _cpu_model(), len(tp), n, min(tp), statistics.median(tp), n, len(te),
+                          min(te), statistics.median(te)))
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one process per GPU, and pass
+    the ranks' output through (rank 0 prints the JSON line last)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env['LSPS_BENCH_SELF_LAUNCHED'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -87,28 +145,53 @@ def main():
                     help="exps/<exp>.yaml: 'nicvl' with --dtype bf16 --batch 256 is BASELINE config 5 on one GPU")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary workloads (estimate3, fwd-only)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="'nccl' = RCCL, one GPU per rank (default); 'gloo': ranks may SHARE a GPU (local_rank %% device count) "
+                         "- the data-parallel machinery on a 1-GPU box, not a performance number")
+    ap.add_argument('--selftest-launch', action='store_true',
+                    help='(no GPU needed) only rendezvous over gloo on CPU, all-reduce once and print {"n_ranks": N}')
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one process per GPU)" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    if world > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29517')
+    if args.selftest_launch:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({'n_ranks': int(t.item()), 'world_size': dist.get_world_size()}), flush=True)
+        dist.destroy_process_group()
+        return
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == 'nccl' else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    n_ranks = 1
     if world > 1 or os.environ.get('LSPS_FORCE_DP') == '1':
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29517')
-        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                      # the rank count as the collective library itself sees it
+        n_ranks = int(probe.item())
 
     import lsps_amd.trainers as trainers
     from lsps_amd import ops, synth
 
     hp = load_hp(args.exp)
     tr = trainers.LSPSTrainer(hp)
-    tr.cuda(local_rank)
+    tr.cuda(dev_index)
     for net, seed in ((tr.gen, 1), (tr.dis, 2), (tr.vae, 3)):      # seeded weights, shapes from the nets' own state dicts
         shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
         net.load_state_dict({k: torch.as_tensor(v) for k, v in synth.make_state_dict(shapes, seed).items()})
@@ -128,6 +211,8 @@ def main():
 
     for _ in range(args.warmup):
         pretrain_step()
+    for r_ in tr._reducers.values():
+        r_.take_stats()                 # count the gradient exchange of the timed region only
     ops.profiler.reset()
     ops.profiler.enabled = os.environ.get('LSPS_BENCH_NO_EVENTS') != '1'   # debugging aid: time without the HIP events
     barrier()
@@ -142,31 +227,57 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = ops.profiler.summary()
+    # gradient exchange inside the timed region: buckets all-reduced, how many were launched DURING backward, and the time
+    # the launch stream stalled on RCCL in finish() (HIP events around the waits) = the exposed (non-overlapped) part
+    dp_stats = None
+    if dist.is_initialized():
+        rs = {k: r.take_stats() for k, r in tr._reducers.items() if k in ('dis', 'gen')}
+        dp_stats = {'backend': 'rccl' if args.backend == 'nccl' else 'gloo',
+                    'bucket_mib': int(os.environ.get('LSPS_BUCKET_BYTES', 32 << 20)) / float(1 << 20),
+                    'allreduce_exposed_ms_per_step': sum(r['exposed_ms'] for r in rs.values()) / args.steps,
+                    'allreduce_mb_per_step': sum(r['bytes'] for r in rs.values()) / args.steps / 1e6,
+                    'per_update': {('dis_update' if k == 'dis' else 'gen_update'): {
+                        'buckets_per_step': r['buckets'] / max(r['steps'], 1),
+                        'launched_during_backward_per_step': r['early'] / max(r['steps'], 1),
+                        'exposed_ms_per_step': r['exposed_ms'] / max(r['steps'], 1)} for k, r in rs.items()}}
+
+    def timed(fn, k):
+        fn()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        barrier()
+        return (time.perf_counter() - t1) / k
 
     extra = {}
+    if not args.no_extra and world > 1:
+        # the literal wording of BASELINE's metric (`estimate3` step) under data parallelism: 128 samples per domain per
+        # rank, discriminator gradients all-reduced, the global first-4 feature term broadcast (lsps_trainer.post_update)
+        t_est = timed(lambda: tr.post_update(b['xa'], b['la'], b['xb'], b['lb'], b['ca'], b['cb'], 3, hp), 10)
+        te = torch.tensor([t_est], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        t_est = float(te.item())
+        r = tr._reducers['dis'].take_stats()
+        extra = {'estimate3_step_bs%d_per_gpu' % args.batch: {
+            'steps_per_s': world / t_est, 'ms_per_step': 1e3 * t_est, 'n_gpus': world,
+            'buckets_per_step': r['buckets'] / max(r['steps'], 1),
+            'launched_during_backward_per_step': r['early'] / max(r['steps'], 1),
+            'allreduce_exposed_ms_per_step': r['exposed_ms'] / max(r['steps'], 1)}}
     if not args.no_extra and world == 1:
-        def timed(fn, k):
-            fn()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(k):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t1) / k
-        t_est = timed(lambda: tr.post_update(b['xa'], b['la'], b['xb'], b['lb'], b['ca'], b['cb'], 3, hp), 5)
+        t_est = timed(lambda: tr.post_update(b['xa'], b['la'], b['xb'], b['lb'], b['ca'], b['cb'], 3, hp), 10)
         tr.gen.eval()
         with torch.no_grad():
             t_fwd = timed(lambda: tr.gen(b['xa'], b['xb']), 3)
         tr.gen.train()
-        t_bf16 = t_split = None
+        t_bf16 = None
         if args.dtype == 'f32':         # BASELINE config 5 (bf16 MFMA conv path) on the same workload, for reference
             ops.set_math_mode('bf16')
             t_bf16 = timed(pretrain_step, 2)
-            ops.set_math_mode('f32_split')
-            t_split = timed(pretrain_step, 2)
             ops.set_math_mode('f32')
         extra = {'estimate3_step_bs%d' % args.batch: {'steps_per_s': 1.0 / t_est, 'ms_per_step': 1e3 * t_est,
-                                                       'algorithmic_tflop_per_step': 0.579 * args.batch / 128.0},
+                                                       'algorithmic_tflop_per_step': 0.579 * args.batch / 128.0,
+                                                       'mfma_floor_ms': 0.579 * args.batch / 128.0 / F32_MFMA_PEAK_TFLOPS * 1e3},
                  'gen_forward_bs%d' % args.batch: {'calls_per_s': 1.0 / t_fwd, 'ms_per_call': 1e3 * t_fwd,
                                                    'tflops': 7.76 * args.batch / 128.0 / t_fwd}}
         if t_bf16:
@@ -174,10 +285,6 @@ def main():
                 'steps_per_s': 1.0 / t_bf16, 'ms_per_step': 1e3 * t_bf16,
                 'note': 'residual 3x3 convs on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 when staged into LDS, f32 '
                         'accumulate, f32 tensors/statistics/Adam); NOT the headline value'}
-            extra['pretrain_step_f32_split_bs%d' % args.batch] = {
-                'steps_per_s': 1.0 / t_split, 'ms_per_step': 1e3 * t_split,
-                'note': 'experimental: 3x3 residual convs with f32-accurate products from 3 bf16 limbs per operand and 6 '
-                        'bf16 MFMAs (error vs fp64 <= exact-f32 MFMA); NOT the headline value'}
 
     if rank == 0:
         peak = F32_MFMA_PEAK_TFLOPS if args.dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
@@ -219,7 +326,7 @@ def main():
         out = {
             'metric': 'depth_train steps/sec (128x128x1, bs=128)', 'value': world * args.steps / elapsed,
             'unit': 'steps/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'n_gpus': world, 'n_ranks': n_ranks, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'pretrain step = LSPSTrainer.dis_update + gen_update (enc+dec+disc+KL), exps/%s.yaml nets ' % args.exp +
                                    '(gen.ch=64, dis.ch=64), synthetic NYU-shape 128x128x1 depth crops',
@@ -228,11 +335,14 @@ def main():
                        'unit_of_work': 'one bs=%d step; value = n_gpus * steps / time (aggregate over ranks)' % args.batch, 'algorithmic_tflop_per_step_per_gpu': 50.0 * args.batch / 128.0},
             'step_tflops_per_gpu': 50.0 * args.batch / 128.0 / (elapsed / args.steps),
             'global_iterations_per_s': args.steps / elapsed,
-            'roofline': roofline, 'other_workloads': extra,
+            'roofline': roofline, 'data_parallel': dp_stats, 'other_workloads': extra,
         }
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(hp)
-            out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
+            out['cpu_baseline'] = cb = cpu_baseline(hp)
+            out['speedup_vs_cpu_baseline'] = out['value'] / cb['value']
+            est = extra.get('estimate3_step_bs%d' % args.batch)
+            if est and args.batch == 128:      # the one comparison with no extrapolation on either side
+                out['estimate3_speedup_vs_cpu_baseline'] = est['steps_per_s'] / cb['estimate3_bs128']['steps_per_s']
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:

@@ -38,6 +38,11 @@ int         lsps_version(void);
 const char *lsps_last_error(void);
 /* number of compute units of the current device (used by callers to size split counts) */
 int         lsps_device_cus(void);
+/* Name of the main compute kernel the most recent conv / convT call OF THIS THREAD dispatched to (e.g. "wino4_f3x3_kernel",
+ * "igemm_f_kernel<2,2,2,2>"), and in *launches (may be NULL) the number of main-kernel launches since the previous call of
+ * this function.  No reference counterpart (torch dispatches inside cuDNN): it exists so that profilers and tests read the
+ * dispatch instead of mirroring it (bench.py `roofline.per_kernel`, tests/test_parity_gpu.py). */
+const char *lsps_last_kernel(int *launches);
 
 /* Scope in which packed weight panels are cached in caller-owned device memory: between two optimizer steps the weights
  * of the reference's modules do not change, yet one update method runs the same nn.Conv2d several times (sub-batches,

@@ -20,6 +20,7 @@ _SIGNATURES = {
     'lsps_version': (c_int, []),
     'lsps_last_error': (c_char_p, []),
     'lsps_device_cus': (c_int, []),
+    'lsps_last_kernel': (c_char_p, [_P]),
     'lsps_set_math_mode': (c_int, [c_int]),
     'lsps_set_winograd': (c_int, [c_int]),
     'lsps_get_winograd': (c_int, []),

@@ -53,6 +53,16 @@ void set_error(const char *fmt, ...) {
 // -------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------
+// What the dispatcher actually launched (lsps_last_kernel): the main compute kernel of the most recent conv call of this
+// thread and the number of main launches since the previous query.  Profilers and tests read the dispatch from here
+// instead of mirroring the *_ok() predicates.
+static thread_local const char *g_last_kernel = "";
+static thread_local int g_last_launches = 0;
+static void note_kernel(const char *name) {
+  g_last_kernel = name;
+  ++g_last_launches;
+}
+
 static unsigned magic_for(int T) { return T <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)T + 1ull); }
 
 // tile configs: 0: 128x128, 1: 64x256, 2: 32x256, 3: 128x64, 4: 64x64 (the last two for small pixel counts:
@@ -206,6 +216,9 @@ static int launch_f(const FParams &p, int cfg, hipStream_t st) {
     LSPS_LAUNCH_F(1, 1, 2, 2);
 #undef LSPS_LAUNCH_F
   LSPS_CHECK_LAUNCH("igemm_f");
+  static const char *const names[5] = {"igemm_f_kernel<2,2,2,2>", "igemm_f_kernel<2,2,1,4>", "igemm_f_kernel<1,2,1,4>",
+                                       "igemm_f_kernel<1,2,4,1>", "igemm_f_kernel<1,1,2,2>"};
+  note_kernel(names[cfg < 0 || cfg > 4 ? 4 : cfg]);
   return 0;
 }
 
@@ -327,6 +340,7 @@ static int run_wino(const float *in, const float *W, const float *bias, float *o
   else
     hipLaunchKernelGGL(wino_f3x3_kernel<1>, dim3(p.NT * (M / 32)), dim3(256), WN_LDS_BYTES(1), st, p);
   LSPS_CHECK_LAUNCH("wino_f3x3");
+  note_kernel("wino_f3x3_kernel");
   return 0;
 }
 
@@ -392,6 +406,7 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
     else
       hipLaunchKernelGGL((igemm_f3x3_bf16_kernel<4, 256>), grid2, dim3(256), 0, st, q);
     LSPS_CHECK_LAUNCH("igemm_f3x3_bf16");
+    note_kernel("igemm_f3x3_bf16_kernel");
     return 0;
   }
   if (g_math_mode != 0) {                  // bf16 / split-precision variants: weights pre-converted to bf16 limb planes
@@ -449,6 +464,7 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
         hipLaunchKernelGGL((igemm_f3x3_split_kernel<2, 1>), grid2, dim3(256), 0, st, q);
     }
     LSPS_CHECK_LAUNCH("igemm_f3x3_split");
+    note_kernel("igemm_f3x3_split_kernel");
     return 0;
   }
   if (wino_ok(N, Cin, H, M))
@@ -493,6 +509,7 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
       grid.z = ks;
       hipLaunchKernelGGL((igemm_f3x3_kernel<2, true>), grid, dim3(256), 0, st, p);
       LSPS_CHECK_LAUNCH("igemm_f3x3");
+      note_kernel("igemm_f3x3_kernel");
       hipLaunchKernelGGL(f3x3_ksplit_reduce_kernel, dim3(ceil_div(total / 4, 256)), dim3(256), 0, st, (const float *)p.part,
                          bias, addend, out, total / 4, ks, M, H * 32, act, slope);
       LSPS_CHECK_LAUNCH("f3x3_ksplit_reduce");
@@ -504,6 +521,7 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   else
     hipLaunchKernelGGL((igemm_f3x3_kernel<2, false>), grid, dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_f3x3");
+  note_kernel("igemm_f3x3_kernel");
   return 0;
 }
 
@@ -563,6 +581,7 @@ static int run_f3x3s2(const float *in, const float *W, const float *bias, float 
     q.slope = slope;
     hipLaunchKernelGGL(igemm_f3x3s2_bf16_kernel, dim3(N * q.tiles_per_img, Mp2 / 128), dim3(256), 0, st, q);
     LSPS_CHECK_LAUNCH("igemm_f3x3s2_bf16");
+    note_kernel("igemm_f3x3s2_bf16_kernel");
     return 0;
   }
   const int RED = Cb * 9;
@@ -594,6 +613,7 @@ static int run_f3x3s2(const float *in, const float *W, const float *bias, float 
   else
     hipLaunchKernelGGL(igemm_f3x3s2_kernel<false>, dim3(N * p.tiles_per_img, Mp / 128), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_f3x3s2");
+  note_kernel("igemm_f3x3s2_kernel");
   return 0;
 }
 
@@ -633,6 +653,7 @@ static int run_c1_fwd(const float *in, const float *W, const float *bias, float 
   hipLaunchKernelGGL(c1_fwd_kernel, dim3(Hs / tp, ceil_div(M, 64), N), dim3(256),
                      C1_FIXED_LDS + (size_t)p.rows * p.LW * sizeof(float), st, p);
   LSPS_CHECK_LAUNCH("c1_fwd");
+  note_kernel("c1_fwd_kernel");
   return 0;
 }
 
@@ -765,6 +786,7 @@ static int run_t3x3s2(const float *in, const float *W, const float *bias, float 
       hipLaunchKernelGGL(igemm_t3x3s2_bf16_kernel<64>, dim3(N * q.tiles_per_img, ceil_div(M, 64), 2), dim3(256), 0, st, q);
     }
     LSPS_CHECK_LAUNCH("igemm_t3x3s2_bf16");
+    note_kernel("igemm_t3x3s2_bf16_kernel");
     return 0;
   }
   const size_t need = class_bytes(RED, Mp);
@@ -805,6 +827,7 @@ static int run_t3x3s2(const float *in, const float *W, const float *bias, float 
       hipLaunchKernelGGL((igemm_t3x3s2_kernel<64, false>), grid, dim3(256), 0, st, p);
   }
   LSPS_CHECK_LAUNCH("igemm_t3x3s2");
+  note_kernel("igemm_t3x3s2_kernel");
   return 0;
 }
 
@@ -970,6 +993,7 @@ static int run_wino_w(const float *dy, const float *x, float *dW, int N, int C, 
   p.per_split = ceil_div(p.ntr, splits);
   hipLaunchKernelGGL(wino_w3x3_kernel, dim3(C / 64, M / 64, splits), dim3(512), WW_LDS_BYTES, st, p);
   LSPS_CHECK_LAUNCH("wino_w3x3");
+  note_kernel("wino_w3x3_kernel");
   hipLaunchKernelGGL(wino_w3x3_reduce_kernel, dim3(ceil_div((long)M * C, 256)), dim3(256), 0, st, (const float *)p.part, dW,
                      M * C, splits);
   LSPS_CHECK_LAUNCH("wino_w3x3_reduce");
@@ -1009,6 +1033,7 @@ static int run_w3x3(const float *dy, const float *x, float *dW, int N, int C, in
   else
     hipLaunchKernelGGL(igemm_w3x3_kernel<0>, dim3(C / 64, M / 64, splits), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_w3x3");
+  note_kernel("igemm_w3x3_kernel");
   const long total = (long)M * C * 9;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float *)p.part, dW, total,
                      splits);
@@ -1079,6 +1104,7 @@ static int run_w3x3s2(const float *small, const float *big, float *dW, int N, in
   else
     hipLaunchKernelGGL(igemm_w3x3s2_kernel<false>, dim3(C / 64, M / 128, splits), dim3(512), WS2_LDS_BYTES, st, p);
   LSPS_CHECK_LAUNCH("igemm_w3x3s2");
+  note_kernel("igemm_w3x3s2_kernel");
   const long total = (long)M * C * 9;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float *)p.part, dW, total,
                      splits);
@@ -1125,6 +1151,7 @@ static int run_c1_wgrad(const float *small, const float *big, float *dW, int N, 
   p.part = (float *)ws;
   hipLaunchKernelGGL(c1_wgrad_kernel, dim3(blocks), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("c1_wgrad");
+  note_kernel("c1_wgrad_kernel");
   const long nW = (long)Cs * R * S;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(nW, 256)), dim3(256), 0, st, (const float *)p.part, dW, nW, blocks);
   LSPS_CHECK_LAUNCH("reduce_partials");
@@ -1203,6 +1230,7 @@ static int run_wgrad(const float *small, const float *big, float *dW, int N, int
       hipLaunchKernelGGL((igemm_w_kernel<2, false>), grid, dim3(256), 0, st, p);
   }
   LSPS_CHECK_LAUNCH("igemm_w");
+  note_kernel("igemm_w_kernel");
   if (splits > 1) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(nW, 256)), dim3(256), 0, st, (const float *)p.part, dW, nW,
                        splits);
@@ -1289,6 +1317,12 @@ extern "C" {
 
 int lsps_version(void) { return LSPS_ABI_VERSION; }
 const char *lsps_last_error(void) { return lsps::g_err; }
+
+const char *lsps_last_kernel(int *launches) {
+  if (launches) *launches = lsps::g_last_launches;
+  lsps::g_last_launches = 0;
+  return lsps::g_last_kernel;
+}
 
 int lsps_set_math_mode(int mode) {
   if (mode < 0 || mode > 2) {
@@ -1439,6 +1473,7 @@ int lsps_convT2d_fwd(const float *x, const float *w, const float *bias, float *y
     hipLaunchKernelGGL(pw1_fwd_kernel, dim3(ceil_div((long)N * HW4, 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                        y, N, Ci, HW4, act, slope);
     LSPS_CHECK_LAUNCH("pw1_fwd");
+    note_kernel("pw1_fwd_kernel");
     return 0;
   }
   // out channel m = co: W[ci][co][r][s] -> sm = R*S ; reduction channel ci -> sc = Co*R*S
@@ -1457,6 +1492,7 @@ int lsps_convT2d_dgrad(const float *dy, const float *w, float *dx, int N, int Ci
     hipLaunchKernelGGL(pw1_dgrad_kernel, dim3(ceil_div((long)N * HW4, 256)), dim3(256), 0, (hipStream_t)stream, dy, w, dx,
                        N, Ci, HW4);
     LSPS_CHECK_LAUNCH("pw1_dgrad");
+    note_kernel("pw1_dgrad_kernel");
     return 0;
   }
   // dx[n][ci][h][w] = sum_{co,r,s} W[ci][co][r][s] dy[n][co][h*st-pad+r][w*st-pad+s]
@@ -1482,6 +1518,7 @@ int lsps_convT2d_wgrad(const float *x, const float *dy, float *dw, float *db, in
     hipLaunchKernelGGL(pw1_wgrad_kernel, dim3(Ci, (int)Sp), dim3(256), 0, (hipStream_t)stream, x, dy, part, N, Ci, HW4,
                        slice4);
     LSPS_CHECK_LAUNCH("pw1_wgrad");
+    note_kernel("pw1_wgrad_kernel");
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(Ci, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)part, dw, (long)Ci, (int)Sp);
     LSPS_CHECK_LAUNCH("pw1_wgrad_reduce");

@@ -37,9 +37,21 @@ def rank():
 
 
 class GradReducer(object):
-    """Bucketed, backward-overlapped all-reduce over a FlatArena's gradient buffer."""
+    """Bucketed, backward-overlapped all-reduce over a FlatArena's gradient buffer.
 
-    def __init__(self, arena, bucket_bytes=32 << 20, group=None):
+    Which gradients a backward pass will produce is LEARNED per step signature: the first time a signature (e.g.
+    ``('dis_update', feat_mat, train_map)``) is seen, every bucket is launched from `finish()`; the set of parameters
+    that were actually accumulated is recorded and, from the second step on, a bucket goes out the moment its last
+    expected gradient has been accumulated, i.e. DURING backward.  Parameters that never receive a gradient (conv biases
+    in front of an affine-free InstanceNorm, the `Post` head in `dis_update`, the `D` head in `post_update`, a frozen
+    discriminator) therefore neither block a bucket nor need a hand-kept list.  All ranks run the same step, so they
+    learn the same sets; a gradient that arrives for a bucket that has already gone out means the signature did not
+    determine the graph and raises instead of reducing a half-filled bucket."""
+
+    def __init__(self, arena, bucket_bytes=None, group=None):
+        import os
+        if bucket_bytes is None:           # 32 MiB: few, large messages (per-link-bound xGMI ring steps)
+            bucket_bytes = int(os.environ.get('LSPS_BUCKET_BYTES', 32 << 20))
         self.arena = arena
         self.group = group
         self.world = world()
@@ -59,51 +71,120 @@ class GradReducer(object):
         self._pending = None
         self._works = []
         self._launched = None
+        self._sig = None
+        self._learned = {}
+        self._scalars = None
+        self.stats = dict(steps=0, buckets=0, early=0, exposed_ms=0.0, bytes=0)
+        self._exposed_events = []
         self.active = active()
         if self.active:
             arena.on_grad_ready = self._on_grad_ready
 
     # ---- per-backward protocol -------------------------------------------------------------
-    def begin(self, expected=None):
-        """Call before backward.  `expected`: iterable of parameter indices that WILL get a gradient
-        (same on every rank).  With it, a bucket is launched as soon as its last expected gradient has
-        been accumulated (overlap with the rest of backward); without it, everything goes at finish()."""
+    def begin(self, sig=None, expected=None, scalars=None):
+        """Call before backward.  `sig`: hashable step signature (see class doc); `expected`: explicit iterable of
+        parameter indices that WILL get a gradient (overrides what was learned for `sig`).  `scalars`: a small device
+        tensor (the step's loss scalars) summed over ranks by one tiny all-reduce that is launched here, ahead of the
+        buckets, and hides under backward; read it back with `reduced_scalars()` after `finish()`."""
         self._works = []
         self._launched = [False] * len(self.buckets)
-        if expected is None or not self.active:
-            self._pending = None
+        self._late = False
+        self._sig = sig
+        self._scalars = None
+        self._pending = None
+        if not self.active:
+            return
+        if scalars is not None:
+            self._scalars = scalars
+            self._works.append(dist.all_reduce(scalars, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if expected is None and sig is not None:
+            expected = self._learned.get(sig)
+        if expected is None:
             return
         self._pending = [0] * len(self.buckets)
-        for i in expected:
+        self._expected = set(expected)
+        for i in self._expected:
             self._pending[self.bucket_of[i]] += 1
 
     def _on_grad_ready(self, i):
         if self._pending is None:
             return
         b = self.bucket_of[i]
+        if self._launched[b] or i not in self._expected:
+            if self._launched[b]:
+                self._late = True             # raised in finish(): raising inside an autograd hook would be swallowed
+            return
         self._pending[b] -= 1
-        if self._pending[b] == 0 and not self._launched[b]:
+        if self._pending[b] == 0:
             self._launch(b)
 
     def _launch(self, b):
         i0, i1 = self.buckets[b]
         self._launched[b] = True
-        self._works.append(dist.all_reduce(self.arena.grad_slice(i0, i1), op=dist.ReduceOp.SUM,
-                                           group=self.group, async_op=True))
+        g = self.arena.grad_slice(i0, i1)
+        self.stats['bytes'] += g.numel() * 4
+        self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Call after backward, before the optimizer step: launches what is left, waits for all."""
         if not self.active:
             return
+        if self._late:
+            raise RuntimeError("GradReducer: a gradient arrived for a bucket that was already all-reduced; the step "
+                               "signature %r does not determine which parameters get gradients" % (self._sig,))
         touched = self.arena.touched
+        early = sum(self._launched)
         for b, (i0, i1) in enumerate(self.buckets):
             # ranks agree on which buckets carry gradients because they run the same step
             if not self._launched[b] and any(touched[i0:i1]):
                 self._launch(b)
+        timed = self.arena.flat_g.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._works:
             w.wait()
+        if timed:
+            e1.record()                        # the launch stream stalls between e0 and e1 = the exposed part
+            self._exposed_events.append((e0, e1))
+        if self._sig is not None:
+            self._learned[self._sig] = tuple(i for i, t in enumerate(touched) if t)
+        self.stats['steps'] += 1
+        self.stats['buckets'] += sum(self._launched)
+        self.stats['early'] += early
+        self.last_early, self.last_buckets = early, sum(self._launched)
         self._works = []
         self._pending = None
+
+    def reduced_scalars(self):
+        """The `scalars` tensor of `begin()` averaged over ranks (valid after `finish()`); None when inactive."""
+        if self._scalars is None:
+            return None
+        return self._scalars / float(self.world)
+
+    def take_stats(self):
+        """Counters since the last call: steps, buckets all-reduced, buckets launched during backward, bytes, and the
+        time the launch stream spent waiting for RCCL in `finish()` (HIP events around the waits)."""
+        s = dict(self.stats)
+        if self._exposed_events:
+            torch.cuda.synchronize()
+            s['exposed_ms'] = sum(a.elapsed_time(b) for a, b in self._exposed_events)
+        self._exposed_events = []
+        self.stats = dict(steps=0, buckets=0, early=0, exposed_ms=0.0, bytes=0)
+        return s
+
+
+def broadcast_from_rank0(tensors, group=None):
+    """Replicas must start from the same state (weights AND Adam moments): rank 0's copy wins."""
+    if not active():
+        return
+    for t in tensors:
+        dist.broadcast(t, 0, group=group)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
 
 
 def all_reduce_mean_scalars(values, device):

@@ -4,6 +4,8 @@ PyTorch is used here for device memory, streams and the autograd tape only; ever
 op below runs in liblsps_hip.so.  Each Function names the torch built-in of the reference it
 replaces.  Inputs must be HIP float32 tensors — there is no CPU fallback (``_lib.ptr`` raises).
 """
+import ctypes as _ctypes
+
 import torch
 
 from . import _lib
@@ -18,19 +20,32 @@ def _c(t):
 
 
 class _Span(object):
-    def __init__(self, prof, key, flops, launches):
-        self.prof, self.key, self.flops, self.launches = prof, key, flops, launches
+    """Brackets ONE C-ABI conv call.  The key is the kernel name the library reports for that call (lsps_last_kernel):
+    nothing here mirrors the dispatch rules."""
+
+    def __init__(self, prof, flops):
+        self.prof, self.flops = prof, flops
 
     def __enter__(self):
-        if self.prof.enabled:
+        p = self.prof
+        if p.enabled or p.log is not None:
+            _lib.lib().lsps_last_kernel(None)       # reset the launch counter of this thread
+        if p.enabled:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()            # torch's current stream == the stream the kernels are launched on
 
     def __exit__(self, *a):
-        if self.prof.enabled:
+        p = self.prof
+        if not (p.enabled or p.log is not None) or a[0] is not None:
+            return
+        n = _ctypes.c_int(0)
+        name = _lib.lib().lsps_last_kernel(_ctypes.byref(n)).decode()
+        if p.log is not None:
+            p.log.append(name)
+        if p.enabled:
             self.e1.record()
-            self.prof.records.append((self.key, self.e0, self.e1, self.flops, self.launches))
+            p.records.append((name, self.e0, self.e1, self.flops, max(n.value, 1)))
 
 
 class Profiler(object):
@@ -40,50 +55,13 @@ class Profiler(object):
     def __init__(self):
         self.enabled = False
         self.records = []
+        self.log = None                 # kernel_log_begin(): list of dispatched kernel names
 
     def reset(self):
         self.records = []
 
-    @staticmethod
-    def f_kernel(M, cin=0, h=0, w=0, r=0, stride=0, pad=0, transposed=False, n=0):
-        """Name of the kernel the C library dispatches to (mirrors igemm.hip: f3x3_ok / t3x3s2_ok / choose_cfg).
-        `h`, `w`: the kernel's INPUT image; `transposed`: conv dgrad / convT forward (small image -> big image)."""
-        if not profiler.enabled:
-            return ''                             # the key is only used while spans are recorded
-        if r == 3 and stride == 1 and pad == 1 and w == 32 and h % 4 == 0 and cin % 8 == 0 and M >= 128:
-            if h % 8 == 0 and M % 64 == 0 and cin % 16 == 0 and get_math_mode() == 'f32':      # wino_ok (igemm.hip)
-                mode = get_winograd()
-                if mode == 'always' or (mode == 'auto' and n * (h // 8) * (M // 64) >= 96):
-                    return 'wino_f3x3_kernel'
-            return 'igemm_f3x3_kernel'
-        if transposed and r == 3 and stride == 2 and pad == 1 and w % 32 == 0 and h % (4 if M >= 128 else 8) == 0 \
-                and cin % 16 == 0 and M >= 64:
-            return 'igemm_t3x3s2_kernel'
-        if not transposed and r == 3 and stride == 2 and pad == 1 and w % 64 == 0 and h % 8 == 0 and cin % 8 == 0 \
-                and M >= 128:
-            return 'igemm_f3x3s2_kernel'
-        if not transposed and cin == 1 and 0 < r * r <= 50 and stride in (1, 2) and w >= 32:
-            return 'c1_fwd_kernel'                # approximate mirror of c1_fwd_ok (output width % 32 == 0)
-        return 'igemm_f_kernel<2,2,2,2>' if M >= 128 else ('igemm_f_kernel<2,2,1,4>' if M >= 64 else 'igemm_f_kernel<1,2,1,4>')
-
-    @staticmethod
-    def w_kernel(cb, hb, wb, cs, r, stride, pad, n=0):
-        if not profiler.enabled:
-            return ''
-        if r == 3 and stride == 1 and pad == 1 and wb == 32 and hb % 2 == 0 and cb % 64 == 0 and cs % 64 == 0:
-            if hb >= 4 and get_math_mode() == 'f32':                                           # wino_w_ok (igemm.hip)
-                mode = get_winograd()
-                if mode == 'always' or (mode == 'auto' and n * (hb // 2) >= 32):
-                    return 'wino_w3x3_kernel'
-            return 'igemm_w3x3_kernel'
-        if r == 3 and stride == 2 and pad == 1 and cb % 64 == 0 and cs % 128 == 0 and wb % 64 == 0 and hb % 2 == 0:
-            return 'igemm_w3x3s2_kernel'
-        if cb == 1 and cs <= 64 and 0 < r * r <= 64 and stride in (1, 2) and wb // stride in (32, 64, 128):
-            return 'c1_wgrad_kernel'
-        return 'igemm_w_kernel'
-
-    def span(self, key, flops, launches):
-        return _Span(self, key, flops, launches)
+    def span(self, flops):
+        return _Span(self, flops)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -104,6 +82,16 @@ class Profiler(object):
 
 
 profiler = Profiler()
+
+
+def kernel_log_begin():
+    """Starts recording the name of the kernel every conv call dispatches to (as reported by the library)."""
+    profiler.log = []
+
+
+def kernel_log_end():
+    names, profiler.log = profiler.log or [], None
+    return names
 
 
 def set_math_mode(mode):
@@ -189,7 +177,7 @@ class _Conv2dFn(torch.autograd.Function):
         P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
         y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
         ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, R, S, stride, pad), x.device)
-        with profiler.span(Profiler.f_kernel(K, C, H, W, R if R == S else 0, stride, pad, n=N), 2.0 * N * K * P * Q * C * R * S, 1):
+        with profiler.span(2.0 * N * K * P * Q * C * R * S):
             _lib.check(L.lsps_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, C, H, W, K, R, S,
                                          stride, pad, act, slope, ws, wsb, _lib.stream()), 'conv2d_fwd')
         ctx.geom = (N, C, H, W, K, R, S, stride, pad, act, slope)
@@ -210,8 +198,7 @@ class _Conv2dFn(torch.autograd.Function):
         dy, db = _act_backward(L, dy, y, act, slope, ctx.has_bias and ctx.needs_input_grad[2], K, ws, wsb, st)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            kname = Profiler.f_kernel(C, K, dy.shape[2], dy.shape[3], R if R == S else 0, stride, pad, True, n=dy.shape[0])
-            with profiler.span(kname, flops, 1 if 't3x3s2' in kname else stride * stride):
+            with profiler.span(flops):
                 _lib.check(L.lsps_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, C, H, W, K, R, S, stride,
                                                pad, ws, wsb, st), 'conv2d_dgrad')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -219,7 +206,7 @@ class _Conv2dFn(torch.autograd.Function):
             db_here = None                  # the bias gradient, unless the fused act_bwd pass already produced it
             if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
                 db = db_here = torch.empty(K, dtype=torch.float32, device=x.device)
-            with profiler.span(Profiler.w_kernel(C, H, W, K, R if R == S else 0, stride, pad, n=N), flops, 1):
+            with profiler.span(flops):
                 _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db_here), N, C, H, W, K,
                                                R, S, stride, pad, ws, wsb, st), 'conv2d_wgrad')
         return dx, dw, db, None, None, None, None
@@ -248,8 +235,7 @@ class _ConvT2dFn(torch.autograd.Function):
         Ho, Wo = convT_out_size(H, R, stride, pad, outpad), convT_out_size(W, S, stride, pad, outpad)
         y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
         ws, wsb = _lib.workspace(L.lsps_convT2d_workspace_bytes(N, Ci, H, W, Co, R, S, stride, pad, outpad), x.device)
-        kname = Profiler.f_kernel(Co, Ci, H, W, R if R == S else 0, stride, pad, True)
-        with profiler.span(kname, 2.0 * N * Ci * H * W * Co * R * S, 1 if 't3x3s2' in kname else stride * stride):
+        with profiler.span(2.0 * N * Ci * H * W * Co * R * S):
             _lib.check(L.lsps_convT2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, Ci, H, W, Co, R, S,
                                           stride, pad, outpad, act, slope, ws, wsb, _lib.stream()), 'convT2d_fwd')
         ctx.geom = (N, Ci, H, W, Co, R, S, stride, pad, outpad, act, slope)
@@ -270,7 +256,7 @@ class _ConvT2dFn(torch.autograd.Function):
         dy, db = _act_backward(L, dy, y, act, slope, ctx.has_bias and ctx.needs_input_grad[2], Co, ws, wsb, st)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            with profiler.span(Profiler.f_kernel(Ci, Co, dy.shape[2], dy.shape[3], R if R == S else 0, stride, pad), flops, 1):
+            with profiler.span(flops):
                 _lib.check(L.lsps_convT2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, Ci, H, W, Co, R, S, stride,
                                                 pad, outpad, ws, wsb, st), 'convT2d_dgrad')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -278,7 +264,7 @@ class _ConvT2dFn(torch.autograd.Function):
             db_here = None
             if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
                 db = db_here = torch.empty(Co, dtype=torch.float32, device=x.device)
-            with profiler.span(Profiler.w_kernel(Co, dy.shape[2], dy.shape[3], Ci, R if R == S else 0, stride, pad), flops, 1):
+            with profiler.span(flops):
                 _lib.check(L.lsps_convT2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db_here), N, Ci, H, W, Co,
                                                 R, S, stride, pad, outpad, ws, wsb, st), 'convT2d_wgrad')
         return dx, dw, db, None, None, None, None, None
@@ -347,13 +333,12 @@ class _ResBlockFn(torch.autograd.Function):
         y = torch.empty_like(a1)
         r1 = torch.empty(N * K, dtype=torch.float32, device=x.device)
         r2 = torch.empty_like(r1)
-        kname = Profiler.f_kernel(K, C, H, W, 3, 1, 1, n=N)
-        with profiler.span(kname, flops, 1):
+        with profiler.span(flops):
             _lib.check(L.lsps_conv2d_fwd(_lib.ptr(x), _lib.ptr(w1), None, _lib.ptr(a1), N, C, H, W, K, 3, 3, 1, 1, ACT_NONE,
                                          1.0, ws, wsb, st), 'conv2d_fwd')
         _lib.check(L.lsps_inorm_fwd(_lib.ptr(a1), None, _lib.ptr(a1), _lib.ptr(r1), N * K, H * W, IN_EPS, LRELU_SLOPE, st),
                    'inorm_fwd')
-        with profiler.span(kname, flops, 1):
+        with profiler.span(flops):
             _lib.check(L.lsps_conv2d_fwd(_lib.ptr(a1), _lib.ptr(w2), None, _lib.ptr(y), N, K, H, W, K, 3, 3, 1, 1, ACT_NONE,
                                          1.0, ws, wsb, st), 'conv2d_fwd')
         _lib.check(L.lsps_inorm_fwd(_lib.ptr(y), _lib.ptr(x), _lib.ptr(y), _lib.ptr(r2), N * K, H * W, IN_EPS, -1.0, st),
@@ -371,18 +356,17 @@ class _ResBlockFn(torch.autograd.Function):
         st = _lib.stream()
         ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, 3, 3, 1, 1), x.device)
         flops = 2.0 * N * K * H * W * C * 9
-        fk, wk = Profiler.f_kernel(C, K, H, W, 3, 1, 1, True, n=N), Profiler.w_kernel(C, H, W, K, 3, 1, 1, n=N)
         dh2 = torch.empty_like(y)
         _lib.check(L.lsps_inorm_bwd(_lib.ptr(g), _lib.ptr(y), _lib.ptr(x), _lib.ptr(r2), _lib.ptr(dh2), N * K, H * W, -1.0,
                                     st), 'inorm_bwd')
         dw1 = dw2 = dx = None
         if ctx.needs_input_grad[2]:
             dw2 = torch.empty_like(w2)
-            with profiler.span(wk, flops, 1):
+            with profiler.span(flops):
                 _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(a1), _lib.ptr(dh2), _lib.ptr(dw2), None, N, K, H, W, K, 3, 3, 1, 1,
                                                ws, wsb, st), 'conv2d_wgrad')
         da1 = torch.empty_like(a1)
-        with profiler.span(fk, flops, 1):
+        with profiler.span(flops):
             _lib.check(L.lsps_conv2d_dgrad(_lib.ptr(dh2), _lib.ptr(w2), _lib.ptr(da1), N, K, H, W, K, 3, 3, 1, 1, ws, wsb,
                                            st), 'conv2d_dgrad')
         dh1 = dh2                                        # dh2 is dead from here on: reuse its storage
@@ -390,12 +374,12 @@ class _ResBlockFn(torch.autograd.Function):
                                     LRELU_SLOPE, st), 'inorm_bwd')
         if ctx.needs_input_grad[1]:
             dw1 = torch.empty_like(w1)
-            with profiler.span(wk, flops, 1):
+            with profiler.span(flops):
                 _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dh1), _lib.ptr(dw1), None, N, C, H, W, K, 3, 3, 1, 1, ws,
                                                wsb, st), 'conv2d_wgrad')
         if ctx.needs_input_grad[0]:
             dx = da1                                     # da1 is dead: reuse
-            with profiler.span(fk, flops, 1):
+            with profiler.span(flops):
                 _lib.check(L.lsps_conv2d_dgrad_acc(_lib.ptr(dh1), _lib.ptr(w1), _lib.ptr(g), _lib.ptr(dx), N, C, H, W, K, 3, 3,
                                                    1, 1, ws, wsb, st), 'conv2d_dgrad_acc')
         return dx, dw1, dw2

@@ -85,7 +85,9 @@ class FlatAdam(torch.optim.Optimizer):
         params = self.param_groups[0]['params']
         if not params[0].is_cuda:
             raise _lib.LspsHipError("FlatAdam.attach(): parameters must be on the HIP device first")
-        old = {p: self.state.get(p) for p in params}
+        # moments loaded BEFORE the arena exists (driver order: resume(load_opt=True), then cuda()): `self.state[p]` is
+        # rebound to arena views below, so take the loaded tensors out first (a shallow copy of each per-param dict)
+        old = {p: dict(self.state.get(p) or {}) for p in params}
         self.arena = FlatArena(params)
         a = self.arena
         self.flat_m = torch.zeros_like(a.flat_p)
@@ -109,6 +111,18 @@ class FlatAdam(torch.optim.Optimizer):
                 st['exp_avg'].copy_(prev['exp_avg'])
                 st['exp_avg_sq'].copy_(prev['exp_avg_sq'])
         return self.arena
+
+    def sync_from_rank0(self):
+        """Data-parallel replicas must hold the SAME weights, Adam moments and step counts: rank 0's arena is
+        broadcast (three flat buffers + one int vector).  No-op outside a process group."""
+        from . import dist as ldist
+        if not ldist.active() or self.arena is None:
+            return
+        params = self.param_groups[0]['params']
+        steps = torch.tensor([int(self.state[p]['step']) for p in params], dtype=torch.int64, device=self.arena.device)
+        ldist.broadcast_from_rank0([self.arena.flat_p, self.flat_m, self.flat_v, steps])
+        for p, t in zip(params, steps.tolist()):
+            self.state[p]['step'] = int(t)
 
     @torch.no_grad()
     def step(self, closure=None):

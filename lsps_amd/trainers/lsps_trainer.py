@@ -93,27 +93,35 @@ class LSPSTrainer(nn.Module):
                 n_._arena = arena
             opt.grad_scale = 1.0 / lsps_dist.world()
             self._reducers[key] = lsps_dist.GradReducer(arena)
+        self.sync_replicas()
         return self
 
-    def _step(self, key, opt, loss, expected_net=None):
+    def sync_replicas(self):
+        """Under data parallelism every rank builds its nets from its own RNG (gaussian_weights_init, nn.Linear's
+        default init) — the replicas are made identical by broadcasting rank 0's parameter arenas, Adam moments and step
+        counts.  Called after `cuda()`, `resume()` and `load_vae()`; no-op in a single process."""
+        if self.gpu is None:
+            return
+        for opt in (self.dis_opt, self.gen_opt, self.vae_opt):
+            opt.sync_from_rank0()
+
+    def _step(self, key, opt, loss, names, tensors, sig):
+        """backward + gradient exchange + optimizer step + publication of the step's scalars (stored as numpy values like
+        the reference, ONE device->host copy).  `sig` identifies the graph of this step for the reducer: it learns which
+        parameters get gradients under that signature and launches each bucket during backward (lsps_amd/dist.py).  Under
+        data parallelism the scalars are summed over ranks by one tiny all-reduce launched BEFORE backward (they are
+        forward results), so publishing costs no second host synchronisation."""
         red = self._reducers[key]
-        expected = None
-        if lsps_dist.active() and expected_net is not None:
-            ids = set(id(p) for p in expected_net)
-            expected = [i for i, p in enumerate(red.arena.params) if id(p) in ids]
-        red.begin(expected)
+        scal = torch.stack([t.detach().reshape(()).float() for t in tensors])
+        red.begin(sig, scalars=scal if lsps_dist.active() else None)
         try:
             loss.backward()
             red.finish()
         finally:
             ops.weight_cache_end()          # the optimizer is about to change the weights
         opt.step()
-
-    def _publish(self, names, tensors):
-        """One device->host copy for all per-step scalars; stored as numpy values like the reference."""
-        vals = torch.stack([t.detach().reshape(()).float() for t in tensors]).cpu().numpy()
-        if lsps_dist.active():
-            vals = np.asarray(lsps_dist.all_reduce_mean_scalars([float(v) for v in vals], 'cuda'), dtype=np.float32)
+        mean = red.reduced_scalars()
+        vals = (scal if mean is None else mean).cpu().numpy()
         for k, v in zip(names, vals):
             setattr(self, k, np.asarray(v, dtype=np.float32))
 
@@ -134,8 +142,7 @@ class LSPSTrainer(nn.Module):
         enc_loss = self._compute_kl(mu, sd)
         ll_loss = self._compute_ll_loss(dec, y)
         total_loss = hyperparameters['kl_loss_vae'] * enc_loss + hyperparameters['ll_loss_vae'] * ll_loss
-        self._step('vae', self.vae_opt, total_loss)
-        self._publish(['vae_total_loss'], [total_loss])
+        self._step('vae', self.vae_opt, total_loss, ['vae_total_loss'], [total_loss], ('vae_update',))
         return dec
 
     def _pose2depth(self, labels_a, labels_b, nz):
@@ -179,14 +186,12 @@ class LSPSTrainer(nn.Module):
         names = ['gen_enc_loss', 'gen_enc_loss2', 'gen_ad_loss', 'gen_ll_loss', 'gen_ll_loss2']
         vals = [enc_loss, enc_aba_loss + enc_bab_loss, ad_loss_a + ad_loss_b, ll_loss_a + ll_loss_b,
                 ll_loss_bab + ll_loss_aba]
-        expected = list(self.gen.parameters())
         if map_terms is not None:
             total_loss = total_loss + hp['ll_map_z_w'] * map_terms[0] + hp['ll_map_w'] * map_terms[1]
             names += ['gen_map_loss', 'gen_map_loss2']
             vals += [map_terms[0], map_terms[1]]
-            expected += list(self.map.parameters())
-        self._step('gen', self.gen_opt, total_loss, expected_net=expected)
-        self._publish(names + ['gen_total_loss'], vals + [total_loss])
+        self._step('gen', self.gen_opt, total_loss, names + ['gen_total_loss'], vals + [total_loss],
+                   ('gen_update', bool(hp['train_map']), self.gen.training))
         return (x_aa, x_ba, x_ab, x_bb, x_aba, x_bab, decode_A, decode_B)
 
     # ------------------------------------------------------------------ :143-218
@@ -230,13 +235,12 @@ class LSPSTrainer(nn.Module):
         loss = hp['gan_w'] * ad_loss
         if feat_mat:
             loss = loss + hp['feature_w'] * feature_loss
-        self._step('dis', self.dis_opt, loss)
         names = ['dis_ad_loss', 'dis_loss', 'dis_true_acc', 'dis_fake_acc']
         vals = [ad_loss, loss, true_acc, fake_acc]
         if feat_mat:
             names.append('dis_feat_loss')
             vals.append(feature_loss)
-        self._publish(names, vals)
+        self._step('dis', self.dis_opt, loss, names, vals, ('dis_update', bool(feat_mat), bool(hp['train_map'])))
         return
 
     # ------------------------------------------------------------------ :220-262
@@ -277,8 +281,8 @@ class LSPSTrainer(nn.Module):
         total_loss = hp['reg_w'] * reg_loss
         if terms_feat:
             total_loss = total_loss + hp['feature_w_reg'] * (terms_feat[0] + terms_feat[1])
-        self._step('dis', self.dis_opt, total_loss)
-        self._publish(['dis_reg_loss', 'dis_total_loss'], [reg_loss, total_loss])
+        self._step('dis', self.dis_opt, total_loss, ['dis_reg_loss', 'dis_total_loss'], [reg_loss, total_loss],
+                   ('post_update', int(mode)))
         return (x_aa, x_ba, x_ab, x_bb, x_aa, x_bb, x_aa, x_bb)
 
     # ------------------------------------------------------------------ :264-276, 349-350
@@ -318,6 +322,7 @@ class LSPSTrainer(nn.Module):
         except Exception:
             print('-----Failed to load map parameters!')
         print('Resume from iteration %d' % iterations)
+        self.sync_replicas()
         return iterations
 
     @staticmethod
@@ -325,11 +330,17 @@ class LSPSTrainer(nn.Module):
         return dict((k, v.detach().clone()) for k, v in net.state_dict().items())   # not views of the arena
 
     def save(self, snapshot_prefix, iterations):
-        torch.save(self._dense_state(self.gen), '%s_gen_%08d.pkl' % (snapshot_prefix, iterations + 1))
-        torch.save(self._dense_state(self.dis), '%s_dis_%08d.pkl' % (snapshot_prefix, iterations + 1))
+        """Replicas are identical, so rank 0 alone writes (N ranks writing one path would race); the barrier keeps a
+        following resume() on another rank from reading a half-written file."""
+        if lsps_dist.rank() == 0:
+            torch.save(self._dense_state(self.gen), '%s_gen_%08d.pkl' % (snapshot_prefix, iterations + 1))
+            torch.save(self._dense_state(self.dis), '%s_dis_%08d.pkl' % (snapshot_prefix, iterations + 1))
+        lsps_dist.barrier()
 
     def save_vae(self, snapshot_prefix, iterations, frac):
-        torch.save(self._dense_state(self.vae), '%s_vae_%.2f_%08d.pkl' % (snapshot_prefix, frac, iterations + 1))
+        if lsps_dist.rank() == 0:
+            torch.save(self._dense_state(self.vae), '%s_vae_%.2f_%08d.pkl' % (snapshot_prefix, frac, iterations + 1))
+        lsps_dist.barrier()
 
     def load_vae(self, snapshot_prefix, frac):
         dirname = os.path.dirname(snapshot_prefix)
@@ -338,6 +349,7 @@ class LSPSTrainer(nn.Module):
             return 0
         self.vae.load_state_dict(self._load(last_model_name))
         print('Loading pretrained VAE parameters from %s' % last_model_name)
+        self.sync_replicas()
         return 0
 
 

@@ -386,6 +386,47 @@ def run_step_cases(A, config, shapes_mod, n=2, post_n=8):
     return R
 
 
+def run_extra_cases(A, shapes_mod, which=('estimate1', 'wide')):
+    """Round-2 additions (golden_extra.npz; the round-1 files stay byte-identical):
+      * `post_update(mode=1)` — regress_b only (lsps_trainer.py:231-234), tiny and full width, two iterations;
+      * one pretrain iteration at FULL width with 3 samples per domain: the generator's residual blocks then run on 6
+        samples, the smallest batch at which the library's default ('auto') dispatch picks the Winograd kernels, so this
+        is a trainer-level golden on the default dispatch of the bench."""
+    R = OrderedDict()
+    if 'estimate1' in which:
+        for config in ('tiny', 'full'):
+            hp = hp_for(config)
+            sds = make_weights(hp, shapes_mod)
+            post_n, zd = 8, hp['vae']['z_dim']
+            bp = make_inputs(post_n)
+            tr = A.make_trainer(hp, sds)
+            A.set_train(tr, True)
+            for it in range(2):
+                A.post_update(tr, bp, 1, hp, None, None, noise((post_n, zd), 7100 + it, 0.05))
+                R['%s.estimate1.it%d.scalars' % (config, it)] = A.scalars(tr)
+                if it == 0:
+                    _grad_digest(R, '%s.estimate1.it0.grads' % config, A, tr, 'dis')
+                R['%s.estimate1.it%d.dis.params' % (config, it)] = A.params(tr, 'dis')
+    if 'wide' in which:
+        hp = hp_for('full')
+        sds = make_weights(hp, shapes_mod)
+        n = 3
+        lat2, lat1 = latent_shape(hp, 2 * n), latent_shape(hp, n)
+        tr = A.make_trainer(hp, sds)
+        A.set_train(tr, True)
+        b = make_inputs(n)
+        A.dis_update(tr, b, hp, noise(lat2, 1500))
+        R['wide.it0.dis_update.scalars'] = A.scalars(tr)
+        _grad_digest(R, 'wide.it0.dis_update.grads', A, tr, 'dis')
+        outs = A.gen_update(tr, b, hp, (noise(lat2, 2500), noise(lat1, 3500), noise(lat1, 4500)))
+        R['wide.it0.gen_update.scalars'] = A.scalars(tr)
+        _grad_digest(R, 'wide.it0.gen_update.grads', A, tr, 'gen')
+        R['wide.it0.gen_update.outputs'] = OrderedDict(zip(('x_aa', 'x_ba', 'x_ab', 'x_bb', 'x_aba', 'x_bab'), outs[:6]))
+        R['wide.it0.dis.params'] = A.params(tr, 'dis')
+        R['wide.it0.gen.params'] = A.params(tr, 'gen')
+    return R
+
+
 # ---------------------------------------------------------------------------------------------
 # residual block with dropout (`res_dropout_ratio` > 0: lsps_nets.py:176-179 -> common_net.py:171-172)
 # ---------------------------------------------------------------------------------------------

@@ -116,3 +116,162 @@ def test_reducer_is_a_noop_single_process():
     assert torch.allclose(arena.flat_g[:15], torch.full((15,), 2.0))
     assert ps[0].data.data_ptr() == arena.flat_p.data_ptr()
     assert ldist.world() == 1 and ldist.rank() == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2: learned step signatures, the product trainer's own `_step` bookkeeping, replicas made identical
+# ---------------------------------------------------------------------------------------------------------------
+class _NoStepOpt(object):
+    def step(self):
+        pass
+
+
+def _product_step_worker(rank, world, port, out):
+    """Drives the PRODUCT trainer's `_step` (lsps_amd/trainers/lsps_trainer.py) on CPU tensors over gloo: the trainer
+    object is the real LSPSTrainer (constructor runs on CPU), its arenas/reducers are the real ones; only the losses
+    are plain-torch stand-ins touching the same parameter subsets as the three update methods, and the Adam launch
+    (HIP-only) is stubbed.  Nothing is passed as `expected`: the reducer has to learn it from the first step."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['LSPS_BUCKET_BYTES'] = str(1 << 14)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        from lsps_amd import dist as ldist
+        from lsps_amd.optim import FlatArena
+        import lsps_amd.trainers as prod
+        torch.manual_seed(100 + rank)                       # every rank starts from DIFFERENT weights
+        hp = cases.hp_for('tiny')
+        tr = prod.LSPSTrainer(hp)
+        tr.gpu = 'cpu-test'
+        for key, opt, nets in (('dis', tr.dis_opt, (tr.dis,)), ('gen', tr.gen_opt, (tr.gen, tr.map))):
+            arena = FlatArena(opt.param_groups[0]['params'])
+            opt.arena = arena
+            opt.flat_m, opt.flat_v = torch.zeros_like(arena.flat_p), torch.zeros_like(arena.flat_p)
+            for p_ in opt.param_groups[0]['params']:
+                opt.state[p_]['step'] = 3 + rank
+            for n_ in nets:
+                n_._arena = arena
+            tr._reducers[key] = ldist.GradReducer(arena)
+        before = float(tr.dis_opt.arena.flat_p.abs().sum())
+        tr.dis_opt.sync_from_rank0()
+        tr.gen_opt.sync_from_rank0()
+        sums = torch.tensor([float(tr.dis_opt.arena.flat_p.double().sum()), float(tr.gen_opt.arena.flat_p.double().sum())],
+                            dtype=torch.float64)
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        steps = set(int(tr.dis_opt.state[p_]['step']) for p_ in tr.dis_opt.param_groups[0]['params'])
+
+        named = dict(tr.dis.named_parameters())
+        subsets = {   # which discriminator parameters each update method reaches (Post head / D head / trunk)
+            ('dis_update', True, False): [k for k in named if not k.startswith('Post')],
+            ('post_update', 0): [k for k in named if not k.startswith('model_D') and not k.startswith('model_B')],
+            ('post_update', 3): [k for k in named if not k.startswith('model_D')],
+        }
+        report = {}
+        for sig, keys in subsets.items():
+            for it in range(2):
+                tr.dis.zero_grad()
+                loss = sum(((rank + 1.0) * named[k]).pow(2).sum() for k in keys)
+                tr._step('dis', _NoStepOpt(), loss, ['dis_loss'], [loss.detach() * 0 + float(rank)], sig)
+                red = tr._reducers['dis']
+                report[(sig, it)] = (red.last_early, red.last_buckets, float(tr.dis_loss))
+            # all-reduced gradient = sum over ranks of 2 (r+1)^2 p
+            k0 = keys[0]
+            want = sum(2.0 * (r + 1.0) ** 2 for r in range(world)) * named[k0].detach()
+            report[(sig, 'err')] = float((named[k0].grad - want).abs().max())
+        # gen arena: the residual-block biases never get a gradient -> they must not block any bucket
+        gnamed = dict(tr.gen.named_parameters())
+        live = [k for k in gnamed if not (k.endswith('.model.0.bias') or k.endswith('.model.3.bias'))]
+        for it in range(2):
+            tr.gen.zero_grad()
+            loss = sum(gnamed[k].pow(2).sum() for k in live)
+            tr._step('gen', _NoStepOpt(), loss, ['gen_total_loss'], [loss.detach()], ('gen_update', False, True))
+            report[('gen', it)] = (tr._reducers['gen'].last_early, tr._reducers['gen'].last_buckets)
+        if rank == 0:
+            out.put(dict(report=report, same=bool(torch.equal(lo, hi)), steps=sorted(steps), moved=before))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_product_step_learns_expected_gradients_and_overlaps_all_updates():
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_product_step_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res['same'], "rank 0's weights were not broadcast"
+    assert res['steps'] == [3], res['steps']                       # Adam step counts follow rank 0 too
+    rep = res['report']
+    for sig in (('dis_update', True, False), ('post_update', 0), ('post_update', 3)):
+        e0, n0, _ = rep[(sig, 0)]
+        e1, n1, scal = rep[(sig, 1)]
+        assert n0 == n1 >= 3, (sig, n0, n1)
+        assert e0 == 0, "first step of a signature: nothing known yet, everything goes at finish()"
+        assert e1 >= n1 - 1, (sig, e1, n1)                         # learned: buckets go out DURING backward
+        assert scal == 0.5                                          # scalars: mean over ranks of (0, 1)
+        assert rep[(sig, 'err')] < 1e-5
+    assert rep[('gen', 0)][0] == 0 and rep[('gen', 1)][0] >= rep[('gen', 1)][1] - 1, rep
+
+
+def test_late_gradient_for_a_launched_bucket_raises():
+    """A signature that does not determine the graph must fail loudly, not reduce a half-filled bucket."""
+    from lsps_amd import dist as ldist
+    from lsps_amd.optim import FlatArena
+    ps = [torch.nn.Parameter(torch.randn(8)), torch.nn.Parameter(torch.randn(8))]
+    arena = FlatArena(ps)
+    red = ldist.GradReducer(arena, bucket_bytes=1 << 20)
+    red.active = True
+    arena.on_grad_ready = red._on_grad_ready
+    launched = []
+    red._launch = lambda b: (launched.append(b), red._launched.__setitem__(b, True))
+    arena.zero_grad()
+    red.begin(('s',), expected=[0])
+    arena.touched[0] = True
+    red._on_grad_ready(0)                                    # the only expected gradient: the bucket goes out
+    assert launched == [0] and not red._late
+    arena.touched[1] = True
+    red._on_grad_ready(1)                                    # ... and then one more gradient arrives for it
+    assert red._late
+    with pytest.raises(RuntimeError):
+        red.finish()
+
+
+def test_flat_adam_attach_keeps_moments_loaded_before_the_arena():
+    """Driver order (depth_train.py:109-114): resume(load_opt=True) THEN cuda(): the loaded exp_avg / exp_avg_sq must
+    survive attach() (they were overwritten by the zero arena views)."""
+    from lsps_amd.optim import FlatAdam
+    import lsps_amd.optim as lo
+    ps = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5))]
+    ref = torch.optim.Adam(ps, lr=1e-3)
+    (ps[0].sum() * 2 + (ps[1] ** 2).sum()).backward()
+    ref.step()
+    ref.step()
+    sd = ref.state_dict()
+    opt = FlatAdam(ps, lr=1e-3)
+    opt.load_state_dict(sd)
+    m_before = [opt.state[p]['exp_avg'].clone() for p in ps]
+
+    class _P(object):                                        # attach() insists on HIP parameters; fake the flag only
+        def __init__(self, p):
+            self.p = p
+    orig = torch.Tensor.is_cuda
+    try:
+        lo.torch.Tensor.is_cuda = property(lambda self: True)
+        orig_pin = torch.Tensor.pin_memory
+        opt.attach()
+    except Exception:
+        raise
+    finally:
+        lo.torch.Tensor.is_cuda = orig
+    for p, m in zip(ps, m_before):
+        assert torch.equal(opt.state[p]['exp_avg'], m) and float(m.abs().sum()) > 0
+        assert opt.state[p]['exp_avg'].data_ptr() >= opt.flat_m.data_ptr()
+        assert int(opt.state[p]['step']) == 2

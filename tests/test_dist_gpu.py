@@ -105,3 +105,102 @@ def test_two_rank_step_equals_global_batch_step():
     assert moved > 50                                  # both optimizers really stepped
     for k, v in scal_1.items():                        # logged scalars are the rank mean
         assert abs(scal_dp[k] - v) <= 2e-3 * max(1.0, abs(v)), (k, scal_dp[k], v)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2: the 2-rank HIP trainer against the REFERENCE's golden global-batch vectors, replicas that start from
+# different RNG streams, and overlap of the all-reduce with backward in all three update methods
+# ---------------------------------------------------------------------------------------------------------------
+def _golden_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    os.environ['LSPS_BUCKET_BYTES'] = str(1 << 16)          # tiny nets: several buckets per arena
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import lsps_amd.trainers as prod
+        from collections import OrderedDict
+        hp = cases.hp_for('tiny')
+        # (1) no pre-seeded weights: each rank initialises from its own RNG stream; cuda() must make them identical
+        torch.manual_seed(4321 + rank)
+        tr0 = prod.LSPSTrainer(hp)
+        tr0.cuda(0)
+        sums = torch.tensor([float(o.arena.flat_p.double().sum()) for o in (tr0.dis_opt, tr0.gen_opt, tr0.vae_opt)],
+                            dtype=torch.float64)
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_equal = bool(torch.equal(lo, hi))
+        del tr0
+
+        A = cases.NativeAdapter(prod, 'cuda')
+        sds = cases.make_weights(hp, lsps_ref)
+        R, overlap = OrderedDict(), {}
+        # (2) pretrain, global n=2 -> one sample per domain per rank (golden case `pretrain.it*`, cases.run_step_cases)
+        n = 2
+        per = n // world
+        sl = slice(rank * per, (rank + 1) * per)
+        two = lambda a: np.concatenate([a[sl], a[n + rank * per:n + (rank + 1) * per]], 0)     # noqa: E731
+        b = cases.make_inputs(n)
+        shard = {k: v[sl] for k, v in b.items()}
+        lat2, lat1 = cases.latent_shape(hp, 2 * n), cases.latent_shape(hp, n)
+        tr = A.make_trainer(hp, sds)
+        A.set_train(tr, True)
+        for it in range(2):
+            A.dis_update(tr, shard, hp, two(cases.noise(lat2, 1000 + it)))
+            R['pretrain.it%d.dis_update.scalars' % it] = A.scalars(tr)
+            overlap[('dis_update', it)] = (tr._reducers['dis'].last_early, tr._reducers['dis'].last_buckets)
+            A.gen_update(tr, shard, hp, (two(cases.noise(lat2, 2000 + it)), cases.noise(lat1, 3000 + it)[sl],
+                                         cases.noise(lat1, 4000 + it)[sl]))
+            R['pretrain.it%d.gen_update.scalars' % it] = A.scalars(tr)
+            overlap[('gen_update', it)] = (tr._reducers['gen'].last_early, tr._reducers['gen'].last_buckets)
+            R['pretrain.it%d.dis.params' % it] = A.params(tr, 'dis')
+            R['pretrain.it%d.gen.params' % it] = A.params(tr, 'gen')
+        # (3) estimate3, global N=8 -> 4 per rank; the feature term uses the GLOBAL first four samples (golden `estimate3.*`)
+        post_n, zd = 8, hp['vae']['z_dim']
+        per = post_n // world
+        sl = slice(rank * per, (rank + 1) * per)
+        bp = cases.make_inputs(post_n)
+        shard = {k: v[sl] for k, v in bp.items()}
+        latp = cases.latent_shape(hp, 8)
+        tr = A.make_trainer(hp, sds)
+        A.set_train(tr, True)
+        for it in range(2):
+            A.post_update(tr, shard, 3, hp, cases.noise(latp, 5000 + it), cases.noise((post_n, zd), 6000 + it, 0.05)[sl],
+                          cases.noise((post_n, zd), 7000 + it, 0.05)[sl])
+            R['estimate3.it%d.scalars' % it] = A.scalars(tr)
+            overlap[('post_update', it)] = (tr._reducers['dis'].last_early, tr._reducers['dis'].last_buckets)
+            R['estimate3.it%d.dis.params' % it] = A.params(tr, 'dis')
+        torch.cuda.synchronize()
+        if rank == 0:
+            out.put((R, overlap, replicas_equal))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_hip_trainer_matches_reference_golden_and_overlaps(golden):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_golden_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    R, overlap, replicas_equal = out.get(timeout=900)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert replicas_equal, "ranks built from different RNG streams must hold rank 0's weights after cuda()"
+    g = {k: v for k, v in golden('tiny').items() if k.split('/')[0] in R}
+    assert len(g) > 300
+    bad, worst = cases.compare(R, g, 1e-3, grad_rtol=2e-2)
+    print("worst rel err", worst)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
+    for step in ('dis_update', 'gen_update', 'post_update'):
+        e0, n0 = overlap[(step, 0)]
+        e1, n1 = overlap[(step, 1)]
+        assert n1 >= 2, (step, n1)
+        assert e0 == 0 and e1 >= n1 - 1, (step, overlap)      # learned in iteration 0, overlapped from iteration 1 on

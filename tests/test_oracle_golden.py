@@ -36,6 +36,17 @@ def test_oracle_steps_match_reference(config, golden):
     assert not bad, "worst=%g first failures: %s" % (worst, bad[:5])
 
 
+def test_oracle_extra_cases_match_reference(golden):
+    """post_update(mode=1) (tiny + full) and the full-width pretrain iteration at 3 samples per domain."""
+    torch.set_num_threads(8)
+    A = cases.NativeAdapter(lsps_ref, 'cpu')
+    R = cases.run_extra_cases(A, lsps_ref)
+    g = golden('extra')
+    assert set(k.split('/')[0] for k in g) == set(R)
+    bad, worst = cases.compare(R, g, 1e-3, grad_rtol=2e-2)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:5])
+
+
 def test_oracle_resnext_generator_matches_reference(golden):
     torch.set_num_threads(8)
     A = cases.NativeAdapter(lsps_ref, 'cpu')

@@ -61,6 +61,23 @@ def test_full_steps_match_reference_golden_per_conv_algorithm(mode, golden):
     assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
 
 
+def test_extra_cases_match_reference_golden(golden):
+    """`post_update(mode=1)` (lsps_trainer.py:231-234) and a full-width pretrain iteration at a batch where the DEFAULT
+    dispatch ('auto') of the residual convs is the Winograd path — the dispatch the bench runs, at trainer level."""
+    A = _adapter()
+    from lsps_amd import ops
+    assert ops.get_winograd() == 'auto'
+    ops.kernel_log_begin()
+    try:
+        R = cases.run_extra_cases(A, lsps_ref)
+    finally:
+        names = ops.kernel_log_end()
+    assert any(n.startswith('wino') for n in names), sorted(set(names))
+    bad, worst = cases.compare(R, golden('extra'), RTOL, grad_rtol=2e-2)
+    print("worst rel err", worst)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
+
+
 def test_resnext_generator_matches_reference_golden(golden):
     A = _adapter()
     R = cases.run_resx_cases(A, lsps_ref)
