@@ -251,14 +251,27 @@ class CropPipeline(object):
 
 
 class _CacheUnpickler(pickle.Unpickler):
-    """Maps the reference's `data.basetypes` records onto the namedtuples above."""
+    """Maps the reference's `data.basetypes` records onto the namedtuples above.  Only the globals a sequence cache
+    legitimately contains are resolved (numpy array reconstruction + the two records); anything else raises, so a cache
+    file from an untrusted source cannot name arbitrary callables (the reference's cPickle.load would run them)."""
+
+    _ALLOWED = {
+        ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+        ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
+        ('numpy', 'ndarray'), ('numpy', 'dtype'),
+        ('collections', 'OrderedDict'), ('__builtin__', 'tuple'), ('__builtin__', 'list'), ('__builtin__', 'dict'),
+        ('builtins', 'tuple'), ('builtins', 'list'), ('builtins', 'dict'),
+        ('_codecs', 'encode'),             # how a python-3 writer stores the array bytes in protocol 2 (str -> latin1)
+    }
 
     def find_class(self, module, name):
         if module.endswith('basetypes') and name == 'DepthFrame':
             return DepthFrame
         if module.endswith('basetypes') and name == 'NamedImgSequence':
             return NamedImgSequence
-        return super(_CacheUnpickler, self).find_class(module, name)
+        if (module, name) in self._ALLOWED:
+            return super(_CacheUnpickler, self).find_class(module, name)
+        raise pickle.UnpicklingError("sequence cache names a global outside the whitelist: %s.%s" % (module, name))
 
 
 def cache_file_name(cache_dir, importer_name, seq_name, hand=None, all_joints=True, crop_joint_idx=32, docom=False,

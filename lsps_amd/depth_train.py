@@ -127,7 +127,8 @@ def run(opts, trainer_factory=None, loader_a=None, loader_b=None, test_batches=N
     os.makedirs(os.path.dirname(config.snapshot_prefix) or '.', exist_ok=True)
     if opts.log:
         os.makedirs(opts.log, exist_ok=True)
-    sink = open(os.path.join(opts.log, 'losses.jsonl'), 'a') if opts.log else None
+    is_rank0 = int(os.environ.get('RANK', '0')) == 0          # replicas log identical (rank-averaged) scalars: one writer
+    sink = open(os.path.join(opts.log, 'losses.jsonl'), 'a') if (opts.log and is_rank0) else None
     history = []
     best_err, best_acc = 100.0, 0.0
     start = time.time()
@@ -148,7 +149,7 @@ def run(opts, trainer_factory=None, loader_a=None, loader_b=None, test_batches=N
             image_outputs = trainer.post_update(images_a, labels_a, images_b, labels_b, com_a, com_b, mode_idx, hp)
         if hasattr(trainer, 'assemble_outputs'):
             trainer.assemble_outputs(images_a, images_b, image_outputs)                   # :161,166
-        if (iterations + 1) % config.display == 0:                                       # :169-172
+        if (iterations + 1) % config.display == 0 and is_rank0:                          # :169-172
             history.append(write_loss(iterations, max_iterations, trainer, time.time() - start, sink))
             start = time.time()
         if (iterations + 1) % config.image_save_iterations == 0 and 'estimate' in opts.mode and test_batches \

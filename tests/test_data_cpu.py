@@ -90,3 +90,12 @@ def test_sequence_cache_reader(tmp_path):
     np.random.RandomState(23455).shuffle(order)
     seq2 = ldata.load_sequence_cache(path, shuffle_rng=rng, nmax=3)
     assert [d.fileName for d in seq2.data] == ['depth_1_%07d.png' % (k + 1) for k in order[:3]]
+
+
+def test_sequence_cache_reader_rejects_foreign_globals():
+    """A cache file is a pickle: the reader resolves numpy reconstruction + the two record types and nothing else."""
+    import pickle
+    import pytest
+    evil = pickle.dumps((os.system, 'echo pwned'), protocol=2)
+    with pytest.raises(pickle.UnpicklingError):
+        ldata.load_sequence_cache(evil)
