@@ -107,6 +107,18 @@ int lsps_convT2d_wgrad(const float *x, const float *dy, float *dw, float *db,
                        int N, int Ci, int H, int W, int Co, int R, int S, int stride, int pad, int outpad,
                        void *ws, size_t ws_bytes, void *stream);
 
+/* ---- 3x3 / stride 1 / pad 1 Conv2d + InstanceNorm2d(affine=False) [+ LeakyReLU | + residual], ONE call -------------
+ * The two conv -> norm pairs of LeakyINSResBlock (common_net.py:162-163 + 166-171; :162-163 + 177-181):
+ *   residual == NULL: y = lrelu_slope(IN(conv3x3(x, w)))   (slope < 0: no activation)
+ *   residual != NULL: y = IN(conv3x3(x, w)) + residual     (slope must be < 0)
+ * The conv bias is not an argument: it cancels exactly under an affine-free InstanceNorm.  rstd[N*K] is saved for
+ * lsps_inorm_bwd (which works from y).  On 32x32 maps with K % 32 == 0 the Winograd F(4x4,3x3) kernel owns whole (n, k)
+ * planes per workgroup and normalises in its epilogue, so the pre-norm tensor never reaches HBM; every other shape runs the
+ * dispatched conv kernel followed by lsps_inorm_fwd in place.  ws as for lsps_conv2d_fwd. */
+int lsps_conv2d_in_fwd(const float *x, const float *w, const float *residual /*nullable*/, float *y, float *rstd,
+                       int N, int C, int H, int W, int K, float slope, float eps,
+                       void *ws, size_t ws_bytes, void *stream);
+
 /* ---- InstanceNorm2d(affine=False) [+ LeakyReLU] [+ residual add], fused --------------------
  * call sites: common_net.py:168-171 (norm + in-place LeakyReLU), :177-181 (norm, out += residual).
  * planes = N*C, hw = H*W.  out = act(IN(y)) (+ residual).  slope < 0 => no activation.

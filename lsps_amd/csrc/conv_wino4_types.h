@@ -1,0 +1,37 @@
+// Parameter blocks and launchers of the Winograd F(4x4,3x3) kernels (conv_wino4.h, compiled in wino4.hip with its own flags).
+#ifndef LSPS_CONV_WINO4_TYPES_H
+#define LSPS_CONV_WINO4_TYPES_H
+#include "common.h"
+
+namespace lsps {
+
+#define W4_RC 4                          // channels per staged row chunk = 2 k-steps between two barriers
+#define W4_UREC 2304                     // floats of U per (32-channel k slice, channel pair): [2 c][4 blocks][32 k][8] + [2][4][32][1]
+#define W4_LDS_BYTES 147456              // epilogue exchange (8 waves x 18 x 64 lanes x 16 B) > main loop (2 x 21760 B)
+
+struct Wino4Pack {
+  const float *W;
+  float *U;
+  int M, C;
+  long sm, sc;
+  int tapidx[9];
+};
+
+struct Wino4Params {
+  const float *X, *U, *bias;
+  const float *R;                // optional addend with Y's layout (dgrad skip connection / residual)
+  float *Y;
+  float *rstd;                   // [N*M], written when norm != 0
+  int Cx, M, N;
+  int act;
+  float slope;
+  int norm;                      // 0: y = act(conv + bias) + R;  1: y = lrelu_slope(IN(conv)) (slope < 0: none);  2: y = IN(conv) + R
+  float eps;
+};
+
+// wino4.hip: 0 or LSPS_E_HIP (lsps_last_error set)
+int wino4_launch_pack(const Wino4Pack &p, hipStream_t st);
+int wino4_launch(const Wino4Params &p, hipStream_t st);
+
+}  // namespace lsps
+#endif

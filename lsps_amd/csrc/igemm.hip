@@ -39,6 +39,7 @@
 #include "conv3x3s2.h"
 #include "conv_c1.h"
 #include "conv_wino.h"
+#include "conv_wino4_types.h"
 
 namespace lsps {
 
@@ -261,11 +262,12 @@ static bool f3x3_ok(int Cin, int H, int W, int R, int S, int st_, int pad) {
 
 // Winograd F(2x2,3x3) path of run_f3x3 (f32 mode): conv_wino.h.  Mode (lsps_set_winograd, initial value from LSPS_WINO):
 // 0 = never (direct kernel), 1 = grids that fill the chip (default), 2 = every eligible shape.
+// 3 / 4 = like 1 / 2 but F(2x2,3x3) only (the F(4x4,3x3) kernel of conv_wino4.h is not used).
 static int g_wino_mode = -1;
 static int wino_mode() {
   if (g_wino_mode < 0) {
     const char *e = getenv("LSPS_WINO");
-    g_wino_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+    g_wino_mode = (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : 1;
   }
   return g_wino_mode;
 }
@@ -275,10 +277,67 @@ static int wino_mode() {
 static bool wino_ok(int N, int Cin, int H, int M) {
   const int mode = wino_mode();
   if (mode == 0 || (H % 8) != 0 || (M % 64) != 0 || (Cin % (2 * WN_RC)) != 0) return false;
-  return mode == 2 || (long)N * (H / 8) * (M / 64) >= 96;
+  return mode == 2 || mode == 4 || (long)N * (H / 8) * (M / 64) >= 96;
 }
 
-static size_t wino_bytes(int Cin, int M) { return (size_t)16 * Cin * M * sizeof(float); }   // U: 16 positions x [M][Cin]
+// F(4x4,3x3) (conv_wino4.h): one workgroup per (image, 32 output channels), 32x32 maps only.  A workgroup runs ~70 us for
+// 256 input channels whatever the batch, so 'auto' wants the chip at least half full.
+static bool wino4_ok(int N, int Cin, int H, int M) {
+  const int mode = wino_mode();
+  if (mode == 0 || mode >= 3 || g_math_mode != 0 || H != 32 || (M % 32) != 0 || (Cin % W4_RC) != 0 || Cin < 8) return false;
+  return mode == 2 || (long)N * (M / 32) >= 128;
+}
+
+static size_t wino_bytes(int Cin, int M) { return (size_t)36 * Cin * M * sizeof(float); }   // U: 36 (F4) / 16 (F2) positions x [M][Cin]
+
+static int run_wino4(const float *in, const float *W, const float *bias, float *out, int N, int Cin, int M, long sm, long sc,
+                     const TapList &l, int act, float slope, void *ws, size_t ws_bytes, hipStream_t st, const float *addend,
+                     int norm, float *rstd, float eps) {
+  const size_t need = (size_t)36 * Cin * M * sizeof(float);
+  PackKey k = {W, M, M, Cin * 36, Cin * 36, 9, 32 * 32, 32, /*cc: marks the F(4x4,3x3) layout*/ 1 << 21, sm, sc, 2166136261u};
+  for (int i = 0; i < 9; ++i) k.taphash = (k.taphash ^ (unsigned)(l.idx[i] * 961 + i)) * 16777619u;
+  bool hit;
+  void *slot = pack_cache_find(k, need, &hit);
+  if (!slot) {
+    if (need > ws_bytes) {
+      set_error("conv workspace too small: need %zu, have %zu", need, ws_bytes);
+      return LSPS_E_WS;
+    }
+    slot = ws;
+  }
+  float *U = (float *)slot;
+  if (!hit) {
+    Wino4Pack pk;
+    pk.W = W;
+    pk.U = U;
+    pk.M = M;
+    pk.C = Cin;
+    pk.sm = sm;
+    pk.sc = sc;
+    for (int t = 0; t < 9; ++t) pk.tapidx[t] = l.idx[t];
+    int rc = wino4_launch_pack(pk, st);
+    if (rc) return rc;
+  }
+  Wino4Params p;
+  memset(&p, 0, sizeof(p));
+  p.X = in;
+  p.U = U;
+  p.bias = bias;
+  p.R = addend;
+  p.Y = out;
+  p.rstd = rstd;
+  p.Cx = Cin;
+  p.M = M;
+  p.N = N;
+  p.act = act;
+  p.slope = slope;
+  p.norm = norm;
+  p.eps = eps;
+  int rc = wino4_launch(p, st);
+  if (rc) return rc;
+  note_kernel("wino4_f3x3_kernel");
+  return 0;
+}
 
 static int run_wino(const float *in, const float *W, const float *bias, float *out, int N, int Cin, int H, int M, long sm,
                     long sc, const TapList &l, int act, float slope, void *ws, size_t ws_bytes, hipStream_t st,
@@ -293,7 +352,7 @@ static int run_wino(const float *in, const float *W, const float *bias, float *o
     }
     attr_set = true;
   }
-  const size_t need = wino_bytes(Cin, M);
+  const size_t need = (size_t)16 * Cin * M * sizeof(float);
   PackKey k = {W, M, M, Cin * 16, Cin * 16, 9, H * 32, 32, /*cc: marks the Winograd layout*/ 1 << 20, sm, sc, 2166136261u};
   for (int i = 0; i < 9; ++i) k.taphash = (k.taphash ^ (unsigned)(l.idx[i] * 961 + i)) * 16777619u;
   bool hit;
@@ -467,6 +526,8 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
     note_kernel("igemm_f3x3_split_kernel");
     return 0;
   }
+  if (wino4_ok(N, Cin, H, M))
+    return run_wino4(in, W, bias, out, N, Cin, M, sm, sc, l, act, slope, ws, ws_bytes, st, addend, 0, nullptr, 0.f);
   if (wino_ok(N, Cin, H, M))
     return run_wino(in, W, bias, out, N, Cin, H, M, sm, sc, l, act, slope, ws, ws_bytes, st, addend);
   const size_t need = class_bytes(REDp, Mp);
@@ -1336,8 +1397,9 @@ int lsps_set_math_mode(int mode) {
 int lsps_get_math_mode(void) { return lsps::g_math_mode; }
 
 int lsps_set_winograd(int mode) {
-  if (mode < 0 || mode > 2) {
-    set_error("set_winograd: mode must be 0 (off), 1 (grids that fill the chip) or 2 (every eligible shape)");
+  if (mode < 0 || mode > 4) {
+    set_error("set_winograd: mode must be 0 (off), 1 (grids that fill the chip), 2 (every eligible shape), 3 / 4 (like 1 / 2, "
+              "F(2x2,3x3) only)");
     return LSPS_E_ARG;
   }
   lsps::g_wino_mode = mode;
@@ -1386,6 +1448,30 @@ int lsps_conv2d_fwd(const float *x, const float *w, const float *bias, float *y,
   LSPS_CHECK_ARG(P > 0 && Q > 0, "conv2d_fwd: empty output");
   return run_forward_dir(x, w, bias, y, N, C, H, W, K, P, Q, R, S, stride, pad, (long)C * R * S, (long)R * S, act,
                          slope, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_conv2d_in_fwd(const float *x, const float *w, const float *residual, float *y, float *rstd, int N, int C, int H,
+                       int W, int K, float slope, float eps, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(x && w && y && rstd && ws, "conv2d_in_fwd: null pointer");
+  LSPS_CHECK_ARG(conv_args_ok(N, C, H, W, K, 3, 3, 1, 1), "conv2d_in_fwd: unsupported geometry");
+  LSPS_CHECK_ARG(!(residual && slope >= 0.f), "conv2d_in_fwd: residual and activation are exclusive (reference block forms)");
+  if (W == 32 && wino4_ok(N, C, H, K)) {
+    TapList l;
+    l.T = 9;
+    for (int t = 0; t < 9; ++t) {
+      l.dh[t] = t / 3 - 1;
+      l.dw[t] = t % 3 - 1;
+      l.idx[t] = t;
+    }
+    return run_wino4(x, w, nullptr, y, N, C, K, (long)C * 9, 9L, l, LSPS_ACT_NONE, slope, ws, ws_bytes, (hipStream_t)stream,
+                     residual, residual ? 2 : 1, rstd, eps);
+  }
+  // other shapes / modes: the conv kernel the dispatcher picks, then the in-place InstanceNorm pass
+  int rc = run_forward_dir(x, w, nullptr, y, N, C, H, W, K, H, W, 3, 3, 1, 1, (long)C * 9, 9L, LSPS_ACT_NONE, 1.f, ws, ws_bytes,
+                           (hipStream_t)stream);
+  if (rc) return rc;
+  return lsps_inorm_fwd(y, residual, y, rstd, N * K, H * W, eps, residual ? -1.f : slope, stream);
 }
 
 int lsps_conv2d_dgrad(const float *dy, const float *w, float *dx, int N, int C, int H, int W, int K, int R, int S,

@@ -1,0 +1,31 @@
+// Winograd F(4x4,3x3) conv kernels (conv_wino4.h) in their own translation unit: built with -fno-slp-vectorize, because
+// the SLP vectoriser fuses the per-column transform ops into v_pk_fma_f32 pairs ACROSS the sched_barrier-pinned MFMA gaps
+// (collapsing "one column per gap" into one block after five back-to-back MFMAs, plus ~20 v_mov per k-step to form the
+// pairs); packed f32 VALU is also the more expensive filler beside MFMAs on this part (MI355X_MICROARCH.md).
+#include "conv_wino4.h"
+
+namespace lsps {
+
+int wino4_launch_pack(const Wino4Pack &p, hipStream_t st) {
+  hipLaunchKernelGGL(wino4_pack_kernel, dim3(ceil_div((long)p.M * p.C, 256)), dim3(256), 0, st, p);
+  LSPS_CHECK_LAUNCH("wino4_pack");
+  return 0;
+}
+
+int wino4_launch(const Wino4Params &p, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {                        // 144 KB of LDS: dynamic + opt-in
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_f3x3_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(wino4_f3x3): %s", hipGetErrorString(e));
+      return LSPS_E_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wino4_f3x3_kernel, dim3(p.N * (p.M / 32)), dim3(512), W4_LDS_BYTES, st, p);
+  LSPS_CHECK_LAUNCH("wino4_f3x3");
+  return 0;
+}
+
+}  // namespace lsps
