@@ -139,36 +139,43 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
     n = lin / KS;
   }
   constexpr int HW = 1024;
-  const float *xn = p.X + (long)n * p.Cx * HW;
-  const int nsteps = p.Cx >> 1, nchunks = p.Cx >> 2;
-  const char *urec = reinterpret_cast<const char *>(p.U + (long)ks * nsteps * W4_UREC);
+  const int nsteps = p.Cx >> 1, nchunks = p.Cx / W4_RC;
+  // Global loads go through buffer descriptors (uniform base in SGPRs + ONE 32-bit lane offset + scalar offset): no
+  // 64-bit per-lane addresses, which the flat form costs in VGPR pairs (this kernel has none to spare).
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.X + (long)n * p.Cx * HW), 0, p.Cx * HW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.U + (long)ks * nsteps * W4_UREC), 0, nsteps * W4_UREC * 4, 0x00020000);
   const unsigned u8_off = (unsigned)(((half * 4 + wp) * 32 + l31) * 8) * 4u;
   const unsigned u1_off = (unsigned)(2048 + (half * 4 + wp) * 32 + l31) * 4u;
 
-  // staging of the raw rows: one chunk = 4 channels x 32 rows x 8 16-B segments = 2 per thread
-  int s_lds[2];
-  unsigned s_off[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int u = tid + 512 * i;
-    const int ch = u >> 8, row = (u >> 3) & 31, seg = u & 7;
-    s_lds[i] = ch * W4_CH + (row + 1) * W4_LDW + 1 + seg * 4;
-    s_off[i] = (unsigned)(ch * HW + row * 32 + seg * 4) * 4u;
-  }
-  f32x4 sreg[2];
+  // staging of the raw rows: one chunk = 8 channels x 32 rows x 8 16-B segments = 4 per thread (thread t: channels
+  // t/256 + 2i), fetched ONE chunk (4 k-steps, ~2 us) ahead: the rows come from HBM / other XCDs, not from L2 like U
+  constexpr int NSEG = W4_RC * 32 * 8 / 512;
+  static_assert(NSEG == 4, "the k-step schedule spreads exactly four staging segments over its gaps");
+  const int s_lds = (tid >> 8) * W4_CH + (((tid >> 3) & 31) + 1) * W4_LDW + 1 + (tid & 7) * 4;
+  const unsigned s_off = (unsigned)((tid >> 8) * HW + ((tid >> 3) & 31) * 32 + (tid & 7) * 4) * 4u;
+  f32x4 sreg[NSEG];
+  auto load_seg = [&](int chunk, int i) {
+#ifndef W4_ABL_NOSTAGE
+    sreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, s_off, (chunk * W4_RC + 2 * i) * HW * 4, 0));
+#endif
+  };
+  auto store_seg = [&](float *buf, int i) {
+#ifndef W4_ABL_NOSTAGE
+    float *d = buf + s_lds + 2 * i * W4_CH;
+    d[0] = sreg[i][0];
+    *reinterpret_cast<f32x2 *>(d + 1) = f32x2{sreg[i][1], sreg[i][2]};
+    d[3] = sreg[i][3];
+#endif
+  };
   auto load_rows = [&](int chunk) {
-    const char *xc = reinterpret_cast<const char *>(xn + (long)chunk * W4_RC * HW);   // uniform
 #pragma unroll
-    for (int i = 0; i < 2; ++i) sreg[i] = *reinterpret_cast<const f32x4 *>(xc + s_off[i]);
+    for (int i = 0; i < NSEG; ++i) load_seg(chunk, i);
   };
   auto store_rows = [&](float *buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float *d = buf + s_lds[i];
-      d[0] = sreg[i][0];
-      *reinterpret_cast<f32x2 *>(d + 1) = f32x2{sreg[i][1], sreg[i][2]};
-      d[3] = sreg[i][3];
-    }
+    for (int i = 0; i < NSEG; ++i) store_seg(buf, i);
   };
 
   f32x16 acc[9];
@@ -176,10 +183,13 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
   float ac1, an1;                // position 8
   float vc[9], vn[9];            // V of the current / next k-step
   auto load_u = [&](int step) {
-    const char *us = urec + (long)step * (W4_UREC * 4);        // uniform
-    an8[0] = *reinterpret_cast<const f32x4 *>(us + u8_off);
-    an8[1] = *reinterpret_cast<const f32x4 *>(us + u8_off + 16);
-    an1 = *reinterpret_cast<const float *>(us + u1_off);
+#ifdef W4_ABL_NOU
+    return;
+#endif
+    const int so = step * (W4_UREC * 4);                       // uniform
+    an8[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, u8_off, so, 0));
+    an8[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, u8_off + 16, so, 0));
+    an1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, u1_off, so, 0));
   };
 
   // prologue: first loads go out before the LDS zero fill
@@ -200,9 +210,16 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
     const float *rd = w4_lds + half * W4_CH + (16 * wt + 4 * tr + BI) * W4_LDW + 4 * tc;
     f32x4 r4[5];
     f32x2 r2[5];
+#ifdef W4_STREAM_P2
+    float T[3];
+#else
     float P[3][5];
+#endif
     // raw rows of one k-step: channel pair g of row buffer `bo` (both compile-time: immediate offsets)
     auto read_raw = [&](int bo, int g) {
+#ifdef W4_ABL_NOLDS
+      return;
+#endif
 #pragma unroll
       for (int l = 0; l < 5; ++l) {
         r4[l] = *(lp4)(rd + bo + 2 * g * W4_CH + l * W4_LDW);
@@ -210,11 +227,48 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
       }
     };
     auto col = [&](int l, int x) -> float { return x < 4 ? r4[l][x] : r2[l][x - 4]; };
-    auto pass1 = [&](int ci) {                   // column x = BJ + ci of the 5 columns this block needs
+    // pass 1: the block's three rows of B^T d for column x = BJ + ci of the 5 columns it needs
+    auto pass1 = [&](int ci) {
+#ifdef W4_ABL_NOXF
+      return;
+#endif
       const int x = BJ + ci;
+#ifdef W4_STREAM_P2
+      w4_xf<BI>(col(0, x), col(1, x), col(2, x), col(3, x), col(4, x), T[0], T[1], T[2]);
+#else
       w4_xf<BI>(col(0, x), col(1, x), col(2, x), col(3, x), col(4, x), P[0][ci], P[1][ci], P[2][ci]);
+#endif
     };
-    auto pass2 = [&](int il) { w4_xf<BJ>(P[il][0], P[il][1], P[il][2], P[il][3], P[il][4], vn[il * 3], vn[il * 3 + 1], vn[il * 3 + 2]); };
+#ifdef W4_STREAM_P2
+    // pass 2, streamed (experiment): column ci's contribution to the block's three columns of V; 11 FMAs per row instead
+    // of the factored 6 ops, but the 3 x 5 intermediate is never kept (12 registers less)
+    auto pass2s = [&](int ci) {
+#ifdef W4_ABL_NOXF
+      return;
+#endif
+      constexpr float K0[3][5] = {{4.f, 0.f, -5.f, 0.f, 1.f}, {0.f, -4.f, -4.f, 1.f, 1.f}, {0.f, 4.f, -4.f, -1.f, 1.f}};
+      constexpr float K1[3][5] = {{-2.f, -1.f, 2.f, 1.f, 0.f}, {2.f, -1.f, -2.f, 1.f, 0.f}, {4.f, 0.f, -5.f, 0.f, 1.f}};
+#pragma unroll
+      for (int il = 0; il < 3; ++il)
+#pragma unroll
+        for (int jl = 0; jl < 3; ++jl) {
+          const float k = BJ ? K1[jl][ci] : K0[jl][ci];
+          bool first = true;
+#pragma unroll
+          for (int cj = 0; cj < 5; ++cj)
+            if (cj < ci && (BJ ? K1[jl][cj] : K0[jl][cj]) != 0.f) first = false;
+          if (k != 0.f) vn[il * 3 + jl] = first ? k * T[il] : fmaf(k, T[il], vn[il * 3 + jl]);
+        }
+    };
+#else
+    // pass 2: the block's three columns of row il
+    auto pass2 = [&](int il) {
+#ifdef W4_ABL_NOXF
+      return;
+#endif
+      w4_xf<BJ>(P[il][0], P[il][1], P[il][2], P[il][3], P[il][4], vn[il * 3], vn[il * 3 + 1], vn[il * 3 + 2]);
+    };
+#endif
     auto mma = [&](int q) {
       const float a = q < 4 ? ac8[0][q] : (q < 8 ? ac8[1][q - 4] : ac1);
       acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vc[q], acc[q], 0, 0, 0);
@@ -227,47 +281,76 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
       ac1 = an1;
     };
     // one k-step: 9 MFMAs on (ac, vc); between them the transform of the NEXT k-step's raw rows (buffer bo, pair g) -> vn
-    auto step = [&](int bo, int g, int ustep) {
-      read_raw(bo, g);
-      load_u(ustep);
+    // One k-step: 9 MFMAs on (ac, vc); the gaps between them carry the transform of the NEXT k-step's raw rows (row buffer
+    // bo, channel pair g) into vn, that step's U loads, and a share of the row staging (STAGE 1: this thread's four
+    // segments of chunk `sc` go from registers into row buffer `sb`, one per gap; STAGE 2: the loads of chunk `sc`, one per
+    // gap).  Nothing is issued in bursts: an in-order wave that queues ten LDS reads or twelve LDS writes back to back
+    // stalls on the LDS / TA queues with the matrix pipe idle behind it, and the eight waves of a workgroup reach such
+    // points together (measured: bursts -> spread = see DESIGN).  The step opens with an MFMA and only one short pass-2
+    // row trails the last one.
+    auto step = [&](int bo, int g, int ustep, auto stage_c, int sb, int sc) {
+      constexpr int STAGE = decltype(stage_c)::value;
       __builtin_amdgcn_sched_barrier(0);
       mma(0);
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef W4_ABL_NOLDS
+#pragma unroll
+      for (int l = 0; l < 5; ++l) r4[l] = *(lp4)(rd + bo + 2 * g * W4_CH + l * W4_LDW);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
       mma(1);
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef W4_ABL_NOLDS
+#pragma unroll
+      for (int l = 0; l < 5; ++l) r2[l] = *(lp2)(rd + bo + 2 * g * W4_CH + l * W4_LDW + 4);
+#endif
+      load_u(ustep);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ci = 0; ci < 5; ++ci) {
         mma(2 + ci);
         __builtin_amdgcn_sched_barrier(0);
         pass1(ci);
+        if (STAGE == 1 && ci >= 1) store_seg(w4_lds + sb, ci - 1);
+        if (STAGE == 2 && ci >= 1) load_seg(sc, ci - 1);
         __builtin_amdgcn_sched_barrier(0);
       }
       mma(7);
       __builtin_amdgcn_sched_barrier(0);
       pass2(0);
+      pass2(1);
       __builtin_amdgcn_sched_barrier(0);
       mma(8);
       __builtin_amdgcn_sched_barrier(0);
-      pass2(1);
       pass2(2);
       __builtin_amdgcn_sched_barrier(0);
       rotate();
     };
     // V(0): transform of k-step 0 (no MFMAs yet)
     read_raw(0, 0);
+#ifdef W4_STREAM_P2
+#pragma unroll
+    for (int ci = 0; ci < 5; ++ci) {
+      pass1(ci);
+      pass2s(ci);
+    }
+#else
 #pragma unroll
     for (int ci = 0; ci < 5; ++ci) pass1(ci);
     pass2(0);
     pass2(1);
     pass2(2);
+#endif
     rotate();                                    // (ac <- U(0), loaded in the prologue)
-    // chunk c lives in buffer c & 1.  Step A (k-step 2c) transforms k-step 2c+1 (same chunk, channels 2,3); then chunk
-    // c+1 is stored and published; step B (k-step 2c+1) transforms k-step 2c+2 (chunk c+1, channels 0,1).
+    // chunk c (k-steps 4c .. 4c+3) lives in buffer c & 1.  K-step s transforms k-step s+1: the first three steps of a
+    // chunk stay inside it (channel pairs 1..3); then chunk c+1 is stored and published and chunk c+2 requested; the
+    // last step transforms pair 0 of chunk c+1.
     auto chunk = [&](int bo, int nbo, int c) {
-      step(bo, 1, min(2 * c + 1, nsteps - 1));
-      store_rows(w4_lds + nbo);
+      step(bo, 1, min(4 * c + 1, nsteps - 1), w4_int<0>(), 0, 0);
+      step(bo, 2, min(4 * c + 2, nsteps - 1), w4_int<0>(), 0, 0);
+      step(bo, 3, min(4 * c + 3, nsteps - 1), w4_int<1>(), nbo, 0);          // + chunk c+1: registers -> buffer nbo
       __syncthreads();
-      load_rows(min(c + 2, nchunks - 1));
-      step(nbo, 0, min(2 * c + 2, nsteps - 1));
+      step(nbo, 0, min(4 * c + 4, nsteps - 1), w4_int<2>(), 0, min(c + 2, nchunks - 1));   // + request chunk c+2
     };
     for (int c = 0; c < nchunks; c += 2) {
       chunk(0, W4_BUF, c);
@@ -278,6 +361,17 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
   // barriers inside are executed the same number of times by every wave, from different program counters.
   auto epilogue = [&](auto bi_c, auto bj_c) {
   constexpr int bi = decltype(bi_c)::value, bj = decltype(bj_c)::value;
+#ifdef W4_ABL_NOEPI
+  {
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += acc[q][r];
+    if (a == 123.456f) p.Y[tid] = a;
+    return;
+  }
+#endif
   __syncthreads();                               // the row buffers are free: reuse LDS for the exchanges below
 
   // ---- epilogue: Y = A^T M A.  Register r of an accumulator = output channel k0 + (r & 3) + 8 (r >> 2) + 4 half, tile l31.
@@ -442,6 +536,9 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
     }
   }
   };
+#ifdef W4_PRIO
+  if (wt) __builtin_amdgcn_s_setprio(1);         // experiment: static priority for the younger half of the workgroup
+#endif
   switch (wp) {                                  // wave-uniform: four instances of main loop + epilogue
     case 0: body(w4_int<0>(), w4_int<0>()); epilogue(w4_int<0>(), w4_int<0>()); break;
     case 1: body(w4_int<0>(), w4_int<1>()); epilogue(w4_int<0>(), w4_int<1>()); break;

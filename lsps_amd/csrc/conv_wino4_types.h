@@ -5,9 +5,9 @@
 
 namespace lsps {
 
-#define W4_RC 4                          // channels per staged row chunk = 2 k-steps between two barriers
+#define W4_RC 8                          // channels per staged row chunk = 4 k-steps between two barriers
 #define W4_UREC 2304                     // floats of U per (32-channel k slice, channel pair): [2 c][4 blocks][32 k][8] + [2][4][32][1]
-#define W4_LDS_BYTES 147456              // epilogue exchange (8 waves x 18 x 64 lanes x 16 B) > main loop (2 x 21760 B)
+#define W4_LDS_BYTES 147456              // epilogue exchange (8 waves x 18 x 64 lanes x 16 B) > main loop (2 x 43520 B)
 
 struct Wino4Pack {
   const float *W;
