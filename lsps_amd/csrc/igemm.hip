@@ -725,7 +725,7 @@ static int run_forward_dir(const float *in, const float *W, const float *bias, f
                            int Cs, int Hs, int Ws, int R, int S, int st_, int pad, long sm, long sc, int act,
                            float slope, void *ws, size_t ws_bytes, hipStream_t st) {
 #ifndef LSPS_NO_F3X3
-  if (f3x3_ok(Cb, Hb, Wb, R, S, st_, pad) && Cs >= 128)
+  if (f3x3_ok(Cb, Hb, Wb, R, S, st_, pad) && (Cs >= 128 || wino4_ok(N, Cb, Hb, Cs)))
     return run_f3x3(in, W, bias, out, N, Cb, Hb, Cs, sm, sc, false, act, slope, ws, ws_bytes, st);
 #endif
 #ifndef LSPS_NO_F3X3S2
@@ -899,7 +899,7 @@ static int run_transposed_dir(const float *in, const float *W, const float *bias
                               float slope, void *ws, size_t ws_bytes, hipStream_t st) {
 #ifndef LSPS_NO_F3X3
   // stride-1 transposed conv == forward 3x3 conv with flipped taps (dh = pad - r)
-  if (f3x3_ok(Cs, Hs, Ws, R, S, st_, pad) && Hb == Hs && Wb == Ws && Cb >= 128)
+  if (f3x3_ok(Cs, Hs, Ws, R, S, st_, pad) && Hb == Hs && Wb == Ws && (Cb >= 128 || wino4_ok(N, Cs, Hs, Cb)))
     return run_f3x3(in, W, bias, out, N, Cs, Hs, Cb, sm, sc, true, act, slope, ws, ws_bytes, st);
 #endif
 #ifndef LSPS_NO_T3X3S2
@@ -1511,7 +1511,7 @@ int lsps_conv2d_dgrad_acc(const float *dy, const float *w, const float *addend, 
   const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
 #ifndef LSPS_NO_F3X3
   // the residual convs: the addend is folded into the epilogue of the 3x3 kernel (no separate pass)
-  if (f3x3_ok(K, P, Q, R, S, stride, pad) && H == P && W == Q && C >= 128)
+  if (f3x3_ok(K, P, Q, R, S, stride, pad) && H == P && W == Q && (C >= 128 || wino4_ok(N, K, P, C)))
     return run_f3x3(dy, w, nullptr, dx, N, K, P, C, (long)R * S, (long)C * R * S, true, LSPS_ACT_NONE, 1.f, ws, ws_bytes,
                     (hipStream_t)stream, addend);
 #endif

@@ -105,15 +105,18 @@ def get_math_mode():
     return ('f32', 'bf16', 'f32_split')[_lib.lib().lsps_get_math_mode()]
 
 
+_WINO_MODES = ('off', 'auto', 'always', 'auto_f2', 'always_f2')
+
+
 def set_winograd(mode):
-    """Algorithm of the f32 3x3 / stride-1 / width-32 convs: 'off' (direct implicit GEMM), 'auto' (Winograd F(2x2,3x3)
-    when the grid fills the chip; default) or 'always' (every eligible shape).  Process-wide."""
-    code = {'off': 0, 'auto': 1, 'always': 2}[mode]
-    _lib.check(_lib.lib().lsps_set_winograd(code), 'set_winograd')
+    """Algorithm of the f32 3x3 / stride-1 / width-32 convs: 'off' (direct implicit GEMM), 'auto' (Winograd when the grid
+    fills the chip: F(4x4,3x3) on 32x32 maps, else F(2x2,3x3); default), 'always' (every eligible shape), 'auto_f2' /
+    'always_f2' (the same without the F(4x4,3x3) kernel).  Process-wide."""
+    _lib.check(_lib.lib().lsps_set_winograd(_WINO_MODES.index(mode)), 'set_winograd')
 
 
 def get_winograd():
-    return ('off', 'auto', 'always')[_lib.lib().lsps_get_winograd()]
+    return _WINO_MODES[_lib.lib().lsps_get_winograd()]
 
 
 def conv_out_size(h, r, stride, pad):
@@ -333,16 +336,14 @@ class _ResBlockFn(torch.autograd.Function):
         y = torch.empty_like(a1)
         r1 = torch.empty(N * K, dtype=torch.float32, device=x.device)
         r2 = torch.empty_like(r1)
+        # conv + InstanceNorm (+ LeakyReLU | + skip) in ONE call each: on 32x32 maps the Winograd F(4x4,3x3) kernel owns
+        # whole (n, k) planes and normalises in its epilogue; other shapes run conv + the in-place norm pass in the library
         with profiler.span(flops):
-            _lib.check(L.lsps_conv2d_fwd(_lib.ptr(x), _lib.ptr(w1), None, _lib.ptr(a1), N, C, H, W, K, 3, 3, 1, 1, ACT_NONE,
-                                         1.0, ws, wsb, st), 'conv2d_fwd')
-        _lib.check(L.lsps_inorm_fwd(_lib.ptr(a1), None, _lib.ptr(a1), _lib.ptr(r1), N * K, H * W, IN_EPS, LRELU_SLOPE, st),
-                   'inorm_fwd')
+            _lib.check(L.lsps_conv2d_in_fwd(_lib.ptr(x), _lib.ptr(w1), None, _lib.ptr(a1), _lib.ptr(r1), N, C, H, W, K,
+                                            LRELU_SLOPE, IN_EPS, ws, wsb, st), 'conv2d_in_fwd')
         with profiler.span(flops):
-            _lib.check(L.lsps_conv2d_fwd(_lib.ptr(a1), _lib.ptr(w2), None, _lib.ptr(y), N, K, H, W, K, 3, 3, 1, 1, ACT_NONE,
-                                         1.0, ws, wsb, st), 'conv2d_fwd')
-        _lib.check(L.lsps_inorm_fwd(_lib.ptr(y), _lib.ptr(x), _lib.ptr(y), _lib.ptr(r2), N * K, H * W, IN_EPS, -1.0, st),
-                   'inorm_fwd')
+            _lib.check(L.lsps_conv2d_in_fwd(_lib.ptr(a1), _lib.ptr(w2), _lib.ptr(x), _lib.ptr(y), _lib.ptr(r2), N, K, H, W, K,
+                                            -1.0, IN_EPS, ws, wsb, st), 'conv2d_in_fwd')
         ctx.save_for_backward(x, w1, w2, a1, y, r1, r2)
         return y
 
