@@ -29,9 +29,19 @@ struct Wino4Params {
   float eps;
 };
 
+// weight gradient (conv_wino4w.h): partial sums part[split][36 positions][M][C], then dW = G^T (sum of splits) G
+#define W4W_LDS_BYTES 130048             // two buffers of 32 x rows-of-6 + 64 dy rows-of-4 channels
+struct Wino4WParams {
+  const float *DY, *X;
+  float *part;
+  int N, M, C, H;
+  int ntr, per_split;            // tile rows in total (N * H/4) and per split
+};
+
 // wino4.hip: 0 or LSPS_E_HIP (lsps_last_error set)
 int wino4_launch_pack(const Wino4Pack &p, hipStream_t st);
 int wino4_launch(const Wino4Params &p, hipStream_t st);
+int wino4_launch_wgrad(const Wino4WParams &p, int splits, float *dW, hipStream_t st);
 
 }  // namespace lsps
 #endif

@@ -1061,8 +1061,56 @@ static int run_wino_w(const float *dy, const float *x, float *dW, int N, int C, 
   return 0;
 }
 
+// F(4x4,3x3) form of the same weight gradient (conv_wino4w.h): one 256-thread workgroup per CU owns a 64 k x 32 c block of
+// all 36 positions; the tile rows (4 image rows each) are split over 256 / blocks workgroups, a multiple of 8 where
+// possible (one split per XCD group).  LSPS_WINO4W=0 keeps the F(2x2,3x3) kernel (A/B comparisons).
+static int wino4_w_splits(int M, int C, int ntr) {
+  int s = 256 / ((M / 64) * (C / 32));
+  if (s > ntr) s = ntr;
+  if (s > 8) s &= ~7;
+  return s < 1 ? 1 : s;
+}
+static size_t wino4_w_ws_bytes(int N, int M, int C, int H) {
+  return (size_t)wino4_w_splits(M, C, N * H / 4) * 36 * M * C * sizeof(float);
+}
+static bool wino4_w_ok(int N, int C, int H, int M) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char *e = getenv("LSPS_WINO4W");
+    enabled = !(e && e[0] == '0');
+  }
+  const int mode = wino_mode();
+  if (!enabled || mode == 0 || mode >= 3 || g_math_mode != 0 || (H % 4) != 0 || (C % 32) != 0 || (M % 64) != 0) return false;
+  return mode == 2 || (long)N * (H / 4) >= 64;
+}
+
+static int run_wino4_w(const float *dy, const float *x, float *dW, int N, int C, int H, int M, void *ws, size_t ws_bytes,
+                       hipStream_t st) {
+  if (wino4_w_ws_bytes(N, M, C, H) > ws_bytes) {
+    set_error("wgrad workspace too small: need %zu, have %zu", wino4_w_ws_bytes(N, M, C, H), ws_bytes);
+    return LSPS_E_WS;
+  }
+  Wino4WParams p;
+  memset(&p, 0, sizeof(p));
+  p.DY = dy;
+  p.X = x;
+  p.part = (float *)ws;
+  p.N = N;
+  p.M = M;
+  p.C = C;
+  p.H = H;
+  p.ntr = N * H / 4;
+  const int splits = wino4_w_splits(M, C, p.ntr);
+  p.per_split = ceil_div(p.ntr, splits);
+  int rc = wino4_launch_wgrad(p, splits, dW, st);
+  if (rc) return rc;
+  note_kernel("wino4_w3x3_kernel");
+  return 0;
+}
+
 static int run_w3x3(const float *dy, const float *x, float *dW, int N, int C, int H, int M, void *ws, size_t ws_bytes,
                     hipStream_t st) {
+  if (wino4_w_ok(N, C, H, M)) return run_wino4_w(dy, x, dW, N, C, H, M, ws, ws_bytes, st);
   if (wino_w_ok(N, C, H, M)) return run_wino_w(dy, x, dW, N, C, H, M, ws, ws_bytes, st);
   W3Params p;
   memset(&p, 0, sizeof(p));
@@ -1344,6 +1392,7 @@ static size_t conv_ws_bytes(int N, int Cb, int Hb, int Wb, int Cs, int Hs, int W
     const size_t w3 = w3x3_ws_bytes(N, Cs, Cb, Hb);
     if (w3 > m) m = w3;
     if (wino_w_ws_bytes(N, Cs, Cb, Hb) > m) m = wino_w_ws_bytes(N, Cs, Cb, Hb);
+    if ((Hb % 4) == 0 && wino4_w_ws_bytes(N, Cs, Cb, Hb) > m) m = wino4_w_ws_bytes(N, Cs, Cb, Hb);
   }
   if (w3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, 1)) {
     const size_t w3 = w3x3s2_ws_bytes(N, Cs, Cb, Hs, Ws);

@@ -3,6 +3,7 @@
 // (collapsing "one column per gap" into one block after five back-to-back MFMAs, plus ~20 v_mov per k-step to form the
 // pairs); packed f32 VALU is also the more expensive filler beside MFMAs on this part (MI355X_MICROARCH.md).
 #include "conv_wino4.h"
+#include "conv_wino4w.h"
 
 namespace lsps {
 
@@ -25,6 +26,25 @@ int wino4_launch(const Wino4Params &p, hipStream_t st) {
   }
   hipLaunchKernelGGL(wino4_f3x3_kernel, dim3(p.N * (p.M / 32)), dim3(512), W4_LDS_BYTES, st, p);
   LSPS_CHECK_LAUNCH("wino4_f3x3");
+  return 0;
+}
+
+int wino4_launch_wgrad(const Wino4WParams &p, int splits, float *dW, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {                        // 127 KB of LDS: dynamic + opt-in
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_w3x3_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4W_LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(wino4_w3x3): %s", hipGetErrorString(e));
+      return LSPS_E_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wino4_w3x3_kernel, dim3(p.C / 32, p.M / 64, splits), dim3(256), W4W_LDS_BYTES, st, p);
+  LSPS_CHECK_LAUNCH("wino4_w3x3");
+  hipLaunchKernelGGL(wino4_w3x3_reduce_kernel, dim3(ceil_div((long)p.M * p.C, 256)), dim3(256), 0, st,
+                     (const float *)p.part, dW, p.M * p.C, splits);
+  LSPS_CHECK_LAUNCH("wino4_w3x3_reduce");
   return 0;
 }
 

@@ -631,6 +631,50 @@ def test_conv3x3_winograd_f4(case):
         ops.set_winograd(prev)
 
 
+# (N, C, H, K): weight gradient in F(4x4,3x3) form (conv_wino4w.h): 64 k x 32 c blocks, tile rows of 4 image rows split over
+# 256 / blocks workgroups (a multiple of 8 where possible), partial sums reduced in double precision
+WINO4W_CASES = [
+    (3, 256, 32, 256),     # the residual conv: 32 blocks x 8 splits of 3 tile rows (XCD mapping)
+    (17, 256, 32, 256),    # 136 tile rows over 8 splits: odd chunk counts per split
+    (1, 64, 4, 64),        # ONE tile row (top and bottom halo rows in the same chunk), one split
+    (2, 64, 8, 128),       # 4 tile rows, 4 blocks -> 4 splits of one chunk each
+    (5, 128, 12, 64),      # H = 12: 15 tile rows over 8 splits of 2: the last split is short, none empty
+    (1, 64, 20, 192),      # 5 tile rows, 6 blocks -> 5 splits (not a multiple of 8: plain workgroup order)
+    (9, 192, 32, 64),      # 72 tile rows, 6 blocks -> 40 splits of 2: the last four splits are EMPTY (zero partials)
+]
+
+
+@pytest.mark.parametrize("case", WINO4W_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv3x3_winograd_f4_wgrad(case):
+    """F(4x4,3x3) weight gradient through lsps_conv2d_wgrad against an f64 reference (own bound W4_TOL like the forward
+    kernel; measured 2e-6 .. 5e-6), against the direct kernel, and the kernel the library reports."""
+    _need_gpu()
+    from lsps_amd import _lib, ops
+    N, C, H, K = case
+    L = _lib.lib()
+    prev = ops.get_winograd()
+    try:
+        x = _rand(N, C, H, 32, seed=31)
+        gy = _rand(N, K, H, 32, seed=32)
+        w = torch.zeros(K, C, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x.double(), w, None, padding=1).backward(gy.double())
+        xd, gyd = x.cuda(), gy.cuda()
+        ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, 32, K, 3, 3, 1, 1), xd.device)
+        res = {}
+        for mode in ('always', 'off'):
+            ops.set_winograd(mode)
+            dw = torch.full((K, C, 3, 3), float('nan'), device='cuda')
+            _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(xd), _lib.ptr(gyd), _lib.ptr(dw), None, N, C, H, 32, K, 3, 3, 1, 1, ws, wsb,
+                                           _lib.stream()), 'wgrad')
+            res[mode] = (dw, L.lsps_last_kernel(None))
+        assert res['always'][1] == b'wino4_w3x3_kernel', res['always'][1]
+        assert res['off'][1] != b'wino4_w3x3_kernel'
+        assert _rel(res['always'][0], w.grad) < W4_TOL, _rel(res['always'][0], w.grad)
+        assert _rel(res['always'][0], res['off'][0]) < W4_TOL
+    finally:
+        ops.set_winograd(prev)
+
+
 @pytest.mark.parametrize("case", [(3, 256, 32, 256), (4, 64, 32, 64), (2, 8, 32, 32), (2, 64, 16, 64), (3, 24, 8, 40), (1, 16, 32, 48)],
                          ids=lambda c: "x".join(map(str, c)))
 @pytest.mark.parametrize("form", ["lrelu", "residual", "plain"])
