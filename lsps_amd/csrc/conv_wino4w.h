@@ -92,29 +92,45 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
   f32x4 xr[6], dr[8];
   bool zt = false, zb = false;       // (uniform) x row 0 / 5 of the chunk requested last (= the one stored next) is outside
   __amdgpu_buffer_rsrc_t xrs, drs;
-  auto chunk_base = [&](int trow, bool want_x, bool want_d) {
-    const int n = trow / trows, ty = trow - n * trows;
-    if (want_x) {
-      zt = ty == 0;
-      zb = ty == trows - 1;
-      xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.X + (((long)n * p.C + cb * 32) * H + 4 * ty - 1) * 32), 0,
-                                              0x7fffffff, 0x00020000);
-    }
-    if (want_d)
-      drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.DY + (((long)n * p.M + kb * 64) * H + 4 * ty) * 32), 0,
-                                              0x7fffffff, 0x00020000);
+  // tile row (within its image) and byte offsets of the chunk requested next, advanced incrementally and branch-free; the
+  // last chunk is requested again instead of running past the end
+  int rq_t = t0, rq_ty = t0 % trows;
+  long rq_x = ((((long)(t0 / trows) * p.C + cb * 32) * H + 4 * rq_ty - 1) * 32) * 4;
+  long rq_d = ((((long)(t0 / trows) * p.M + kb * 64) * H + 4 * rq_ty) * 32) * 4;
+  const long jump_x = ((long)p.C * H * 32 - (trows - 1) * 128) * 4, jump_d = ((long)p.M * H * 32 - (trows - 1) * 128) * 4;
+  auto chunk_base = [&]() {
+    zt = rq_ty == 0;
+    zb = rq_ty == trows - 1;
+    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.X) + rq_x), 0, 0x7fffffff, 0x00020000);
+    drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.DY) + rq_d), 0, 0x7fffffff, 0x00020000);
+  };
+  auto chunk_advance = [&]() {
+    const bool adv = rq_t + 1 < t1, wrap = rq_ty + 1 == trows;
+    rq_t += adv ? 1 : 0;
+    rq_x += adv ? (wrap ? jump_x : 512) : 0;
+    rq_d += adv ? (wrap ? jump_d : 512) : 0;
+    rq_ty = adv ? (wrap ? 0 : rq_ty + 1) : rq_ty;
   };
   // rows -1 / H of the image do not exist: the load is redirected to the neighbouring (valid) row and the registers are
   // replaced by zeros when they are stored (selects on a uniform condition: no branch, the chunk loop stays one basic
   // block, which is what keeps the sched_barrier-pinned order and the asm MFMAs' operand distances intact)
   auto load_x = [&](int i) {
+#ifdef W4W_ABL_NOSTAGE
+    return;
+#endif
     const int so = i == 0 ? (zt ? 128 : 0) : (i == 5 ? (zb ? -128 : 0) : 0);
     xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, sv + i * 128, so, 0));
   };
   auto load_d = [&](int i) {
+#ifdef W4W_ABL_NOSTAGE
+    return;
+#endif
     dr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, sv + (i >> 1) * 128, (i & 1) * dk_off, 0));
   };
   auto store_x = [&](float *buf, int i) {
+#ifdef W4W_ABL_NOSTAGE
+    return;
+#endif
     float *d = buf + xs_lds + i * W4_LDW;
     f32x4 v = xr[i];
     if (i == 0) v = zt ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
@@ -124,6 +140,9 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
     d[3] = v[3];
   };
   auto store_d = [&](float *buf, int i) {
+#ifdef W4W_ABL_NOSTAGE
+    return;
+#endif
     *reinterpret_cast<f32x4 *>(buf + ds_lds + (i & 1) * 32 * W4W_DS + (i >> 1) * 32) = dr[i];
   };
 
@@ -151,29 +170,51 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
 
     // the next k-step's operands, in units that fit one MFMA gap
     auto RX = [&](const float *rx, int sn, int l) {                        // raw x row l of the block's five
+#ifdef W4W_ABL_NOLDS
+      return;
+#endif
       rx4[l] = *(lp4)(rx + 8 * sn + l * W4_LDW);
       rx2[l] = *(lp2)(rx + 8 * sn + l * W4_LDW + 4);
     };
     auto RD = [&](const float *rd, int sn, int kh, int l) {                // raw dy row l of k half kh
+#ifdef W4W_ABL_NOLDS
+      return;
+#endif
       rd4[kh][l] = *(lp4)(rd + 8 * sn + kh * 32 * W4W_DS + l * 32);
     };
     auto XR = [&](int l) {                                                 // row l: the block's three columns of d B
+#ifdef W4W_ABL_NOXF
+      return;
+#endif
       auto c = [&](int x) -> float { return x < 4 ? rx4[l][x] : rx2[l][x - 4]; };
       w4_xf<BJ>(c(BJ), c(BJ + 1), c(BJ + 2), c(BJ + 3), c(BJ + 4), P[l][0], P[l][1], P[l][2]);
     };
     auto XC = [&](int set, int jl) {                                       // column jl: the block's three rows of B^T (d B)
+#ifdef W4W_ABL_NOXF
+      return;
+#endif
       w4_xf<BI>(P[0][jl], P[1][jl], P[2][jl], P[3][jl], P[4][jl], V[set][jl], V[set][3 + jl], V[set][6 + jl]);
     };
     auto DR = [&](int kh, int l) {                                         // dy row l: the block's three columns of dY A^T
+#ifdef W4W_ABL_NOXF
+      return;
+#endif
       w4_at<BJ>(rd4[kh][l][0], rd4[kh][l][1], rd4[kh][l][2], rd4[kh][l][3], Q[kh][l][0], Q[kh][l][1], Q[kh][l][2]);
     };
     auto DC = [&](int set, int kh, int jl) {                               // column jl: the block's three rows of A (dY A^T)
+#ifdef W4W_ABL_NOXF
+      return;
+#endif
       w4_at<BI>(Q[kh][0][jl], Q[kh][1][jl], Q[kh][2][jl], Q[kh][3][jl], T[set][kh][jl], T[set][kh][3 + jl], T[set][kh][6 + jl]);
     };
 
-    // One k-step: 18 MFMAs on operand set SET; the gaps between them carry the reads + transforms of the NEXT k-step (tile
-    // pair sn of the buffer behind rx / rd) into set SET ^ 1, and a share of the staging of the next chunk (STAGE 0: request
-    // dy rows; 1: x registers -> LDS buffer sb; 2: dy registers -> LDS buffer sb; 3: request x rows).
+    // One k-step s: 18 MFMAs on operand set SET.  The gaps between them carry (a) the transforms of the raw rows already in
+    // registers into set SET ^ 1 (the operands of k-step s + 1), (b) in the last third, once those rows are consumed, the LDS
+    // reads of the raw rows of k-step s + 2 (tile pair sn of the buffer behind rx / rd): a wave is alone on its SIMD, so a
+    // read must be many gaps old when it is first used, or the wait stalls the matrix pipe, and (c) a share of the staging of
+    // the next chunks (STAGE 0: x registers -> LDS buffer sb; 1: dy registers -> sb; 2: request x rows; 3: request dy rows).
+    // STAGE 2 also carries the workgroup barrier (chunk j + 1 published) right before its reads, which are the first ones
+    // of that buffer.
     auto step = [&](auto set_c, auto stage_c, const float *rx, const float *rd, int sn, float *sb) {
       constexpr int SET = decltype(set_c)::value, NS = SET ^ 1, STAGE = decltype(stage_c)::value;
 #define W4W_SB __builtin_amdgcn_sched_barrier(0)
@@ -182,93 +223,102 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
   w4w_mfma<((m) < 16)>(T[SET][(m) & 1][(m) >> 1], V[SET][(m) >> 1], acc[(m) & 1][(m) >> 1]);                              \
   W4W_SB
       W4W_MMA(0);
-      RX(rx, sn, 0);
-      RX(rx, sn, 1);
-      if (STAGE == 0) load_d(0);
-      if (STAGE == 3) load_x(0);
-      W4W_MMA(1);
-      RX(rx, sn, 2);
-      if (STAGE == 1) store_x(sb, 0);
-      if (STAGE == 2) store_d(sb, 0);
-      W4W_MMA(2);
       XR(0);
-      RX(rx, sn, 3);
-      if (STAGE == 0) load_d(1);
-      W4W_MMA(3);
+      if (STAGE == 0) store_x(sb, 0);
+      if (STAGE == 1) store_d(sb, 0);
+      if (STAGE == 2) load_x(0);
+      if (STAGE == 3) load_d(0);
+      W4W_MMA(1);
       XR(1);
-      RX(rx, sn, 4);
-      if (STAGE == 2) store_d(sb, 1);
-      if (STAGE == 3) load_x(1);
-      W4W_MMA(4);
+      if (STAGE == 1) store_d(sb, 1);
+      if (STAGE == 3) load_d(1);
+      W4W_MMA(2);
       XR(2);
-      if (STAGE == 0) load_d(2);
-      if (STAGE == 1) store_x(sb, 1);
-      W4W_MMA(5);
+      if (STAGE == 0) store_x(sb, 1);
+      if (STAGE == 2) load_x(1);
+      if (STAGE == 3) load_d(2);
+      W4W_MMA(3);
       XR(3);
-      RD(rd, sn, 0, 0);
-      RD(rd, sn, 0, 1);
-      if (STAGE == 2) store_d(sb, 2);
-      W4W_MMA(6);
+      if (STAGE == 1) store_d(sb, 2);
+      W4W_MMA(4);
       XR(4);
-      RD(rd, sn, 0, 2);
-      RD(rd, sn, 0, 3);
-      if (STAGE == 0) load_d(3);
-      if (STAGE == 3) load_x(2);
-      W4W_MMA(7);
+      if (STAGE == 0) store_x(sb, 2);
+      if (STAGE == 1) store_d(sb, 3);
+      if (STAGE == 2) load_x(2);
+      if (STAGE == 3) load_d(3);
+      W4W_MMA(5);
       XC(NS, 0);
-      if (STAGE == 1) store_x(sb, 2);
-      if (STAGE == 2) store_d(sb, 3);
-      W4W_MMA(8);
+      if (STAGE == 1) store_d(sb, 4);
+      if (STAGE == 3) load_d(4);
+      W4W_MMA(6);
       XC(NS, 1);
-      RD(rd, sn, 1, 0);
-      RD(rd, sn, 1, 1);
-      if (STAGE == 0) load_d(4);
-      W4W_MMA(9);
+      if (STAGE == 0) store_x(sb, 3);
+      if (STAGE == 2) load_x(3);
+      W4W_MMA(7);
       XC(NS, 2);
-      RD(rd, sn, 1, 2);
-      RD(rd, sn, 1, 3);
-      if (STAGE == 2) store_d(sb, 4);
-      if (STAGE == 3) load_x(3);
-      W4W_MMA(10);
+      if (STAGE == 1) store_d(sb, 5);
+      if (STAGE == 3) load_d(5);
+      W4W_MMA(8);
       DR(0, 0);
       DR(0, 1);
-      if (STAGE == 0) load_d(5);
-      if (STAGE == 1) store_x(sb, 3);
-      W4W_MMA(11);
+      if (STAGE == 0) store_x(sb, 4);
+      if (STAGE == 2) load_x(4);
+      W4W_MMA(9);
       DR(0, 2);
       DR(0, 3);
-      if (STAGE == 2) store_d(sb, 5);
-      W4W_MMA(12);
+      if (STAGE == 1) store_d(sb, 6);
+      if (STAGE == 3) load_d(6);
+      W4W_MMA(10);
       DC(NS, 0, 0);
       DC(NS, 0, 1);
-      if (STAGE == 0) load_d(6);
-      if (STAGE == 3) load_x(4);
-      W4W_MMA(13);
+      if (STAGE == 0) store_x(sb, 5);
+      if (STAGE == 1) store_d(sb, 7);
+      if (STAGE == 2) load_x(5);
+      if (STAGE == 3) load_d(7);
+      W4W_MMA(11);
       DC(NS, 0, 2);
       DR(1, 0);
-      if (STAGE == 1) store_x(sb, 4);
-      if (STAGE == 2) store_d(sb, 6);
-      W4W_MMA(14);
+      if (STAGE == 2) __syncthreads();
+      W4W_MMA(12);
       DR(1, 1);
       DR(1, 2);
-      if (STAGE == 0) load_d(7);
-      W4W_MMA(15);
+      RX(rx, sn, 0);
+      RX(rx, sn, 1);
+      W4W_MMA(13);
       DR(1, 3);
       DC(NS, 1, 0);
-      if (STAGE == 2) store_d(sb, 7);
-      if (STAGE == 3) load_x(5);
-      W4W_MMA(16);
+      RX(rx, sn, 2);
+      RX(rx, sn, 3);
+      W4W_MMA(14);
       DC(NS, 1, 1);
       DC(NS, 1, 2);
-      if (STAGE == 1) store_x(sb, 5);
+      RX(rx, sn, 4);
+      RD(rd, sn, 0, 0);
+      RD(rd, sn, 0, 1);
+      W4W_MMA(15);
+      RD(rd, sn, 0, 2);
+      RD(rd, sn, 0, 3);
+      RD(rd, sn, 1, 0);
+      W4W_MMA(16);
+      RD(rd, sn, 1, 1);
+      RD(rd, sn, 1, 2);
+      RD(rd, sn, 1, 3);
       W4W_MMA(17);
       W4W_SB;
 #undef W4W_MMA
     };
+    auto read_raw = [&](const float *rx, const float *rd, int sn) {
+#pragma unroll
+      for (int l = 0; l < 5; ++l) RX(rx, sn, l);
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) RD(rd, sn, kh, l);
+    };
 
     if (t0 < t1) {
-      // prologue: chunk t0 -> buffer 0, x rows of chunk t0 + 1 requested, operands of k-step 0
-      chunk_base(t0, true, true);
+      // prologue: chunk t0 -> buffer 0, chunk t0 + 1 requested, operands of k-step 0 (set 0), raw rows of k-step 1
+      chunk_base();
 #pragma unroll
       for (int i = 0; i < 6; ++i) load_x(i);
 #pragma unroll
@@ -278,16 +328,14 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
       for (int i = 0; i < 6; ++i) store_x(w4w_lds, i);
 #pragma unroll
       for (int i = 0; i < 8; ++i) store_d(w4w_lds, i);
-      chunk_base(min(t0 + 1, t1 - 1), true, false);
+      chunk_advance();
+      chunk_base();
 #pragma unroll
       for (int i = 0; i < 6; ++i) load_x(i);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) load_d(i);
       __syncthreads();
-#pragma unroll
-      for (int l = 0; l < 5; ++l) RX(rdx0, 0, l);
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-        for (int l = 0; l < 4; ++l) RD(rdd0, 0, kh, l);
+      read_raw(rdx0, rdd0, 0);
 #pragma unroll
       for (int l = 0; l < 5; ++l) XR(l);
 #pragma unroll
@@ -299,6 +347,7 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
 #pragma unroll
         for (int jl = 0; jl < 3; ++jl) DC(0, kh, jl);
       }
+      read_raw(rdx0, rdd0, 1);
       asm volatile("s_nop 4" ::: "memory");          // VALU -> asm MFMA operand distance for the first k-step
       // chunk j lives in buffer (j - t0) & 1.  The last chunk stages / transforms a clamped (valid) chunk nobody consumes.
       int bo = 0;
@@ -306,18 +355,30 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
         const int nbo = W4W_BUF - bo;
         const float *rx = rdx0 + bo, *rd = rdd0 + bo;
         float *sb = w4w_lds + nbo;
-        chunk_base(min(j + 1, t1 - 1), false, true);
-        step(w4_int<0>(), w4_int<0>(), rx, rd, 1, sb);          // + request the dy rows of chunk j + 1
-        step(w4_int<1>(), w4_int<1>(), rx, rd, 2, sb);          // + x rows of chunk j + 1: registers -> buffer nbo
-        step(w4_int<0>(), w4_int<2>(), rx, rd, 3, sb);          // + dy rows of chunk j + 1: registers -> buffer nbo
-        __syncthreads();
-        chunk_base(min(j + 2, t1 - 1), true, false);
-        step(w4_int<1>(), w4_int<3>(), rdx0 + nbo, rdd0 + nbo, 0, sb);   // + request the x rows of chunk j + 2
+        step(w4_int<0>(), w4_int<0>(), rx, rd, 2, sb);          // + x rows of chunk j + 1: registers -> buffer nbo
+        step(w4_int<1>(), w4_int<1>(), rx, rd, 3, sb);          // + dy rows of chunk j + 1: registers -> buffer nbo
+        chunk_advance();
+        chunk_base();
+        step(w4_int<0>(), w4_int<2>(), rdx0 + nbo, rdd0 + nbo, 0, sb);   // + request x of chunk j + 2; barrier; first reads of nbo
+        step(w4_int<1>(), w4_int<3>(), rdx0 + nbo, rdd0 + nbo, 1, sb);   // + request dy of chunk j + 2
         bo = nbo;
       }
     }
 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");        // the last MFMAs' results (18 wait states before a VALU read)
+#ifdef W4W_ABL_NOEPI
+    {
+      float a = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a += acc[kh][q][r];
+      if (a == 123.456f) p.part[tid] = a;
+      return;
+    }
+#endif
     // partial sums: part[z][(3 BI + il) * 6 + 3 BJ + jl][k][c]; accumulator register r = row (r & 3) + 8 (r >> 2) + 4 half
     const long MC = (long)p.M * p.C;
     float *pz = p.part + (long)z * 36 * MC + (long)(kb * 64 + 4 * half) * p.C + cb * 32 + l31;
