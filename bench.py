@@ -145,6 +145,9 @@ def main():
                     help="exps/<exp>.yaml: 'nicvl' with --dtype bf16 --batch 256 is BASELINE config 5 on one GPU")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary workloads (estimate3, fwd-only)')
+    ap.add_argument('--graphs', action='store_true',
+                    help='replay the pretrain step from hipGraphs (LSPSTrainer.use_graphs); the per-kernel HIP events cannot be '
+                         'recorded inside a replay, so the roofline block is empty: an experiment, not the default')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'nccl' = RCCL, one GPU per rank (default); 'gloo': ranks may SHARE a GPU (local_rank %% device count) "
                          "- the data-parallel machinery on a 1-GPU box, not a performance number")
@@ -209,12 +212,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.graphs and world == 1:
+        tr.use_graphs(True)
+        pretrain_step()                 # eager warm-up of the two signatures; the next call captures
     for _ in range(args.warmup):
         pretrain_step()
     for r_ in tr._reducers.values():
         r_.take_stats()                 # count the gradient exchange of the timed region only
     ops.profiler.reset()
-    ops.profiler.enabled = os.environ.get('LSPS_BENCH_NO_EVENTS') != '1'   # debugging aid: time without the HIP events
+    ops.profiler.enabled = os.environ.get('LSPS_BENCH_NO_EVENTS') != '1' and not args.graphs   # debugging aid: no HIP events
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -222,6 +228,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.profiler.enabled = False
+    if args.graphs:
+        tr.use_graphs(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -265,7 +273,14 @@ def main():
             'launched_during_backward_per_step': r['early'] / max(r['steps'], 1),
             'allreduce_exposed_ms_per_step': r['exposed_ms'] / max(r['steps'], 1)}}
     if not args.no_extra and world == 1:
-        t_est = timed(lambda: tr.post_update(b['xa'], b['la'], b['xb'], b['lb'], b['ca'], b['cb'], 3, hp), 10)
+        est_step = lambda: tr.post_update(b['xa'], b['la'], b['xb'], b['lb'], b['ca'], b['cb'], 3, hp)   # noqa: E731
+        t_est_eager = timed(est_step, 10)
+        # the same step replayed from a hipGraph (LSPSTrainer.use_graphs: forward + losses + backward captured, Adam and
+        # the loss read-out after the replay): the eager step is bound by the ~400 launches' host side, not by the GPU
+        tr.use_graphs(True)
+        est_step()                      # warm-up call of this signature was the eager timing above; this one captures
+        t_est = timed(est_step, 20)
+        tr.use_graphs(False)
         tr.gen.eval()
         with torch.no_grad():
             t_fwd = timed(lambda: tr.gen(b['xa'], b['xb']), 3)
@@ -276,6 +291,7 @@ def main():
             t_bf16 = timed(pretrain_step, 2)
             ops.set_math_mode('f32')
         extra = {'estimate3_step_bs%d' % args.batch: {'steps_per_s': 1.0 / t_est, 'ms_per_step': 1e3 * t_est,
+                                                       'hip_graph': True, 'eager_ms_per_step': 1e3 * t_est_eager,
                                                        'algorithmic_tflop_per_step': 0.579 * args.batch / 128.0,
                                                        'mfma_floor_ms': 0.579 * args.batch / 128.0 / F32_MFMA_PEAK_TFLOPS * 1e3},
                  'gen_forward_bs%d' % args.batch: {'calls_per_s': 1.0 / t_fwd, 'ms_per_call': 1e3 * t_fwd,

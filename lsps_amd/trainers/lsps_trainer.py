@@ -41,17 +41,81 @@ def _net(spec):
 
 def _weights_constant(fn):
     """The conv weights do not change inside an update method until its optimizer step (`_step` ends the scope just
-    before it): packed weight panels are cached for that long (ops.weight_cache_begin)."""
+    before it): packed weight panels are cached for that long (ops.weight_cache_begin).  With `use_graphs(True)` the
+    method's launches (forward, losses, backward: everything up to the optimizer step) are captured into a hipGraph the
+    second time a call signature is seen and replayed from then on (`_GraphedUpdate`)."""
     import functools
 
-    @functools.wraps(fn)
-    def wrapped(self, images_a, *a, **k):
+    def eager(self, images_a, *a, **k):
         ops.weight_cache_begin(images_a.device)
         try:
             return fn(self, images_a, *a, **k)
         finally:
             ops.weight_cache_end()
+
+    @functools.wraps(fn)
+    def wrapped(self, images_a, *a, **k):
+        if not self._graphs_on or lsps_dist.active():
+            return eager(self, images_a, *a, **k)
+        return self._graphed(fn.__name__, eager, (images_a,) + a, k)
     return wrapped
+
+
+def _flatten_tensors(obj, out):
+    """Tensor leaves of nested tuples / lists / dicts in a fixed order; returns a hashable description of the rest."""
+    if torch.is_tensor(obj):
+        out.append(obj)
+        return ('T', tuple(obj.shape), str(obj.dtype))
+    if isinstance(obj, (tuple, list)):
+        return (type(obj).__name__,) + tuple(_flatten_tensors(o, out) for o in obj)
+    if isinstance(obj, dict):
+        return ('dict',) + tuple((k, _flatten_tensors(obj[k], out)) for k in sorted(obj))
+    return ('V', repr(obj))
+
+
+def _rebuild(obj, it):
+    if torch.is_tensor(obj):
+        return next(it)
+    if isinstance(obj, (tuple, list)):
+        return type(obj)(_rebuild(o, it) for o in obj)
+    if isinstance(obj, dict):
+        return dict((k, _rebuild(obj[k], it)) for k in sorted(obj))
+    return obj
+
+
+class _GraphedUpdate(object):
+    """One update method at one call signature as a hipGraph: static copies of the tensor arguments, the captured launches
+    (zero_grad memset, forward, losses, backward into the gradient arena, the stacked loss scalars), and the host-side
+    facts a replay must restore (which parameters got a gradient; the pending optimizer step)."""
+
+    def __init__(self, trainer, eager, args, kwargs, pool):
+        self.static_in = []
+        _flatten_tensors((args, kwargs), self.static_in)
+        self.static_in = [t.clone() for t in self.static_in]
+        a, k = _rebuild((args, kwargs), iter(self.static_in))
+        self.graph = torch.cuda.CUDAGraph()
+        trainer._capturing = self
+        self.pending = None
+        try:
+            with torch.cuda.graph(self.graph, pool=pool):
+                self.result = eager(trainer, *a, **k)
+        finally:
+            trainer._capturing = None
+        assert self.pending is not None, "update method did not reach _step"
+        key, opt, names, scal = self.pending
+        self.touched = list(opt.arena.touched)
+
+    def replay(self, trainer, args, kwargs):
+        fresh = []
+        _flatten_tensors((args, kwargs), fresh)
+        for dst, src in zip(self.static_in, fresh):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        self.graph.replay()
+        key, opt, names, scal = self.pending
+        opt.arena.touched[:] = self.touched
+        trainer._finish_step(opt, names, scal, None)
+        return self.result
 
 
 class LSPSTrainer(nn.Module):
@@ -75,6 +139,11 @@ class LSPSTrainer(nn.Module):
             net.apply(gaussian_weights_init)
         self.gpu = None
         self._reducers = {}
+        self._graphs_on = False
+        self._graphs = {}
+        self._graph_seen = set()
+        self._graph_pool = None
+        self._capturing = None
 
     # ------------------------------------------------------------------ device / arenas
     def cuda(self, gpu=None):
@@ -105,12 +174,43 @@ class LSPSTrainer(nn.Module):
         for opt in (self.dis_opt, self.gen_opt, self.vae_opt):
             opt.sync_from_rank0()
 
+    def use_graphs(self, on=True):
+        """hipGraph replay of dis_update / gen_update / post_update (single process only; under torch.distributed the
+        methods stay eager).  A call signature = method + tensor shapes + every non-tensor argument (mode, the
+        hyperparameter dict, feat_mat ...) + train/eval state; its first call runs eagerly (warm-up: workspaces, kernel
+        attributes), the second is captured, later ones replay.  Results are those of the eager path (same kernels, same
+        order); the tensors a graphed method returns are static buffers overwritten by the next replay.  Random draws
+        (GaussianNoiseLayer, the VAE code) come from torch's graph-safe generator offsets."""
+        self._graphs_on = bool(on)
+        if not on:
+            self._graphs.clear()
+            self._graph_seen.clear()
+        return self
+
+    def _graphed(self, name, eager, args, kwargs):
+        tensors = []
+        sig = (name, _flatten_tensors((args, kwargs), tensors), self.gen.training, self.dis.training,
+               ops.get_winograd(), ops.get_math_mode())
+        g = self._graphs.get(sig)
+        if g is not None:
+            return g.replay(self, args, kwargs)
+        if sig not in self._graph_seen:                  # warm-up call: eager
+            self._graph_seen.add(sig)
+            return eager(self, *args, **kwargs)
+        torch.cuda.synchronize()
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        g = self._graphs[sig] = _GraphedUpdate(self, eager, args, kwargs, self._graph_pool)
+        # the capture only recorded the launches: run them once for this call's result
+        return g.replay(self, args, kwargs)
+
     def _step(self, key, opt, loss, names, tensors, sig):
         """backward + gradient exchange + optimizer step + publication of the step's scalars (stored as numpy values like
         the reference, ONE device->host copy).  `sig` identifies the graph of this step for the reducer: it learns which
         parameters get gradients under that signature and launches each bucket during backward (lsps_amd/dist.py).  Under
         data parallelism the scalars are summed over ranks by one tiny all-reduce launched BEFORE backward (they are
-        forward results), so publishing costs no second host synchronisation."""
+        forward results), so publishing costs no second host synchronisation.  While a hipGraph is being captured the
+        optimizer step and the host copy are left to the replay (`_finish_step`)."""
         red = self._reducers[key]
         scal = torch.stack([t.detach().reshape(()).float() for t in tensors])
         red.begin(sig, scalars=scal if lsps_dist.active() else None)
@@ -119,8 +219,13 @@ class LSPSTrainer(nn.Module):
             red.finish()
         finally:
             ops.weight_cache_end()          # the optimizer is about to change the weights
+        if self._capturing is not None:
+            self._capturing.pending = (key, opt, list(names), scal)
+            return
+        self._finish_step(opt, names, scal, red.reduced_scalars())
+
+    def _finish_step(self, opt, names, scal, mean):
         opt.step()
-        mean = red.reduced_scalars()
         vals = (scal if mean is None else mean).cpu().numpy()
         for k, v in zip(names, vals):
             setattr(self, k, np.asarray(v, dtype=np.float32))
