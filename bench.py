@@ -308,37 +308,45 @@ def main():
         dom = prof.get(dom_name)
         roofline = None
         traffic = None
-        try:        # PMC traffic is collected offline (rocprofv3 --pmc cannot run inside the timed bench)
-            with open(os.path.join(REPO, 'profiles', 'r1_traffic.json')) as f:
-                tj = json.load(f).get(dom_name)
-            if tj:   # scaled from the profiled launch shape to this run's average launch by algorithmic work
-                traffic = tj['hbm_bytes_per_launch'] * dom['gflop_per_launch'] / tj['gflop_per_launch']
-        except (OSError, ValueError, TypeError):
-            traffic = None
+        traffic_file = None
+        for tf in ('r2_traffic.json', 'r1_traffic.json'):   # PMC traffic is collected offline (rocprofv3 --pmc cannot run inside the timed bench)
+            try:
+                with open(os.path.join(REPO, 'profiles', tf)) as f:
+                    tj = json.load(f).get(dom_name)
+                if tj:   # scaled from the profiled launch shape to this run's average launch by algorithmic work
+                    traffic = tj['hbm_bytes_per_launch'] * dom['gflop_per_launch'] / tj['gflop_per_launch']
+                    traffic_file = tf
+                    break
+            except (OSError, ValueError, TypeError, KeyError):
+                traffic = None
         if dom:
             mfma = 'v_mfma_f32_32x32x2_f32' if args.dtype == 'f32' else 'v_mfma_f32_32x32x16_bf16'
             if args.dtype != 'f32':
                 traffic = None          # the PMC passes in profiles/ were taken in the f32 mode
-            wino = dom_name == 'wino_f3x3_kernel'
-            roofline = {'bound': 'mfma', 'kernel': dom_name + (' (fused Winograd F(2x2,3x3) conv on %s)' if wino else
-                                                               ' (implicit-GEMM conv on %s)') % mfma,
+            wino = dom_name in ('wino_f3x3_kernel', 'wino4_f3x3_kernel', 'wino4_w3x3_kernel')
+            wino_x = 2.25 if dom_name == 'wino_f3x3_kernel' else 4.0      # algorithmic multiplies per issued MFMA multiply
+            roofline = {'bound': 'mfma', 'kernel': dom_name + ((' (fused Winograd F(2x2,3x3) conv on %s)' if wino_x == 2.25 else
+                                                                ' (fused Winograd F(4x4,3x3) conv + InstanceNorm epilogue on %s)')
+                                                               if wino else ' (implicit-GEMM conv on %s)') % mfma,
                         'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                         'frac': dom['tflops'] / peak, 'traffic': traffic,
                         'traffic_note': 'HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE KB, calibrated), '
-                                        'profiles/r1_traffic.json; scaled to this run\'s mean launch size',
+                                        'profiles/%s; scaled to this run\'s mean launch size' % (traffic_file or 'r2_traffic.json'),
                         'launches': dom['launches'], 'avg_launch_ms': dom['avg_ms'],
                         'algorithmic_gflop_per_launch': dom['gflop_per_launch'],
                         'share_of_step_time': dom['total_ms'] / (1e3 * elapsed),
                         'per_kernel': prof}
             if wino:
                 # `achieved` counts ALGORITHMIC flops (2*N*K*P*Q*C*9), the contract's definition; the kernel
-                # issues 16 MFMA multiplies per 36 algorithmic ones, so the matrix pipe itself runs at achieved / 2.25
-                roofline['mfma_issued_tflops'] = dom['tflops'] / 2.25
-                roofline['mfma_issued_frac'] = dom['tflops'] / 2.25 / peak
-                roofline['note'] = ('frac > 1 is not a measurement error: Winograd F(2x2,3x3) needs 2.25x fewer multiplies '
+                # issues 16 (F2) / 36 (F4) MFMA multiplies per 36 / 144 algorithmic ones, so the matrix pipe itself runs at
+                # achieved / 2.25 resp. / 4
+                roofline['mfma_issued_tflops'] = dom['tflops'] / wino_x
+                roofline['mfma_issued_frac'] = dom['tflops'] / wino_x / peak
+                roofline['note'] = ('frac > 1 is not a measurement error: Winograd F(%s,3x3) needs %.2fx fewer multiplies '
                                     'than the algorithmic count that `achieved` is defined on; mfma_issued_frac is the '
                                     'utilisation of the f32 MFMA pipe (its sustained ceiling is 0.874, '
-                                    'profiles/r1i_mfma_sustained_probe.txt)')
+                                    'profiles/r1i_mfma_sustained_probe.txt; plain VALU does not overlap the f32 MFMA, '
+                                    'profiles/r2_mfma_valu_overlap.txt)' % ('2x2' if wino_x == 2.25 else '4x4', wino_x))
         out = {
             'metric': 'depth_train steps/sec (128x128x1, bs=128)', 'value': world * args.steps / elapsed,
             'unit': 'steps/s',

@@ -105,6 +105,8 @@ def run(opts, trainer_factory=None, loader_a=None, loader_b=None, test_batches=N
                 trainer.dis_sch.step()
                 trainer.gen_sch.step()
         trainer.cuda(gpu)
+        if getattr(opts, 'graphs', False):
+            trainer.use_graphs(True)        # hipGraph replay of the update steps (single process)
         try:                                                                             # :116-124
             trainer.load_vae(config.snapshot_prefix, 2 + opts.frac if mode_idx in (3, 4) else opts.frac)
         except Exception:
@@ -180,6 +182,7 @@ def build_parser():
     p.add_argument('--batch_size', type=int, default=0, help="override (reference: 1 in pretrain, YAML in estimate)")
     p.add_argument('--iterations', type=int, default=0, help="stop after this many iterations (default: YAML max_iterations)")
     p.add_argument('--data', type=str, default='synthetic', choices=['synthetic'])
+    p.add_argument('--graphs', action='store_true', help="replay dis_update / gen_update / post_update from hipGraphs")
     p.add_argument('--augment', action='store_true', help="augment every batch as the datasets do (geometry on the host, pixels on the GPU)")
     return p
 
