@@ -88,6 +88,13 @@ int lsps_conv2d_dgrad(const float *dy, const float *w, float *dx,
 int lsps_conv2d_dgrad_acc(const float *dy, const float *w, const float *addend, float *dx,
                           int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
                           void *ws, size_t ws_bytes, void *stream);
+/* dx = backward of [InstanceNorm2d + LeakyReLU(slope)] applied to conv2d_dgrad(dy, w): the input gradient of the SECOND
+ * conv of a residual block pushed through the norm + activation in front of it (reference: autograd through
+ * common_net.py:168-171 into :162), with the norm recovered from its saved OUTPUT `out_saved` [N,C,H,W] and `rstd` [N*C]
+ * (as written by lsps_conv2d_in_fwd / lsps_inorm_fwd).  On 32x32 maps it happens in the epilogue of the F(4x4,3x3) dgrad
+ * kernel (the un-normalised gradient never reaches HBM); otherwise dgrad followed by lsps_inorm_bwd in place. */
+int lsps_conv2d_dgrad_inbwd(const float *dy, const float *w, const float *out_saved, const float *rstd, float *dx,
+                            int N, int C, int H, int W, int K, float slope, void *ws, size_t ws_bytes, void *stream);
 int lsps_conv2d_wgrad(const float *x, const float *dy, float *dw, float *db /*nullable*/,
                       int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
                       void *ws, size_t ws_bytes, void *stream);

@@ -462,6 +462,64 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
   const int orow = 16 * wt + 4 * tr;
   float *ybase = p.Y + ((long)n * p.M + kbase) * HW + orow * 32 + 4 * tc;
 
+  if (p.norm == 3) {
+    // BACKWARD of the InstanceNorm + LeakyReLU in front of this (dgrad) conv, recovered from that layer's saved OUTPUT o (p.R)
+    // and rstd, on the gradient d this conv just produced (norm_act.hip: inorm_bwd_kernel, activation variant):
+    //   g = d * lrelu'(o),  xh = o > 0 ? o : o / slope,  out = rstd * (g - mean(g) - xh * mean(g * xh))
+    // Both plane sums in ONE pass over the registers; the un-normalised gradient never reaches HBM.
+    __syncthreads();                             // phase-2 regions are read
+    float *red = w4_lds;                         // [sum 2][wt 2][wp 4][half 2][i 4]
+    const float inv_slope = 1.f / p.slope;
+    float xh[4][4][4], s[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float *om = p.R + (ybase - p.Y) + (long)i * HW;
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int yy = 0; yy < 4; ++yy) {
+        const f32x4 o = *reinterpret_cast<const f32x4 *>(om + yy * 32);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const bool pos = o[x] > 0.f;
+          const float h = pos ? o[x] : o[x] * inv_slope;
+          const float g = pos ? y[i][yy][x] : y[i][yy][x] * p.slope;
+          xh[i][yy][x] = h;
+          y[i][yy][x] = g;
+          a1 += g;
+          a2 = fmaf(g, h, a2);
+        }
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        a1 += __shfl_xor(a1, o, 64);
+        a2 += __shfl_xor(a2, o, 64);
+      }
+      s[0][i] = a1;
+      s[1][i] = a2;
+    }
+    if (l31 == 0) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[((q * 2 + wt) * 4 + wp) * 8 + half * 4 + i] = s[q][i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float m1 = (red[((0 * 2 + 0) * 4 + wp) * 8 + half * 4 + i] + red[((0 * 2 + 1) * 4 + wp) * 8 + half * 4 + i]) * (1.f / 1024.f);
+      const float m2 = (red[((1 * 2 + 0) * 4 + wp) * 8 + half * 4 + i] + red[((1 * 2 + 1) * 4 + wp) * 8 + half * 4 + i]) * (1.f / 1024.f);
+      const float rs = p.rstd[(long)n * p.M + kbase + i];
+      float *ym = ybase + (long)i * HW;
+#pragma unroll
+      for (int yy = 0; yy < 4; ++yy) {
+        f32x4 ov;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ov[x] = rs * (y[i][yy][x] - m1 - xh[i][yy][x] * m2);
+        *reinterpret_cast<f32x4 *>(ym + yy * 32) = ov;
+      }
+    }
+    return;
+  }
   if (p.norm) {
     // InstanceNorm over the (n, k) plane = 64 tiles = the 32 lanes of this half in waves (wp, wt = 0) and (wp, wt = 1).
     // Two passes over the registers (mean, then centred sum of squares), each: 16-value lane sum, xor-shuffles inside

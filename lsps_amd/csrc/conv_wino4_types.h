@@ -21,11 +21,12 @@ struct Wino4Params {
   const float *X, *U, *bias;
   const float *R;                // optional addend with Y's layout (dgrad skip connection / residual)
   float *Y;
-  float *rstd;                   // [N*M], written when norm != 0
+  float *rstd;                   // [N*M], written when norm is 1 or 2, READ when norm == 3
   int Cx, M, N;
   int act;
   float slope;
   int norm;                      // 0: y = act(conv + bias) + R;  1: y = lrelu_slope(IN(conv)) (slope < 0: none);  2: y = IN(conv) + R
+                                 // 3: y = backward of IN + LeakyReLU(slope) applied to conv, from that layer's saved output R and rstd
   float eps;
 };
 

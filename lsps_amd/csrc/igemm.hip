@@ -1573,6 +1573,30 @@ int lsps_conv2d_dgrad_acc(const float *dy, const float *w, const float *addend, 
   return 0;
 }
 
+int lsps_conv2d_dgrad_inbwd(const float *dy, const float *w, const float *out_saved, const float *rstd, float *dx, int N, int C,
+                            int H, int W, int K, float slope, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(dy && w && out_saved && rstd && dx && ws, "conv2d_dgrad_inbwd: null pointer");
+  LSPS_CHECK_ARG(conv_args_ok(N, C, H, W, K, 3, 3, 1, 1), "conv2d_dgrad_inbwd: unsupported geometry");
+  LSPS_CHECK_ARG(slope > 0.f, "conv2d_dgrad_inbwd: needs an invertible LeakyReLU slope (> 0)");
+  // 32x32 maps: the F(4x4,3x3) dgrad kernel owns whole (n, c) planes of dx and applies the norm backward in its epilogue
+  if (W == 32 && wino4_ok(N, K, H, C)) {
+    TapList l;
+    l.T = 9;
+    for (int t = 0; t < 9; ++t) {
+      l.dh[t] = t / 3 - 1;
+      l.dw[t] = t % 3 - 1;
+      l.idx[t] = 8 - t;
+    }
+    return run_wino4(dy, w, nullptr, dx, N, K, C, 9L, (long)C * 9, l, LSPS_ACT_NONE, slope, ws, ws_bytes, (hipStream_t)stream,
+                     out_saved, 3, const_cast<float *>(rstd), 0.f);
+  }
+  // other shapes / modes: the dgrad kernel the dispatcher picks, then the norm backward pass in place
+  int rc = lsps_conv2d_dgrad(dy, w, dx, N, C, H, W, K, 3, 3, 1, 1, ws, ws_bytes, stream);
+  if (rc) return rc;
+  return lsps_inorm_bwd(dx, out_saved, nullptr, rstd, dx, N * C, H * W, slope, stream);
+}
+
 int lsps_conv2d_wgrad(const float *x, const float *dy, float *dw, float *db, int N, int C, int H, int W, int K, int R,
                       int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream) {
   (void)hipGetLastError();   // clear stale sticky errors left by other users of the runtime

@@ -366,13 +366,13 @@ class _ResBlockFn(torch.autograd.Function):
             with profiler.span(flops):
                 _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(a1), _lib.ptr(dh2), _lib.ptr(dw2), None, N, K, H, W, K, 3, 3, 1, 1,
                                                ws, wsb, st), 'conv2d_wgrad')
-        da1 = torch.empty_like(a1)
+        # dgrad of the second conv pushed through InstanceNorm + LeakyReLU in ONE call: on 32x32 maps the norm backward runs
+        # in the epilogue of the F(4x4,3x3) dgrad kernel (da1 never reaches HBM)
+        dh1 = torch.empty_like(a1)
         with profiler.span(flops):
-            _lib.check(L.lsps_conv2d_dgrad(_lib.ptr(dh2), _lib.ptr(w2), _lib.ptr(da1), N, K, H, W, K, 3, 3, 1, 1, ws, wsb,
-                                           st), 'conv2d_dgrad')
-        dh1 = dh2                                        # dh2 is dead from here on: reuse its storage
-        _lib.check(L.lsps_inorm_bwd(_lib.ptr(da1), _lib.ptr(a1), None, _lib.ptr(r1), _lib.ptr(dh1), N * K, H * W,
-                                    LRELU_SLOPE, st), 'inorm_bwd')
+            _lib.check(L.lsps_conv2d_dgrad_inbwd(_lib.ptr(dh2), _lib.ptr(w2), _lib.ptr(a1), _lib.ptr(r1), _lib.ptr(dh1), N, K, H,
+                                                 W, K, LRELU_SLOPE, ws, wsb, st), 'conv2d_dgrad_inbwd')
+        da1 = dh2                                        # dh2 is dead from here on: its storage receives dx below
         if ctx.needs_input_grad[1]:
             dw1 = torch.empty_like(w1)
             with profiler.span(flops):

@@ -113,8 +113,10 @@ class LeakyINSResBlock(nn.Module):
         """`drop_mask` (tests): the keep mask ALREADY divided by 1-p; default: drawn here in training mode."""
         c1, c2 = self.model[0], self.model[3]
         dropping = self.dropout > 0 and (self.training or drop_mask is not None)
-        if not dropping and c1.stride == 1 and c1.weight.shape[0] == c1.weight.shape[1] and torch.is_grad_enabled():
-            return ops.res_block(x, c1.weight, c2.weight)          # one autograd node (fused skip-gradient add)
+        if not dropping and c1.stride == 1 and c1.weight.shape[0] == c1.weight.shape[1]:
+            # one autograd node (fused conv + InstanceNorm entries, skip gradient added in the dgrad epilogue); also under
+            # no_grad (dis_update's generator pass, evaluation): nothing is saved then, the fused forward is the same
+            return ops.res_block(x, c1.weight, c2.weight)
         h = ops.conv2d(x, c1.weight, None, c1.stride, 1)
         h = ops.instance_norm_(h, None, LRELU_SLOPE)
         h = ops.conv2d(h, c2.weight, None, 1, 1)

@@ -631,6 +631,42 @@ def test_conv3x3_winograd_f4(case):
         ops.set_winograd(prev)
 
 
+@pytest.mark.parametrize("case", [(3, 256, 32, 256), (4, 64, 32, 32), (2, 32, 16, 64), (1, 24, 8, 16)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv3x3_dgrad_through_instance_norm_fused(case):
+    """lsps_conv2d_dgrad_inbwd = conv dgrad pushed through the InstanceNorm + LeakyReLU in front of the conv
+    (common_net.py:168-171 <- :162 in backward) against f64 autograd of the composition: the F(4x4,3x3) epilogue path on
+    32x32 maps, dgrad + in-place norm backward elsewhere.  (N, C, H, K): the conv maps C -> K channels, dx has C."""
+    _need_gpu()
+    from lsps_amd import _lib, ops
+    N, C, H, K = case
+    L = _lib.lib()
+    prev = ops.get_winograd()
+    ops.set_winograd('always')
+    try:
+        c0 = _rand(N, C, H, 32, seed=41).double().requires_grad_(True)          # pre-norm tensor
+        w = _rand(K, C, 3, 3, seed=42, scale=0.1)
+        gy = _rand(N, K, H, 32, seed=43)
+        a1 = F.leaky_relu(F.instance_norm(c0, eps=1e-5), 0.01)
+        F.conv2d(a1, w.double(), None, padding=1).backward(gy.double())
+        rstd = 1.0 / torch.sqrt(c0.detach().var(dim=(2, 3), unbiased=False) + 1e-5)
+        a1d, rd = a1.detach().float().cuda().contiguous(), rstd.float().reshape(-1).cuda().contiguous()
+        dx = torch.full((N, C, H, 32), float('nan'), device='cuda')
+        ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, 32, K, 3, 3, 1, 1), dx.device)
+        gyd, wd = gy.cuda(), w.cuda()                     # named: a temporary's block could be reused within the call expression
+        _lib.check(L.lsps_conv2d_dgrad_inbwd(_lib.ptr(gyd), _lib.ptr(wd), _lib.ptr(a1d), _lib.ptr(rd), _lib.ptr(dx),
+                                             N, C, H, 32, K, 0.01, ws, wsb, _lib.stream()), 'dgrad_inbwd')
+        f4 = H == 32 and C % 32 == 0 and K % 8 == 0
+        assert (L.lsps_last_kernel(None) == b'wino4_f3x3_kernel') == f4, L.lsps_last_kernel(None)
+        # where the normalised value is within round-off of 0 the LeakyReLU slope is decided by that round-off (see above)
+        xhat = F.instance_norm(c0.detach(), eps=1e-5)
+        diff = (dx.cpu().double() - c0.grad).abs() / c0.grad.abs().max()
+        off = diff > 1e-4
+        assert int(off.sum()) <= 64 and bool((xhat[off].abs() < 1e-3).all()), (int(off.sum()), float(diff.max()))
+    finally:
+        ops.set_winograd(prev)
+
+
 # (N, C, H, K): weight gradient in F(4x4,3x3) form (conv_wino4w.h): 64 k x 32 c blocks, tile rows of 4 image rows split over
 # 256 / blocks workgroups (a multiple of 8 where possible), partial sums reduced in double precision
 WINO4W_CASES = [
