@@ -99,6 +99,24 @@ int lsps_conv2d_wgrad(const float *x, const float *dy, float *dw, float *db /*nu
                       int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
                       void *ws, size_t ws_bytes, void *stream);
 
+/* ---- 3x3 / stride 2 / pad 1 convs on small feature maps in batch-innermost layout [C][H][W][N] ("CHWN") ---------------
+ * The discriminator trunk (reference lsps_nets.py:119-121 `_make_shared_net`: four LeakyReLUConv2d(tch, 2 tch, 3, 2, 1),
+ * common_net.py:250-252) runs on 16x16 ... 2x2 maps with 128 ... 2048 channels; with the batch innermost every
+ * (output position, tap) pair is a plain [K x C] x [C x N] GEMM over contiguous rows (no gather, padding taps skipped).
+ * x [C][H][W][N], w [K][C][3][3] (the reference's layout), y [K][H/2][W/2][N]; needs N % 4 == 0, C % 128 == 0,
+ * K % 128 == 0, even H and W.  lsps_transpose2d converts [R][S] -> [S][R] (NCHW <-> CHWN with R = N, S = C*H*W).
+ * The LeakyReLU backward + bias gradient of such a layer is lsps_act_bwd_bias(dy, y, dpre, db, 1, K, (H/2)*(W/2)*N, ...). */
+int lsps_transpose2d(const float *src, float *dst, long R, long S, void *stream);
+size_t lsps_conv3x3s2_chwn_workspace_bytes(int N, int C, int H, int W, int K);
+int lsps_conv3x3s2_chwn_fwd(const float *x, const float *w, const float *bias /*nullable*/, float *y,
+                            int N, int C, int H, int W, int K, int act, float slope,
+                            void *ws, size_t ws_bytes, void *stream);
+int lsps_conv3x3s2_chwn_dgrad(const float *dy, const float *w, float *dx, int N, int C, int H, int W, int K,
+                              void *ws, size_t ws_bytes, void *stream);
+/* dw[K,C,3,3] is OVERWRITTEN */
+int lsps_conv3x3s2_chwn_wgrad(const float *x, const float *dy, float *dw, int N, int C, int H, int W, int K,
+                              void *ws, size_t ws_bytes, void *stream);
+
 /* ---- ConvTranspose2d: replaces nn.ConvTranspose2d forward/backward -------------------------
  * call sites: common_net.py:262 (LeakyReLUConvTranspose2d), lsps_nets.py:226-227 (1x1 output),
  *             lsps_nets.py:17-23 (Mapping).

@@ -42,7 +42,7 @@ struct Wino4WParams {
 // wino4.hip: 0 or LSPS_E_HIP (lsps_last_error set)
 int wino4_launch_pack(const Wino4Pack &p, hipStream_t st);
 int wino4_launch(const Wino4Params &p, hipStream_t st);
-int wino4_launch_wgrad(const Wino4WParams &p, int splits, float *dW, hipStream_t st);
+int wino4_launch_wgrad(const Wino4WParams &p, int splits, float *dW, int waves /*4 or 8 per workgroup*/, hipStream_t st);
 
 }  // namespace lsps
 #endif

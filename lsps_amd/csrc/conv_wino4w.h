@@ -60,7 +60,13 @@ __device__ __forceinline__ void w4w_mfma(float a, float b, f32x16 &c) {
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
-__global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
+// KH = k halves per wave.  KH = 2: the design above (256 threads, one wave per SIMD, 18 accumulator tiles per wave).
+// KH = 1: 512 threads, two waves per SIMD, wave = (position block, k half) with 9 accumulator tiles: the x transform is
+// computed by both k-half waves (76 instead of 52 VALU per 9 MFMAs), but a filler beside an f32 MFMA costs ~2.2 cycles with
+// two waves on the SIMD against ~4 with one (tools/mfma_valu_overlap.hip).
+template <int KH>
+__global__ __launch_bounds__(KH == 2 ? 256 : 512, KH == 2 ? 1 : 2) void wino4_w3x3_kernel(Wino4WParams p) {
+  constexpr int NT = KH == 2 ? 256 : 512, XSEG = 1536 / NT, DSEG = 2048 / NT;
   extern __shared__ __attribute__((aligned(16))) float w4w_lds[];
   typedef const volatile f32x4 __attribute__((address_space(3))) *lp4;
   typedef const volatile f32x2 __attribute__((address_space(3))) *lp2;
@@ -68,6 +74,7 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
+  const int wp = wave & 3, kh0 = KH == 1 ? wave >> 2 : 0;
   // XCD-aware mapping (workgroups go to the 8 XCDs round-robin in launch order): all (k, c) blocks of one split of the
   // tile rows sit on ONE XCD, so its dy / x rows come from HBM once and from that XCD's L2 for the other blocks
   int cb = blockIdx.x, kb = blockIdx.y, z = blockIdx.z;
@@ -82,14 +89,17 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
   const int H = p.H, trows = H >> 2;                   // tile rows per image
   const int t0 = z * p.per_split, t1 = min(p.ntr, t0 + p.per_split);
 
-  // staging: x 32 c x 6 rows x 8 segments = 6 per thread (thread t: channel t/8, segment t%8, row i), dy 64 k x 4 rows x
-  // 8 segments = 8 per thread (channel t/8 + 32 (i&1), row i/2).  Buffer descriptors: uniform base + one 32-bit lane offset
-  const int sc = tid >> 3, sseg = tid & 7;
+  // staging: x 32 c x 6 rows x 8 segments = XSEG per thread (channel (t/8) % 32, segment t%8, rows xrow0 + i (KH = 2) or
+  // xrow0 + 2i (KH = 1, xrow0 = t/256)), dy 64 k x 4 rows x 8 segments = DSEG per thread (KH = 2: channel t/8 + 32 (i&1), row
+  // i/2; KH = 1: channel t/8, row i).  Buffer descriptors: uniform base + one 32-bit lane offset
+  const int sc = (tid >> 3) & 31, sseg = tid & 7, xrow0 = KH == 2 ? 0 : tid >> 8;
+  auto xrow = [&](int i) { return KH == 2 ? i : xrow0 + 2 * i; };
   const unsigned sv = (unsigned)(sc * H * 32 + sseg * 4) * 4u;
-  const int xs_lds = sc * W4W_XS + 1 + sseg * 4;                       // + i * W4_LDW
-  const int ds_lds = W4W_XBUF + sc * W4W_DS + sseg * 4;                // + (i & 1) * 32 * W4W_DS + (i >> 1) * 32
+  const unsigned svd = (unsigned)((tid >> 3) * H * 32 + sseg * 4) * 4u;
+  const int xs_lds = sc * W4W_XS + 1 + sseg * 4;                       // + row * W4_LDW
+  const int ds_lds = W4W_XBUF + (tid >> 3) * W4W_DS + sseg * 4;        // KH = 2: + (i & 1) * 32 * W4W_DS + (i >> 1) * 32; KH = 1: + i * 32
   const int dk_off = H * 32 * 32 * 4;                                  // bytes between dy channels k and k + 32
-  f32x4 xr[6], dr[8];
+  f32x4 xr[XSEG], dr[DSEG];
   bool zt = false, zb = false;       // (uniform) x row 0 / 5 of the chunk requested last (= the one stored next) is outside
   __amdgpu_buffer_rsrc_t xrs, drs;
   // tile row (within its image) and byte offsets of the chunk requested next, advanced incrementally and branch-free; the
@@ -118,23 +128,37 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
 #ifdef W4W_ABL_NOSTAGE
     return;
 #endif
-    const int so = i == 0 ? (zt ? 128 : 0) : (i == 5 ? (zb ? -128 : 0) : 0);
-    xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, sv + i * 128, so, 0));
+    const int r = xrow(i);
+    if (KH == 2) {
+      const int so = i == 0 ? (zt ? 128 : 0) : (i == 5 ? (zb ? -128 : 0) : 0);
+      xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, sv + i * 128, so, 0));
+    } else {
+      const int adj = (r == 0 && zt) ? 128 : ((r == 5 && zb) ? -128 : 0);
+      xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, sv + r * 128 + adj, 0, 0));
+    }
   };
   auto load_d = [&](int i) {
 #ifdef W4W_ABL_NOSTAGE
     return;
 #endif
-    dr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, sv + (i >> 1) * 128, (i & 1) * dk_off, 0));
+    if (KH == 2)
+      dr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, svd + (i >> 1) * 128, (i & 1) * dk_off, 0));
+    else
+      dr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, svd + i * 128, 0, 0));
   };
   auto store_x = [&](float *buf, int i) {
 #ifdef W4W_ABL_NOSTAGE
     return;
 #endif
-    float *d = buf + xs_lds + i * W4_LDW;
+    const int r = xrow(i);
+    float *d = buf + xs_lds + r * W4_LDW;
     f32x4 v = xr[i];
-    if (i == 0) v = zt ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
-    if (i == 5) v = zb ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
+    if (KH == 2) {
+      if (i == 0) v = zt ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
+      if (i == 5) v = zb ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
+    } else {
+      v = ((r == 0 && zt) || (r == 5 && zb)) ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
+    }
     d[0] = v[0];
     *reinterpret_cast<f32x2 *>(d + 1) = f32x2{v[1], v[2]};
     d[3] = v[3];
@@ -143,30 +167,31 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
 #ifdef W4W_ABL_NOSTAGE
     return;
 #endif
-    *reinterpret_cast<f32x4 *>(buf + ds_lds + (i & 1) * 32 * W4W_DS + (i >> 1) * 32) = dr[i];
+    const int off = KH == 2 ? (i & 1) * 32 * W4W_DS + (i >> 1) * 32 : i * 32;
+    *reinterpret_cast<f32x4 *>(buf + ds_lds + off) = dr[i];
   };
 
   // halo columns of the x rows (index 0 and 33): zero once in both buffers
-  for (int u = tid; u < 2 * 32 * 6 * 2; u += 256) {
+  for (int u = tid; u < 2 * 32 * 6 * 2; u += NT) {
     const int b = u / 384, rr = (u % 384) >> 1;
     w4w_lds[b * W4W_BUF + (rr / 6) * W4W_XS + (rr % 6) * W4_LDW + (u & 1) * 33] = 0.f;
   }
 
   auto body = [&](auto bi_c, auto bj_c) {
     constexpr int BI = decltype(bi_c)::value, BJ = decltype(bj_c)::value;
-    f32x16 acc[2][9];
+    f32x16 acc[KH][9];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < KH; ++h)
 #pragma unroll
       for (int q = 0; q < 9; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][q][r] = 0.f;
-    float T[2][2][9], V[2][9];                   // [set][k half][position], [set][position]
-    float P[5][3], Q[2][4][3];
-    f32x4 rx4[5], rd4[2][4];
+    float T[2][KH][9], V[2][9];                  // [set][k half][position], [set][position]
+    float P[5][3], Q[KH][4][3];
+    f32x4 rx4[5], rd4[KH][4];
     f32x2 rx2[5];
     const float *rdx0 = w4w_lds + l31 * W4W_XS + BI * W4_LDW + 4 * half;   // + buffer, + 8 s (tile 2s + half), + row * W4_LDW
-    const float *rdd0 = w4w_lds + W4W_XBUF + l31 * W4W_DS + 4 * half;      // + buffer, + 8 s, + 32 * W4W_DS (k half), + row * 32
+    const float *rdd0 = w4w_lds + W4W_XBUF + (kh0 * 32 + l31) * W4W_DS + 4 * half;   // + buffer, + 8 s, + 32 * W4W_DS (k half), + row * 32
 
     // the next k-step's operands, in units that fit one MFMA gap
     auto RX = [&](const float *rx, int sn, int l) {                        // raw x row l of the block's five
@@ -218,6 +243,66 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
     auto step = [&](auto set_c, auto stage_c, const float *rx, const float *rd, int sn, float *sb) {
       constexpr int SET = decltype(set_c)::value, NS = SET ^ 1, STAGE = decltype(stage_c)::value;
 #define W4W_SB __builtin_amdgcn_sched_barrier(0)
+      if constexpr (KH == 1) {
+        // two waves per SIMD, 9 MFMAs per k-step (compiler-allocated accumulators: the builtin's hazards are the compiler's)
+#define W4W_MMA1(m)                                                                                                       \
+  W4W_SB;                                                                                                                 \
+  acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(T[SET][0][m], V[SET][m], acc[0][m], 0, 0, 0);                          \
+  W4W_SB
+        // reads of the raw rows of k-step s + 1 (tile pair sn behind rx / rd) two gaps ahead of their transform: with two
+        // waves per SIMD the partner covers what is left of the LDS latency, and the raw registers live for half a k-step
+        // only (144 accumulator + 112 other registers is all a wave has at this occupancy)
+        if (STAGE == 3) __syncthreads();             // chunk j + 1 published: this step's reads are the first ones of its buffer
+        W4W_MMA1(0);
+        RX(rx, sn, 0);
+        RX(rx, sn, 1);
+        if (STAGE == 0) store_x(sb, 0);
+        if (STAGE == 1) store_d(sb, 0);
+        if (STAGE == 2) load_x(0);
+        if (STAGE == 3) load_d(0);
+        W4W_MMA1(1);
+        RX(rx, sn, 2);
+        RX(rx, sn, 3);
+        if (STAGE == 0) store_x(sb, 1);
+        if (STAGE == 1) store_d(sb, 1);
+        if (STAGE == 2) load_x(1);
+        if (STAGE == 3) load_d(1);
+        W4W_MMA1(2);
+        XR(0);
+        XR(1);
+        RX(rx, sn, 4);
+        if (STAGE == 0) store_x(sb, 2);
+        if (STAGE == 1) store_d(sb, 2);
+        if (STAGE == 2) load_x(2);
+        if (STAGE == 3) load_d(2);
+        W4W_MMA1(3);
+        XR(2);
+        XR(3);
+        RD(rd, sn, 0, 0);
+        RD(rd, sn, 0, 1);
+        if (STAGE == 1) store_d(sb, 3);
+        if (STAGE == 3) load_d(3);
+        W4W_MMA1(4);
+        XR(4);
+        XC(NS, 0);
+        RD(rd, sn, 0, 2);
+        RD(rd, sn, 0, 3);
+        W4W_MMA1(5);
+        XC(NS, 1);
+        XC(NS, 2);
+        W4W_MMA1(6);
+        DR(0, 0);
+        DR(0, 1);
+        DR(0, 2);
+        W4W_MMA1(7);
+        DR(0, 3);
+        DC(NS, 0, 0);
+        DC(NS, 0, 1);
+        W4W_MMA1(8);
+        DC(NS, 0, 2);
+        W4W_SB;
+#undef W4W_MMA1
+      } else {
 #define W4W_MMA(m)                                                                                                        \
   W4W_SB;                                                                                                                 \
   w4w_mfma<((m) < 16)>(T[SET][(m) & 1][(m) >> 1], V[SET][(m) >> 1], acc[(m) & 1][(m) >> 1]);                              \
@@ -306,12 +391,13 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
       W4W_MMA(17);
       W4W_SB;
 #undef W4W_MMA
+      }
     };
     auto read_raw = [&](const float *rx, const float *rd, int sn) {
 #pragma unroll
       for (int l = 0; l < 5; ++l) RX(rx, sn, l);
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
+      for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
         for (int l = 0; l < 4; ++l) RD(rd, sn, kh, l);
     };
@@ -320,20 +406,20 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
       // prologue: chunk t0 -> buffer 0, chunk t0 + 1 requested, operands of k-step 0 (set 0), raw rows of k-step 1
       chunk_base();
 #pragma unroll
-      for (int i = 0; i < 6; ++i) load_x(i);
+      for (int i = 0; i < XSEG; ++i) load_x(i);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) load_d(i);
+      for (int i = 0; i < DSEG; ++i) load_d(i);
       __syncthreads();                             // halo zero fill done
 #pragma unroll
-      for (int i = 0; i < 6; ++i) store_x(w4w_lds, i);
+      for (int i = 0; i < XSEG; ++i) store_x(w4w_lds, i);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) store_d(w4w_lds, i);
+      for (int i = 0; i < DSEG; ++i) store_d(w4w_lds, i);
       chunk_advance();
       chunk_base();
 #pragma unroll
-      for (int i = 0; i < 6; ++i) load_x(i);
+      for (int i = 0; i < XSEG; ++i) load_x(i);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) load_d(i);
+      for (int i = 0; i < DSEG; ++i) load_d(i);
       __syncthreads();
       read_raw(rdx0, rdd0, 0);
 #pragma unroll
@@ -341,13 +427,13 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
 #pragma unroll
       for (int jl = 0; jl < 3; ++jl) XC(0, jl);
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
+      for (int kh = 0; kh < KH; ++kh) {
 #pragma unroll
         for (int l = 0; l < 4; ++l) DR(kh, l);
 #pragma unroll
         for (int jl = 0; jl < 3; ++jl) DC(0, kh, jl);
       }
-      read_raw(rdx0, rdd0, 1);
+      if (KH == 2) read_raw(rdx0, rdd0, 1);
       asm volatile("s_nop 4" ::: "memory");          // VALU -> asm MFMA operand distance for the first k-step
       // chunk j lives in buffer (j - t0) & 1.  The last chunk stages / transforms a clamped (valid) chunk nobody consumes.
       int bo = 0;
@@ -355,12 +441,21 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
         const int nbo = W4W_BUF - bo;
         const float *rx = rdx0 + bo, *rd = rdd0 + bo;
         float *sb = w4w_lds + nbo;
-        step(w4_int<0>(), w4_int<0>(), rx, rd, 2, sb);          // + x rows of chunk j + 1: registers -> buffer nbo
-        step(w4_int<1>(), w4_int<1>(), rx, rd, 3, sb);          // + dy rows of chunk j + 1: registers -> buffer nbo
-        chunk_advance();
-        chunk_base();
-        step(w4_int<0>(), w4_int<2>(), rdx0 + nbo, rdd0 + nbo, 0, sb);   // + request x of chunk j + 2; barrier; first reads of nbo
-        step(w4_int<1>(), w4_int<3>(), rdx0 + nbo, rdd0 + nbo, 1, sb);   // + request dy of chunk j + 2
+        if constexpr (KH == 2) {                                // raw rows are read one k-step ahead of their transform
+          step(w4_int<0>(), w4_int<0>(), rx, rd, 2, sb);        // + x rows of chunk j + 1: registers -> buffer nbo
+          step(w4_int<1>(), w4_int<1>(), rx, rd, 3, sb);        // + dy rows of chunk j + 1: registers -> buffer nbo
+          chunk_advance();
+          chunk_base();
+          step(w4_int<0>(), w4_int<2>(), rdx0 + nbo, rdd0 + nbo, 0, sb);   // + request x of chunk j + 2; barrier; first reads of nbo
+          step(w4_int<1>(), w4_int<3>(), rdx0 + nbo, rdd0 + nbo, 1, sb);   // + request dy of chunk j + 2
+        } else {                                                // raw rows are read in the k-step that transforms them
+          step(w4_int<0>(), w4_int<0>(), rx, rd, 1, sb);
+          step(w4_int<1>(), w4_int<1>(), rx, rd, 2, sb);
+          chunk_advance();
+          chunk_base();
+          step(w4_int<0>(), w4_int<2>(), rx, rd, 3, sb);
+          step(w4_int<1>(), w4_int<3>(), rdx0 + nbo, rdd0 + nbo, 0, sb);   // barrier first; + request dy of chunk j + 2
+        }
         bo = nbo;
       }
     }
@@ -370,7 +465,7 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
     {
       float a = 0.f;
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
+      for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
         for (int q = 0; q < 9; ++q)
 #pragma unroll
@@ -383,15 +478,15 @@ __global__ __launch_bounds__(256, 1) void wino4_w3x3_kernel(Wino4WParams p) {
     const long MC = (long)p.M * p.C;
     float *pz = p.part + (long)z * 36 * MC + (long)(kb * 64 + 4 * half) * p.C + cb * 32 + l31;
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
+    for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
-        float *pq = pz + (long)((3 * BI + q / 3) * 6 + 3 * BJ + q % 3) * MC + (long)(kh * 32) * p.C;
+        float *pq = pz + (long)((3 * BI + q / 3) * 6 + 3 * BJ + q % 3) * MC + (long)((kh0 + kh) * 32) * p.C;
 #pragma unroll
         for (int r = 0; r < 16; ++r) pq[(long)((r & 3) + 8 * (r >> 2)) * p.C] = acc[kh][q][r];
       }
   };
-  switch (wave) {                                // wave-uniform: four instances of the main loop
+  switch (wp) {                                  // wave-uniform: four instances of the main loop
     case 0: body(w4_int<0>(), w4_int<0>()); break;
     case 1: body(w4_int<0>(), w4_int<1>()); break;
     case 2: body(w4_int<1>(), w4_int<0>()); break;

@@ -1064,6 +1064,7 @@ static int run_wino_w(const float *dy, const float *x, float *dW, int N, int C, 
 // F(4x4,3x3) form of the same weight gradient (conv_wino4w.h): one 256-thread workgroup per CU owns a 64 k x 32 c block of
 // all 36 positions; the tile rows (4 image rows each) are split over 256 / blocks workgroups, a multiple of 8 where
 // possible (one split per XCD group).  LSPS_WINO4W=0 keeps the F(2x2,3x3) kernel (A/B comparisons).
+#define W4W_DEFAULT_WAVES 4
 static int wino4_w_splits(int M, int C, int ntr) {
   int s = 256 / ((M / 64) * (C / 32));
   if (s > ntr) s = ntr;
@@ -1102,7 +1103,12 @@ static int run_wino4_w(const float *dy, const float *x, float *dW, int N, int C,
   p.ntr = N * H / 4;
   const int splits = wino4_w_splits(M, C, p.ntr);
   p.per_split = ceil_div(p.ntr, splits);
-  int rc = wino4_launch_wgrad(p, splits, dW, st);
+  static int waves = 0;
+  if (!waves) {                            // LSPS_WINO4W_WAVES=4|8: workgroup shape of the kernel (A/B comparisons)
+    const char *e = getenv("LSPS_WINO4W_WAVES");
+    waves = (e && e[0] == '8') ? 8 : ((e && e[0] == '4') ? 4 : W4W_DEFAULT_WAVES);
+  }
+  int rc = wino4_launch_wgrad(p, splits, dW, waves, st);
   if (rc) return rc;
   note_kernel("wino4_w3x3_kernel");
   return 0;

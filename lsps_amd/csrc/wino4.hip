@@ -29,18 +29,23 @@ int wino4_launch(const Wino4Params &p, hipStream_t st) {
   return 0;
 }
 
-int wino4_launch_wgrad(const Wino4WParams &p, int splits, float *dW, hipStream_t st) {
+int wino4_launch_wgrad(const Wino4WParams &p, int splits, float *dW, int waves, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {                        // 127 KB of LDS: dynamic + opt-in
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_w3x3_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4W_LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(wino4_w3x3): %s", hipGetErrorString(e));
-      return LSPS_E_HIP;
+    for (const void *f : {reinterpret_cast<const void *>(wino4_w3x3_kernel<2>), reinterpret_cast<const void *>(wino4_w3x3_kernel<1>)}) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4W_LDS_BYTES);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(wino4_w3x3): %s", hipGetErrorString(e));
+        return LSPS_E_HIP;
+      }
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(wino4_w3x3_kernel, dim3(p.C / 32, p.M / 64, splits), dim3(256), W4W_LDS_BYTES, st, p);
+  const dim3 grid(p.C / 32, p.M / 64, splits);
+  if (waves == 8)
+    hipLaunchKernelGGL(wino4_w3x3_kernel<1>, grid, dim3(512), W4W_LDS_BYTES, st, p);
+  else
+    hipLaunchKernelGGL(wino4_w3x3_kernel<2>, grid, dim3(256), W4W_LDS_BYTES, st, p);
   LSPS_CHECK_LAUNCH("wino4_w3x3");
   hipLaunchKernelGGL(wino4_w3x3_reduce_kernel, dim3(ceil_div((long)p.M * p.C, 256)), dim3(256), 0, st,
                      (const float *)p.part, dW, p.M * p.C, splits);

@@ -21,10 +21,11 @@ def _c(t):
 
 class _Span(object):
     """Brackets ONE C-ABI conv call.  The key is the kernel name the library reports for that call (lsps_last_kernel):
-    nothing here mirrors the dispatch rules."""
+    nothing here mirrors the dispatch rules.  `name`: entries with a single kernel that does not go through that
+    dispatcher (csrc/chwn.hip)."""
 
-    def __init__(self, prof, flops):
-        self.prof, self.flops = prof, flops
+    def __init__(self, prof, flops, name=None):
+        self.prof, self.flops, self.name = prof, flops, name
 
     def __enter__(self):
         p = self.prof
@@ -41,6 +42,8 @@ class _Span(object):
             return
         n = _ctypes.c_int(0)
         name = _lib.lib().lsps_last_kernel(_ctypes.byref(n)).decode()
+        if self.name is not None:
+            name, n = self.name, _ctypes.c_int(1)
         if p.log is not None:
             p.log.append(name)
         if p.enabled:
@@ -60,8 +63,8 @@ class Profiler(object):
     def reset(self):
         self.records = []
 
-    def span(self, flops):
-        return _Span(self, flops)
+    def span(self, flops, name=None):
+        return _Span(self, flops, name)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -278,6 +281,103 @@ def conv_transpose2d(x, w, b=None, stride=1, pad=0, outpad=0, act=ACT_NONE, slop
         return _empty(x, (0, w.shape[1], convT_out_size(x.shape[2], w.shape[2], stride, pad, outpad),
                           convT_out_size(x.shape[3], w.shape[3], stride, pad, outpad)), w, b)
     return _ConvT2dFn.apply(x, w, b, int(stride), int(pad), int(outpad), int(act), float(slope))
+
+
+# ------------------------------------------------------------------------------------------
+# 3x3 / stride-2 convs on small maps in batch-innermost layout [C][H][W][N] (the discriminator trunk; csrc/chwn.hip)
+# ------------------------------------------------------------------------------------------
+class _Transpose2dFn(torch.autograd.Function):
+    """[R][S] -> [S][R] of a contiguous tensor viewed as a matrix (NCHW <-> CHWN); backward = the inverse transpose."""
+
+    @staticmethod
+    def forward(ctx, x, R, S, out_shape):
+        x = _c(x)
+        y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().lsps_transpose2d(_lib.ptr(x), _lib.ptr(y), R, S, _lib.stream()), 'transpose2d')
+        ctx.dims = (R, S, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        R, S, in_shape = ctx.dims
+        g = _c(g)
+        dx = torch.empty(in_shape, dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().lsps_transpose2d(_lib.ptr(g), _lib.ptr(dx), S, R, _lib.stream()), 'transpose2d')
+        return dx, None, None, None
+
+
+def nchw_to_chwn(x):
+    N, C, H, W = x.shape
+    return _Transpose2dFn.apply(x, N, C * H * W, (C, H, W, N))
+
+
+def chwn_to_nchw(x):
+    C, H, W, N = x.shape
+    return _Transpose2dFn.apply(x, C * H * W, N, (N, C, H, W))
+
+
+def conv3x3s2_chwn_ok(N, C, H, W, K):
+    return _lib.lib().lsps_conv3x3s2_chwn_workspace_bytes(N, C, H, W, K) > 0 and get_math_mode() == 'f32'
+
+
+class _ConvS2CHWNFn(torch.autograd.Function):
+    """LeakyReLUConv2d(C, K, 3, 2, 1) (common_net.py:250-252) on x [C][H][W][N] -> [K][H/2][W/2][N]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope):
+        L = _lib.lib()
+        x, w = _c(x), _c(w)
+        C, H, W, N = x.shape
+        K = w.shape[0]
+        assert tuple(w.shape) == (K, C, 3, 3), "conv3x3s2_chwn: weight must be (K, C, 3, 3)"
+        y = torch.empty((K, H // 2, W // 2, N), dtype=torch.float32, device=x.device)
+        ws, wsb = _lib.workspace(L.lsps_conv3x3s2_chwn_workspace_bytes(N, C, H, W, K), x.device)
+        with profiler.span(2.0 * N * K * (H // 2) * (W // 2) * C * 9, 'chwn_gemm_kernel'):
+            _lib.check(L.lsps_conv3x3s2_chwn_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, C, H, W, K, act, slope,
+                                                 ws, wsb, _lib.stream()), 'conv3x3s2_chwn_fwd')
+        ctx.geom = (N, C, H, W, K, act, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w, y = ctx.saved_tensors
+        N, C, H, W, K, act, slope = ctx.geom
+        dy = _c(dy)
+        st = _lib.stream()
+        P, Q = H // 2, W // 2
+        flops = 2.0 * N * K * P * Q * C * 9
+        ws, wsb = _lib.workspace(max(L.lsps_conv3x3s2_chwn_workspace_bytes(N, C, H, W, K), 1 << 20), x.device)
+        dx = dw = db = None
+        # the layout makes the layer look like one image with P*Q*N pixels per channel to the activation-backward kernels
+        if act != ACT_NONE:
+            dpre = torch.empty_like(dy)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = torch.empty(K, dtype=torch.float32, device=dy.device)
+                _lib.check(L.lsps_act_bwd_bias(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dpre), _lib.ptr(db), 1, K, P * Q * N, act, slope,
+                                               ws, wsb, st), 'act_bwd_bias')
+            else:
+                _lib.check(L.lsps_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dpre), dy.numel(), act, slope, st), 'act_bwd')
+            dy = dpre
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.reshape(K, -1).sum(1)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            with profiler.span(flops, 'chwn_gemm_kernel'):
+                _lib.check(L.lsps_conv3x3s2_chwn_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, C, H, W, K, ws, wsb, st),
+                           'conv3x3s2_chwn_dgrad')
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            with profiler.span(flops, 'chwn_wgrad_kernel'):
+                _lib.check(L.lsps_conv3x3s2_chwn_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), N, C, H, W, K, ws, wsb, st),
+                           'conv3x3s2_chwn_wgrad')
+        return dx, dw, db, None, None
+
+
+def conv3x3s2_chwn(x, w, b=None, act=ACT_NONE, slope=LRELU_SLOPE):
+    return _ConvS2CHWNFn.apply(x, w, b, int(act), float(slope))
 
 
 # ------------------------------------------------------------------------------------------

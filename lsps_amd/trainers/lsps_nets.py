@@ -135,8 +135,33 @@ class SharedDis(_Net):
         discrim = Conv2d(tch, 1, kernel_size=1, stride=1, padding=0)
         return nn.Sequential(*layers), discrim, post
 
+    def _trunk(self, f):
+        """model_S on `f` [N][C][H][W].  The trunk is a chain of 3x3 / stride-2 LeakyReLUConv2d on 16x16 ... 2x2 maps: where
+        the geometry allows (N % 4 == 0, channels % 128 == 0, even maps, f32 math) it runs in batch-innermost layout on
+        the plain-GEMM kernels of csrc/chwn.hip (one transpose in, one out); otherwise layer by layer in NCHW."""
+        import os
+        layers = list(self.model_S)
+        N, C, H, W = f.shape
+        # below ~96 samples the 128-wide batch tile of the GEMM is mostly padding (dis.feats on 16 samples: slower than NCHW)
+        ok = len(layers) > 0 and N >= int(os.environ.get('LSPS_CHWN_MIN_N', '96')) and os.environ.get('LSPS_CHWN', '1') != '0'
+        c, h, w = C, H, W
+        for l in layers:
+            conv = l.model[0] if isinstance(l, LeakyReLUConv2d) else None
+            ok = ok and conv is not None and tuple(conv.weight.shape[1:]) == (c, 3, 3) and conv.stride == 2 and \
+                conv.padding == 1 and ops.conv3x3s2_chwn_ok(N, c, h, w, conv.weight.shape[0])
+            if not ok:
+                break
+            c, h, w = conv.weight.shape[0], h // 2, w // 2
+        if not ok:
+            return self.model_S(f)
+        t = ops.nchw_to_chwn(f)
+        for l in layers:
+            conv = l.model[0]
+            t = ops.conv3x3s2_chwn(t, conv.weight, conv.bias, ops.ACT_LRELU, ops.LRELU_SLOPE)
+        return ops.chwn_to_nchw(t)
+
     def _regress(self, front, x):
-        post = self.Post(self.model_S(front(x))).squeeze()
+        post = self.Post(self._trunk(front(x))).squeeze()
         return post, post, post
 
     def regress_a(self, x_A):
@@ -147,11 +172,11 @@ class SharedDis(_Net):
 
     def feats(self, x_aa, x_ba, x_ab, x_bb):
         f = torch.cat((self.model_A(torch.cat((x_aa, x_ba), 0)), self.model_B(torch.cat((x_ab, x_bb), 0))), 0)
-        f = self.model_S(f)
+        f = self._trunk(f)
         return torch.split(f, f.size(0) // 4, dim=0)
 
     def forward(self, x_A, x_B, second_feats=False):
-        f = self.model_S(torch.cat((self.model_A(x_A), self.model_B(x_B)), 0))
+        f = self._trunk(torch.cat((self.model_A(x_A), self.model_B(x_B)), 0))
         out_D = self.D(f)
         feats_A, feats_B = torch.split(f, f.size(0) // 2, dim=0)
         out_D_A, out_D_B = torch.split(out_D, out_D.size(0) // 2, dim=0)

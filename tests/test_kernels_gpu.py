@@ -768,3 +768,58 @@ def test_conv3x3_instance_norm_fused(case, form):
             assert _rel(dpre, c0g.grad) < 1e-4, _rel(dpre, c0g.grad)
     finally:
         ops.set_winograd(prev)
+
+
+# (N, C, H, W, K): 3x3 / stride 2 / pad 1 convs in batch-innermost layout (csrc/chwn.hip): the four discriminator-trunk
+# geometries, small batches (reduction splits), a batch that is not a multiple of the 128-wide tile, non-square maps
+CHWN_CASES = [
+    (8, 128, 32, 32, 256),      # dis_s0 geometry: 16x16 outputs, wgrad over 256 positions split 29 ways
+    (12, 256, 16, 16, 512),     # dis_s1
+    (20, 512, 8, 8, 1024),      # dis_s2: forward / dgrad reduction splits
+    (36, 1024, 4, 4, 2048),     # dis_s3: 2x2 outputs, 25 of 36 taps real
+    (132, 128, 4, 6, 128),      # two n tiles (128 + 4), non-square map
+    (4, 128, 2, 2, 128),        # one output position, 4 of 9 taps real
+]
+
+
+@pytest.mark.parametrize("case", CHWN_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv3x3s2_chwn(case):
+    """lsps_conv3x3s2_chwn_{fwd,dgrad,wgrad} + lsps_transpose2d against an f64 torch convolution (bias + LeakyReLU in the
+    forward epilogue, LeakyReLU backward + bias gradient through lsps_act_bwd_bias on the [C][H][W][N] tensor)."""
+    _need_gpu()
+    from lsps_amd import ops
+    N, C, H, W, K = case
+    assert ops.conv3x3s2_chwn_ok(N, C, H, W, K)
+    x = _rand(N, C, H, W, seed=51).double().requires_grad_(True)
+    w = _rand(K, C, 3, 3, seed=52, scale=0.05).double().requires_grad_(True)
+    b = _rand(K, seed=53, scale=0.1).double().requires_grad_(True)
+    y_ref = F.leaky_relu(F.conv2d(x, w, b, stride=2, padding=1), 0.01)
+    gy = _rand(*y_ref.shape, seed=54)
+    y_ref.backward(gy.double())
+    xd, wd, bd = (t.detach().float().cuda().requires_grad_(True) for t in (x, w, b))
+    t = ops.nchw_to_chwn(xd)
+    assert tuple(t.shape) == (C, H, W, N)
+    assert torch.equal(t.detach().cpu(), xd.detach().cpu().permute(1, 2, 3, 0).contiguous())
+    yc = ops.conv3x3s2_chwn(t, wd, bd, ops.ACT_LRELU, 0.01)
+    y = ops.chwn_to_nchw(yc)
+    assert _rel(y, y_ref) < 2e-5, _rel(y, y_ref)
+    y.backward(gy.cuda())
+    errs = dict(dx=_rel(xd.grad, x.grad), dw=_rel(wd.grad, w.grad), db=_rel(bd.grad, b.grad))
+    assert errs['dx'] < LRELU_BWD_TOL and errs['dw'] < 1e-4 and errs['db'] < 1e-4, errs
+
+
+def test_conv3x3s2_chwn_rejects_unsupported_geometry():
+    _need_gpu()
+    from lsps_amd import _lib, ops
+    L = _lib.lib()
+    assert not ops.conv3x3s2_chwn_ok(6, 128, 8, 8, 256)        # N % 4 != 0
+    assert not ops.conv3x3s2_chwn_ok(8, 64, 8, 8, 256)         # C % 128 != 0
+    assert not ops.conv3x3s2_chwn_ok(8, 128, 7, 8, 256)        # odd map
+    x = torch.zeros(128, 8, 8, 6, device='cuda')
+    w = torch.zeros(256, 128, 3, 3, device='cuda')
+    y = torch.zeros(256, 4, 4, 6, device='cuda')
+    ws, wsb = _lib.workspace(1 << 20, x.device)
+    assert L.lsps_conv3x3s2_chwn_fwd(_lib.ptr(x), _lib.ptr(w), None, _lib.ptr(y), 6, 128, 8, 8, 256, 0, 0.0, ws, wsb,
+                                     _lib.stream()) != 0
+    assert b'geometry' in L.lsps_last_error()
+

@@ -16,6 +16,8 @@ LAYERS = [
     ('down2', (128, 64, 64, 256, 3, 2, 1)),
     ('stem7x7', (1, 128, 128, 64, 7, 1, 3)),
     ('dis_s0', (128, 32, 32, 256, 3, 2, 1)),
+    ('dis_s1', (256, 16, 16, 512, 3, 2, 1)),
+    ('dis_s2', (512, 8, 8, 1024, 3, 2, 1)),
     ('dis_s3', (1024, 4, 4, 2048, 3, 2, 1)),
     ('disstem', (1, 128, 128, 64, 7, 2, 3)),
     ('dis_f1', (64, 64, 64, 128, 3, 2, 1)),
