@@ -128,26 +128,39 @@ __global__ __launch_bounds__(256, 4) void chwn_gemm_kernel(CGParams p) {
   const int total = ntap * RC;
   const int it0 = (int)((long)total * sp / p.splits), it1 = (int)((long)total * (sp + 1) / p.splits);
 
-  // staging: per operand CG_BK rows x 32 float4 = CG_BK / 8 per thread (rows tid/32 + 8 i)
+  // staging: per operand CG_BK rows x 32 float4 = CG_BK / 8 per thread (rows tid/32 + 8 i).  Everything that changes from
+  // one chunk to the next is uniform: a (tap, chunk) cursor with byte pointers advanced incrementally (no division, no 64-bit
+  // lane arithmetic in the loop: those instructions cost their full issue time beside an f32 MFMA); the lanes keep ONE 32-bit
+  // offset per operand and load through buffer descriptors.  Batch columns >= N of the last n tile are never stored, so
+  // their loads are only redirected to a valid column, not zeroed.
   const int srow = tid >> 5, scol = (tid & 31) * 4;
-  const bool bn_ok = n0 + scol < p.N;                  // N % 4 == 0: a float4 is inside or outside
   const long ldb = (long)p.Hb * p.Wb * p.N;
-  f32x4 ra[CG_BK / 8], rb[CG_BK / 8];
-  auto load_tiles = [&](int it) {
-    const int ti = it / RC, c0 = (it - ti * RC) * CG_BK;
+  const unsigned a_vo = (unsigned)(srow * p.Md + scol) * 4u;
+  const unsigned b_vo = (unsigned)((long)srow * ldb + min(n0 + scol, p.N - 4)) * 4u;
+  const int a_row8 = 8 * p.Md * 4, b_row8 = (int)(8 * ldb * 4);           // rows + 8: uniform byte offsets
+  const long a_step = (long)CG_BK * p.Md * 4, b_step = (long)CG_BK * ldb * 4;
+  int cur_ti = 0, cur_ch = 0;
+  const char *a_ptr = nullptr, *b_ptr = nullptr;
+  auto seek = [&](int ti, int ch) {                    // byte pointers of chunk `ch` of the ti-th valid tap
     const int t = (int)((taps >> (4 * ti)) & 15), r = t / 3, s = t - 3 * r;
-    int pb;
-    if (p.mode == 0)
-      pb = (2 * oh + r - 1) * p.Wb + 2 * ow + s - 1;
-    else
-      pb = ((oh + 1 - r) >> 1) * p.Wb + ((ow + 1 - s) >> 1);
-    const float *a = p.A + ((long)t * p.Rd + c0) * p.Md + m0 + scol;
-    const float *b = p.B + (long)c0 * ldb + (long)pb * p.N + n0 + scol;
+    const int pb = p.mode == 0 ? (2 * oh + r - 1) * p.Wb + 2 * ow + s - 1 : ((oh + 1 - r) >> 1) * p.Wb + ((ow + 1 - s) >> 1);
+    a_ptr = reinterpret_cast<const char *>(p.A + ((long)t * p.Rd * p.Md + m0)) + ch * a_step;
+    b_ptr = reinterpret_cast<const char *>(p.B + (long)pb * p.N) + ch * b_step;
+    cur_ti = ti;
+    cur_ch = ch;
+  };
+  f32x4 ra[CG_BK / 8], rb[CG_BK / 8];
+  auto load_tiles = [&]() {                            // the chunk under the cursor, then advance the cursor
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a_ptr), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b_ptr), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int i = 0; i < CG_BK / 8; ++i) {
-      ra[i] = *reinterpret_cast<const f32x4 *>(a + (long)(srow + 8 * i) * p.Md);
-      rb[i] = bn_ok ? *reinterpret_cast<const f32x4 *>(b + (long)(srow + 8 * i) * ldb) : f32x4{0.f, 0.f, 0.f, 0.f};
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, a_vo, i * a_row8, 0));
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, b_vo, i * b_row8, 0));
     }
+    a_ptr += a_step;
+    b_ptr += b_step;
+    if (++cur_ch == RC && cur_ti + 1 < ntap) seek(cur_ti + 1, 0);
   };
   auto store_tiles = [&](int buf) {
 #pragma unroll
@@ -166,12 +179,13 @@ __global__ __launch_bounds__(256, 4) void chwn_gemm_kernel(CGParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (it0 < it1) {
-    load_tiles(it0);
+    seek(it0 / RC, it0 % RC);
+    load_tiles();
     store_tiles(0);
     __syncthreads();
     int buf = 0;
     for (int it = it0; it < it1; ++it) {
-      if (it + 1 < it1) load_tiles(it + 1);
+      if (it + 1 < it1) load_tiles();
       // operands of k-pair kk + 1 are read BEFORE the MFMAs of kk are issued (order pinned: left alone, the compiler reads,
       // waits out the LDS latency and only then issues the four MFMAs of every pair)
       const float *as = &As[buf][half][wm * 64 + l31], *bs = &Bs[buf][half][wn * 64 + l31];
@@ -264,23 +278,45 @@ __global__ __launch_bounds__(256, 4) void chwn_wgrad_kernel(CWParams p) {
   const int total = np * nq * NC;
   const int it0 = (int)((long)total * sp / p.splits), it1 = (int)((long)total * (sp + 1) / p.splits);
 
-  // staging: per operand 128 rows x CW_BK floats: thread -> row tid/2, CW_BK / 2 floats at (tid & 1) * CW_BK / 2
+  // staging: per operand 128 rows x CW_BK floats: thread -> row tid/2, CW_BK / 2 floats at (tid & 1) * CW_BK / 2.  As in
+  // chwn_gemm_kernel everything that changes per chunk is a uniform cursor (position, n chunk) with incrementally advanced
+  // byte pointers; a lane keeps one 32-bit offset per operand.  Here the batch IS the reduction: columns >= N must
+  // contribute zeros (only when N is not a multiple of the chunk: a uniform flag).
   const int srow = tid >> 1, scol = (tid & 1) * (CW_BK / 2);
   const long lda = (long)p.P * p.Q * p.N, ldb = (long)p.H * p.W * p.N;
-  const bool a_ok = k0 + srow < p.K, b_ok = c0 + srow < p.C;
-  f32x4 ra[CW_BK / 8], rb[CW_BK / 8];
-  auto load_tiles = [&](int it) {
-    const int pi = it / NC, nc = it - pi * NC;
+  const unsigned a_vo = (unsigned)((long)(k0 + srow) * lda + scol) * 4u, b_vo = (unsigned)((long)(c0 + srow) * ldb + scol) * 4u;
+  const bool tail = (p.N % CW_BK) != 0;
+  int cur_pi = 0, cur_nc = 0;
+  const char *a_ptr = nullptr, *b_ptr = nullptr;
+  auto seek = [&](int pi, int nc) {
     const int pp = pl + pi / nq, qq = ql + pi % nq;
-    const int n = nc * CW_BK + scol;
-    const float *a = p.DY + (long)(k0 + srow) * lda + (long)(pp * p.Q + qq) * p.N + n;
-    const float *b = p.X + (long)(c0 + srow) * ldb + (long)((2 * pp + r - 1) * p.W + 2 * qq + s - 1) * p.N + n;
+    a_ptr = reinterpret_cast<const char *>(p.DY + (long)(pp * p.Q + qq) * p.N + nc * CW_BK);
+    b_ptr = reinterpret_cast<const char *>(p.X + (long)((2 * pp + r - 1) * p.W + 2 * qq + s - 1) * p.N + nc * CW_BK);
+    cur_pi = pi;
+    cur_nc = nc;
+  };
+  f32x4 ra[CW_BK / 8], rb[CW_BK / 8];
+  auto load_tiles = [&]() {
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a_ptr), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b_ptr), 0, 0x7fffffff, 0x00020000);
+    if (tail && cur_nc == NC - 1) {                    // last n chunk of a ragged batch: in-range float4s only
+      const int n = cur_nc * CW_BK + scol;
 #pragma unroll
-    for (int i = 0; i < CW_BK / 8; ++i) {
-      const bool in = n + 4 * i < p.N;
-      ra[i] = (a_ok && in) ? *reinterpret_cast<const f32x4 *>(a + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-      rb[i] = (b_ok && in) ? *reinterpret_cast<const f32x4 *>(b + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < CW_BK / 8; ++i) {
+        const bool in = n + 4 * i < p.N;
+        ra[i] = in ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, a_vo + 16 * i, 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        rb[i] = in ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, b_vo + 16 * i, 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CW_BK / 8; ++i) {
+        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, a_vo + 16 * i, 0, 0));
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, b_vo + 16 * i, 0, 0));
+      }
     }
+    a_ptr += CW_BK * 4;
+    b_ptr += CW_BK * 4;
+    if (++cur_nc == NC && cur_pi + 1 < np * nq) seek(cur_pi + 1, 0);
   };
   auto store_tiles = [&](int buf) {
     float *a = &As[buf][srow * CW_LD + scol], *b = &Bs[buf][srow * CW_LD + scol];
@@ -302,12 +338,13 @@ __global__ __launch_bounds__(256, 4) void chwn_wgrad_kernel(CWParams p) {
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
   if (it0 < it1) {
-    load_tiles(it0);
+    seek(it0 / NC, it0 % NC);
+    load_tiles();
     store_tiles(0);
     __syncthreads();
     int buf = 0;
     for (int it = it0; it < it1; ++it) {
-      if (it + 1 < it1) load_tiles(it + 1);
+      if (it + 1 < it1) load_tiles();
       const float *as = &As[buf][(wm * 64 + l31) * CW_LD + half], *bs = &Bs[buf][(wn * 64 + l31) * CW_LD + half];
       float a0 = as[0], a1 = as[32 * CW_LD], b0 = bs[0], b1 = bs[32 * CW_LD];
 #pragma unroll
@@ -375,7 +412,7 @@ static int chwn_device_cus() {
 
 static bool chwn_geom_ok(int N, int C, int H, int W, int K) {
   return N > 0 && (N % 4) == 0 && C > 0 && (C % 128) == 0 && K > 0 && (K % 128) == 0 && H >= 2 && W >= 2 && (H % 2) == 0 &&
-         (W % 2) == 0 && (long)C * H * W * N < (1L << 40);
+         (W % 2) == 0 && (long)128 * H * W * N * 4 < (1L << 32);     // 32-bit byte offsets of a lane inside a 128-row tile
 }
 
 // reduction splits of the forward / dgrad GEMM: fill the chip twice over when the batch alone does not
