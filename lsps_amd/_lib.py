@@ -124,13 +124,15 @@ _workspaces = {}
 
 
 def workspace(nbytes, device):
-    """One scratch buffer per device, grown on demand; ops on one stream run in order, so it is shared."""
+    """One scratch buffer per (device, stream), grown on demand: ops on one stream run in order, so they share it; a second
+    stream (the trainer overlaps independent branches of a step) gets its own."""
     import torch
-    key = (device.type, device.index)
+    cur = torch.cuda.current_stream(device)
+    key = (device.type, device.index, cur.cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
-            torch.cuda.current_stream().synchronize()   # outstanding users of the old buffer
+            cur.synchronize()                           # outstanding users of the old buffer
         nbytes = max(int(nbytes * 1.25), 1 << 20)
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _workspaces[key] = buf

@@ -118,6 +118,7 @@ struct PackKey {
 struct PackEntry {
   PackKey key;
   void *cls;
+  hipStream_t st;                // the stream the pack kernel was enqueued on: a hit is only valid for work on THAT stream
 };
 static char *g_pc_arena = nullptr;
 static size_t g_pc_bytes = 0, g_pc_used = 0;
@@ -131,11 +132,12 @@ static bool pack_key_eq(const PackKey &a, const PackKey &b) {
 
 // scope lookup: the cached panel for key k (*hit = true), a fresh arena slot of `need` bytes that the caller fills and
 // that is remembered under k (*hit = false), or nullptr (no scope open / arena full: use the call's workspace)
-static void *pack_cache_find(const PackKey &k, size_t need, bool *hit) {
+// (another stream of the same scope — the trainer overlaps independent branches of a step — packs its own copy)
+static void *pack_cache_find(const PackKey &k, size_t need, bool *hit, hipStream_t st) {
   *hit = false;
   if (!g_pc_arena) return nullptr;
   for (int i = 0; i < g_pc_n; ++i)
-    if (pack_key_eq(g_pc_tab[i].key, k)) {
+    if (g_pc_tab[i].st == st && pack_key_eq(g_pc_tab[i].key, k)) {
       *hit = true;
       return g_pc_tab[i].cls;
     }
@@ -144,6 +146,7 @@ static void *pack_cache_find(const PackKey &k, size_t need, bool *hit) {
   g_pc_used += align_up(need, 256);
   g_pc_tab[g_pc_n].key = k;
   g_pc_tab[g_pc_n].cls = cls;
+  g_pc_tab[g_pc_n].st = st;
   ++g_pc_n;
   return cls;
 }
@@ -155,7 +158,7 @@ static int launch_pack(const float *W, void *cls, int M, int Mp, int RED, int RE
     PackKey k = {W, M, Mp, RED, REDp, l.T, HxWx, Wx, cc, sm, sc, 2166136261u};
     for (int i = 0; i < l.T; ++i) k.taphash = (k.taphash ^ (unsigned)(l.idx[i] * 961 + (l.dh[i] + 8) * 31 + (l.dw[i] + 8))) * 16777619u;
     bool hit;
-    void *slot = pack_cache_find(k, class_bytes(REDp, Mp), &hit);
+    void *slot = pack_cache_find(k, class_bytes(REDp, Mp), &hit, st);
     if (hit) {
       char *c = (char *)slot;
       *gtab_out = (const int2 *)c;
@@ -297,7 +300,7 @@ static int run_wino4(const float *in, const float *W, const float *bias, float *
   PackKey k = {W, M, M, Cin * 36, Cin * 36, 9, 32 * 32, 32, /*cc: marks the F(4x4,3x3) layout*/ 1 << 21, sm, sc, 2166136261u};
   for (int i = 0; i < 9; ++i) k.taphash = (k.taphash ^ (unsigned)(l.idx[i] * 961 + i)) * 16777619u;
   bool hit;
-  void *slot = pack_cache_find(k, need, &hit);
+  void *slot = pack_cache_find(k, need, &hit, st);
   if (!slot) {
     if (need > ws_bytes) {
       set_error("conv workspace too small: need %zu, have %zu", need, ws_bytes);
@@ -356,7 +359,7 @@ static int run_wino(const float *in, const float *W, const float *bias, float *o
   PackKey k = {W, M, M, Cin * 16, Cin * 16, 9, H * 32, 32, /*cc: marks the Winograd layout*/ 1 << 20, sm, sc, 2166136261u};
   for (int i = 0; i < 9; ++i) k.taphash = (k.taphash ^ (unsigned)(l.idx[i] * 961 + i)) * 16777619u;
   bool hit;
-  void *slot = pack_cache_find(k, need, &hit);
+  void *slot = pack_cache_find(k, need, &hit, st);
   if (!slot) {
     if (need > ws_bytes) {
       set_error("conv workspace too small: need %zu, have %zu", need, ws_bytes);

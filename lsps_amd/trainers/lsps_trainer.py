@@ -144,6 +144,7 @@ class LSPSTrainer(nn.Module):
         self._graph_seen = set()
         self._graph_pool = None
         self._capturing = None
+        self._side = None
 
     # ------------------------------------------------------------------ device / arenas
     def cuda(self, gpu=None):
@@ -173,6 +174,19 @@ class LSPSTrainer(nn.Module):
             return
         for opt in (self.dis_opt, self.gen_opt, self.vae_opt):
             opt.sync_from_rank0()
+
+    def _side_stream(self, device):
+        """Second HIP stream for the independent branch of the estimate modes (LSPS_NO_OVERLAP=1 or data parallelism: none)."""
+        if os.environ.get('LSPS_NO_OVERLAP') == '1' or lsps_dist.active():
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=device)
+            # the discriminator's AccumulateGrad nodes live on the main stream while part of their gradients now arrive from
+            # the side stream: intended (the engine synchronises them), so the advisory warning is switched off
+            fn = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+            if fn is not None:
+                fn(False)
+        return self._side
 
     def use_graphs(self, on=True):
         """hipGraph replay of dis_update / gen_update / post_update (single process only; under torch.distributed the
@@ -374,14 +388,25 @@ class LSPSTrainer(nn.Module):
                 first_a, first_b = first_a.clone(), first_b.clone()
                 torch.distributed.broadcast(first_a, 0)
                 torch.distributed.broadcast(first_b, 0)
-            with torch.no_grad():
-                x_aa, x_ba, x_ab, x_bb, _ = self.gen(first_a, first_b, noise=noise.get('gen'))
-            f_x_aa, f_x_ba, f_x_ab, f_x_bb = self.dis.feats(x_aa, x_ba, x_ab, x_bb)
-            terms_feat.append(self._compute_ll_loss(f_x_ab, f_x_aa))
-            terms_feat.append(self._compute_ll_loss(f_x_ba, f_x_bb))
+            # The feature branch (generator on 8 samples -> dis.feats on 16) and the regression branch (dis on the whole
+            # batch) are independent until the loss is summed, and the first one's launches fill a quarter of the chip at
+            # best: it runs on a second HIP stream (forward here, its backward follows it there: autograd replays a node on
+            # the stream of its forward).  Same kernels, same arithmetic; per-stream workspaces and pack-cache entries.
+            side = self._side_stream(images_a.device)
+            main = torch.cuda.current_stream(images_a.device)
+            if side is not None:
+                side.wait_stream(main)
+            with torch.cuda.stream(side if side is not None else main):
+                with torch.no_grad():
+                    x_aa, x_ba, x_ab, x_bb, _ = self.gen(first_a, first_b, noise=noise.get('gen'))
+                f_x_aa, f_x_ba, f_x_ab, f_x_bb = self.dis.feats(x_aa, x_ba, x_ab, x_bb)
+                terms_feat.append(self._compute_ll_loss(f_x_ab, f_x_aa))
+                terms_feat.append(self._compute_ll_loss(f_x_ba, f_x_bb))
             terms_reg.append(regression(self.dis.regress_a, images_a, labels_a, noise.get('vae_a')))
             if mode == 4:
                 terms_reg.append(regression(self.dis.regress_b, images_b, labels_b, noise.get('vae_b')))
+            if side is not None:
+                main.wait_stream(side)
         reg_loss = sum(terms_reg[1:], terms_reg[0])
         total_loss = hp['reg_w'] * reg_loss
         if terms_feat:

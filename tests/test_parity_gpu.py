@@ -190,6 +190,38 @@ def test_hip_graph_replay_matches_eager_bitwise():
             assert np.array_equal(outs[0][net][k], outs[1][net][k]), k
 
 
+@pytest.mark.parametrize("mode", [3, 4])
+def test_post_update_overlapped_branches_match_serial_bitwise(mode, monkeypatch):
+    """Estimate modes: the feature branch (generator on the first 4 samples + dis.feats) runs on a second HIP stream beside
+    the regression branch.  Two steps with the overlap, without it (LSPS_NO_OVERLAP=1) and with the overlap inside a
+    hipGraph give bit-identical losses and discriminator weights."""
+    A = _adapter()
+    hp = cases.hp_for('tiny')
+    sds = cases.make_weights(hp, lsps_ref)
+    b = cases.make_inputs(8)
+    lat, zd = cases.latent_shape(hp, 8), hp['vae']['z_dim']
+    outs = []
+    for variant in ('overlap', 'serial', 'graph'):
+        if variant == 'serial':
+            monkeypatch.setenv('LSPS_NO_OVERLAP', '1')
+        else:
+            monkeypatch.delenv('LSPS_NO_OVERLAP', raising=False)
+        tr = A.make_trainer(hp, sds)
+        tr.use_graphs(variant == 'graph')
+        A.set_train(tr, True)
+        trace = []
+        for rnd in range(3):
+            A.post_update(tr, b, mode, hp, cases.noise(lat, 80 + rnd), cases.noise((8, zd), 81 + rnd, 0.05),
+                          cases.noise((8, zd), 82 + rnd, 0.05))
+            trace.append(A.scalars(tr))
+        assert (tr._side is not None) == (variant != 'serial')
+        outs.append((trace, A.params(tr, 'dis')))
+    for o in outs[1:]:
+        assert o[0] == outs[0][0], (o[0], outs[0][0])
+        for k in outs[0][1]:
+            assert np.array_equal(o[1][k], outs[0][1][k]), k
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 5])
 def test_ragged_batches_against_oracle(n):
     """Edge cases the reference's code paths have: batch smaller than the [0:4] slice of post_update
