@@ -27,13 +27,17 @@ struct FS2Params {
   float slope;
 };
 
-template <bool BF16>
-__global__ __launch_bounds__(256, 2) void igemm_f3x3s2_kernel(FS2Params p) {
-  constexpr int BM = 128, RC = F3_CC * 9;
-  constexpr int A4 = RC * BM / 4 / 256;                            // 9 float4 of weights per thread per chunk
-  constexpr int LINES = F3_CC * FS2_ROWS;                          // 72 (channel, row) lines of 64 columns
+// CC = input channels per chunk.  8 (the bf16 mode needs it: K = 16 = 2 taps x 8 channels): 55.6 KB of LDS and ~210 registers = two
+// workgroups per CU.  4: 27.8 KB and half the prefetch registers = three to four per CU, 72 instead of 144 MFMAs per wave
+// between the barrier pairs (measured in DESIGN.md 3.9).
+template <bool BF16, int CC>
+__global__ __launch_bounds__(256, CC == 8 ? 2 : 3) void igemm_f3x3s2_kernel(FS2Params p) {
+  constexpr int BM = 128, RC = CC * 9;
+  constexpr int A4 = (RC * BM / 4 + 255) / 256;                    // float4 of weights per thread per chunk (9, or 4.5 -> 5)
+  constexpr bool A_RAGGED = (RC * BM / 4) % 256 != 0;
+  constexpr int LINES = CC * FS2_ROWS;                          // 72 (channel, row) lines of 64 columns
   constexpr int B4 = (LINES * 16 + 255) / 256;                     // 5 float4 of input per thread per chunk (4.5)
-  __shared__ __attribute__((aligned(16))) float lds[RC * BM + F3_CC * FS2_CH];
+  __shared__ __attribute__((aligned(16))) float lds[RC * BM + CC * FS2_CH];
   float *As = lds, *Bs = lds + RC * BM;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3s2_kernel(FS2Params p) {
 
   f32x4 areg[A4], breg[B4];
   float hreg = 0.f;
-  const int nchunks = p.Cx / F3_CC;
+  const int nchunks = p.Cx / CC;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
   const float *Ap = As + half * BM + wm * 64 + l31;
@@ -83,7 +87,8 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3s2_kernel(FS2Params p) {
     if (ch >= 0) {
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4 *>(As + (tid + 256 * i) * 4) = areg[i];
+      for (int i = 0; i < A4; ++i)
+        if (!A_RAGGED || tid + 256 * i < RC * BM / 4) *reinterpret_cast<f32x4 *>(As + (tid + 256 * i) * 4) = areg[i];
 #pragma unroll
       for (int i = 0; i < B4; ++i)
         if (b_use[i]) {
@@ -102,9 +107,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3s2_kernel(FS2Params p) {
       for (int i = 0; i < A4; ++i) {
         const int u = tid + 256 * i;
         const int row = u >> 5, c4 = u & 31;
-        areg[i] = *reinterpret_cast<const f32x4 *>(wsrc + (long)row * p.Mp + c4 * 4);
+        if (!A_RAGGED || u < RC * BM / 4) areg[i] = *reinterpret_cast<const f32x4 *>(wsrc + (long)row * p.Mp + c4 * 4);
       }
-      const float *xc = xn + (long)(ch + 1) * F3_CC * HWx;
+      const float *xc = xn + (long)(ch + 1) * CC * HWx;
 #pragma unroll
       for (int i = 0; i < B4; ++i) {
         const float *src = b_ok[i] ? (xc + b_off[i]) : p.zero;
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3s2_kernel(FS2Params p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)A0[(tsel * F3_CC + e) * BM + i * 32];
+          for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)A0[(tsel * CC + e) * BM + i * 32];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -152,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void igemm_f3x3s2_kernel(FS2Params p) {
         const int tr = t / 3, ts = t - tr * 3;
         const int coff = ts == 1 ? 33 : (ts == 2 ? 1 : 0);
 #pragma unroll
-        for (int cp = 0; cp < F3_CC / 2; ++cp) {
-          const int kk = t * (F3_CC / 2) + cp;
+        for (int cp = 0; cp < CC / 2; ++cp) {
+          const int kk = t * (CC / 2) + cp;
           float a[2], b[2];
 #pragma unroll
           for (int i = 0; i < 2; ++i) a[i] = Ap[2 * kk * BM + i * 32];

@@ -589,6 +589,7 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   return 0;
 }
 
+#define FS2_DEFAULT_CC 4
 static bool f3x3s2_ok(int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad) {
   return R == 3 && S == 3 && st_ == 2 && pad == 1 && Hb == 2 * Hs && Wb == 2 * Ws && (Ws % 32) == 0 && (Hs % 4) == 0 &&
          (Cb % F3_CC) == 0 && Cs >= 128 && (long)F3_CC * Hb * Wb < (1L << 31);
@@ -658,7 +659,13 @@ static int run_f3x3s2(const float *in, const float *W, const float *bias, float 
   FS2Params p;
   memset(&p, 0, sizeof(p));
   const int2 *gtab_unused;
-  int rc = launch_pack(W, ws, M, Mp, RED, RED, l, sm, sc, 4 * Hs * Ws, 2 * Ws, st, &p.Wp, &gtab_unused, &p.zero, F3_CC);
+  static int cc = 0;                       // LSPS_FS2_CC=4|8: channel-chunk variant of the f32 kernel (A/B comparisons)
+  if (!cc) {
+    const char *e = getenv("LSPS_FS2_CC");
+    cc = (e && e[0] == '8') ? 8 : ((e && e[0] == '4') ? 4 : FS2_DEFAULT_CC);
+  }
+  const int ccu = g_math_mode == 1 ? 8 : cc;
+  int rc = launch_pack(W, ws, M, Mp, RED, RED, l, sm, sc, 4 * Hs * Ws, 2 * Ws, st, &p.Wp, &gtab_unused, &p.zero, ccu);
   if (rc) return rc;
   p.X = in;
   p.bias = bias;
@@ -673,9 +680,11 @@ static int run_f3x3s2(const float *in, const float *W, const float *bias, float 
   p.act = act;
   p.slope = slope;
   if (g_math_mode == 1)
-    hipLaunchKernelGGL(igemm_f3x3s2_kernel<true>, dim3(N * p.tiles_per_img, Mp / 128), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_f3x3s2_kernel<true, 8>), dim3(N * p.tiles_per_img, Mp / 128), dim3(256), 0, st, p);
+  else if (ccu == 4)
+    hipLaunchKernelGGL((igemm_f3x3s2_kernel<false, 4>), dim3(N * p.tiles_per_img, Mp / 128), dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL(igemm_f3x3s2_kernel<false>, dim3(N * p.tiles_per_img, Mp / 128), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_f3x3s2_kernel<false, 8>), dim3(N * p.tiles_per_img, Mp / 128), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("igemm_f3x3s2");
   note_kernel("igemm_f3x3s2_kernel");
   return 0;
