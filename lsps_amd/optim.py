@@ -47,6 +47,10 @@ class FlatArena(object):
             p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.on_grad_ready = None                       # set by dist.GradReducer
+        # (bias index, weight index) of convs whose bias is mathematically dead (trainers/common_net.py:_mark_dead_bias)
+        index = dict((id(p), i) for i, p in enumerate(self.params))
+        self.dead_bias = [(i, index[id(p._lsps_dead_of)]) for i, p in enumerate(self.params)
+                          if getattr(p, '_lsps_dead_of', None) is not None and id(p._lsps_dead_of) in index]
 
     def _make_hook(self, i):
         def hook(param):
@@ -132,6 +136,9 @@ class FlatAdam(torch.optim.Optimizer):
         b1, b2 = g['betas']
         a = self.arena
         params = g['params']
+        for bi, wi in a.dead_bias:                      # zero gradient (the arena was zeroed) + weight decay, like the reference
+            if a.touched[wi]:
+                a.touched[bi] = True
         if self._copied is not None:
             self._copied.synchronize()                  # previous step's H2D of the pinned tables
         max_len = 0

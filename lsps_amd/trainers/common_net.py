@@ -33,6 +33,14 @@ class _Fused(nn.Module):
         return 'fused: %s' % self.what
 
 
+def _mark_dead_bias(conv):
+    """The bias of a conv that feeds an affine-free InstanceNorm cancels exactly and is not applied here (its gradient is
+    exactly 0).  The reference still passes it through Adam — round-off-sized gradient plus the coupled weight decay — so the
+    trainer lets the optimizer see it (zero gradient + weight decay) whenever the conv's weight got a gradient."""
+    if getattr(conv, 'bias', None) is not None:
+        conv.bias._lsps_dead_of = conv.weight
+
+
 def _default_reset(weight, bias, fan_in):
     nn.init.kaiming_uniform_(weight, a=math.sqrt(5))          # torch's default conv / linear init
     if bias is not None:
@@ -108,6 +116,8 @@ class LeakyINSResBlock(nn.Module):
             layers.append(_Fused('Dropout'))            # same child count as the reference (common_net.py:171-172)
         self.model = nn.Sequential(*layers)
         self.model.apply(gaussian_weights_init)
+        _mark_dead_bias(self.model[0])
+        _mark_dead_bias(self.model[3])
 
     def forward(self, x, drop_mask=None):
         """`drop_mask` (tests): the keep mask ALREADY divided by 1-p; default: drawn here in training mode."""

@@ -72,7 +72,8 @@ def dead_bias_keys(golden):
     """Biases of convs that feed an affine-free InstanceNorm (both convs of every LeakyINSResBlock,
     common_net.py:160-181) are mathematically cancelled: their gradient is exactly 0 and what the
     reference computes for it is pure round-off (~1e-8), which Adam then amplifies to +-lr steps.
-    Nothing observable depends on them, so they are excluded from grad / post-step comparisons."""
+    Nothing observable depends on them; their GRADIENTS are excluded from comparisons, their post-step VALUES are compared
+    with the rule in `compare` (the weight-decay term decides the sign of most elements)."""
     names = set(k.split('/')[1] for k in golden if k.count('/') >= 2)
     dead = set()
     for nme in names:
@@ -94,11 +95,24 @@ def compare(results, golden, rtol, atol_scale=1.0, skip=(), grad_rtol=None):
     worst = 0.0
     flat = flatten(results)
     dead = dead_bias_keys(golden)
+    dead_off = {}
     for key, g in golden.items():
         if any(key.startswith(s) for s in skip):
             continue
         parts = key.split('/')
-        if parts[1] in dead and ('grads' in parts[0] or 'params' in parts[0]):
+        if parts[1] in dead and 'grads' in parts[0]:
+            continue                       # the reference's gradient there is round-off noise around an exact 0
+        if parts[1] in dead and 'params' in parts[0]:
+            # ... but its Adam step is not noise: g = noise + weight_decay * p is dominated by the decay term unless |p| is
+            # tiny, so the bias moves by lr * sign(p) per step.  The product feeds Adam an exact zero gradient + the decay:
+            # most elements land on the reference's value, the sign-ambiguous rest within 2 lr per step.
+            # A single tensor can be mostly sign-ambiguous (the reference vs. its own restatement: 56 % of one bias), so
+            # the fraction is judged over all dead biases of a case (restatement: 1 - 4 %; biases that never move: 100 %).
+            if key in flat and key.rsplit('/', 1)[1] in ('full', 'sample') and g.size:
+                d = np.abs(np.asarray(flat[key], np.float64) - np.asarray(g, np.float64))
+                if float(d.max()) > PARAM_ABS:
+                    bad.append((key, float(d.max()), PARAM_ABS))
+                dead_off.setdefault(parts[0], []).append(float((d > 5e-6).mean()))
             continue
         if key not in flat:
             bad.append((key, 'missing', 0))
@@ -132,6 +146,9 @@ def compare(results, golden, rtol, atol_scale=1.0, skip=(), grad_rtol=None):
         worst = max(worst, err / max(scale, 1e-30))
         if not np.isfinite(err) or err > tol:
             bad.append((key, err, tol))
+    for case, fr in dead_off.items():
+        if float(np.mean(fr)) > 0.15:
+            bad.append((case + '/<dead biases: mean fraction of elements off the reference>', float(np.mean(fr)), 0.15))
     return bad, worst
 
 
