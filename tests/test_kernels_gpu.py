@@ -823,3 +823,50 @@ def test_conv3x3s2_chwn_rejects_unsupported_geometry():
                                      _lib.stream()) != 0
     assert b'geometry' in L.lsps_last_error()
 
+
+_VARIANT_SNIPPET = r"""
+import sys, torch, torch.nn.functional as F
+sys.path.insert(0, %(repo)r)
+from lsps_amd import _lib, ops
+L = _lib.lib()
+torch.manual_seed(0)
+def rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max())
+# 3x3 / stride-2 forward (igemm_f3x3s2_kernel, LSPS_FS2_CC)
+x = torch.randn(3, 64, 64, 64, device='cuda'); w = torch.randn(128, 64, 3, 3, device='cuda') * 0.05; b = torch.randn(128, device='cuda')
+y = ops.conv2d(x, w, b, 2, 1, ops.ACT_LRELU, 0.01)
+assert L.lsps_last_kernel(None) == b'igemm_f3x3s2_kernel', L.lsps_last_kernel(None)
+ref = F.leaky_relu(F.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), stride=2, padding=1), 0.01)
+assert rel(y, ref) < 2e-5, rel(y, ref)
+# F(4x4,3x3) weight gradient (wino4_w3x3_kernel, LSPS_WINO4W_WAVES)
+ops.set_winograd('always')
+N, C, K = 5, 64, 128
+x = torch.randn(N, C, 32, 32, device='cuda'); gy = torch.randn(N, K, 32, 32, device='cuda')
+dw = torch.empty(K, C, 3, 3, device='cuda')
+ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, 32, 32, K, 3, 3, 1, 1), x.device)
+_lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), None, N, C, 32, 32, K, 3, 3, 1, 1, ws, wsb, _lib.stream()), 'wgrad')
+assert L.lsps_last_kernel(None) == b'wino4_w3x3_kernel'
+wr = torch.zeros(K, C, 3, 3, dtype=torch.float64, requires_grad=True)
+F.conv2d(x.double().cpu(), wr, None, padding=1).backward(gy.double().cpu())
+assert rel(dw, wr.grad) < 5e-5, rel(dw, wr.grad)
+print('variants ok')
+"""
+
+
+@pytest.mark.parametrize("env", [{'LSPS_FS2_CC': '8', 'LSPS_WINO4W_WAVES': '8'}, {'LSPS_FS2_CC': '4', 'LSPS_WINO4W_WAVES': '4'}],
+                         ids=['cc8_waves8', 'cc4_waves4'])
+def test_env_selected_kernel_variants(env):
+    """The A/B knobs that are read once per process (LSPS_FS2_CC: 4- / 8-channel chunks of the stride-2 forward kernel;
+    LSPS_WINO4W_WAVES: 4- / 8-wave workgroups of the F(4x4,3x3) weight gradient): both settings of each give the same
+    results against f64 references, in a fresh process."""
+    _need_gpu()
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, '-c', _VARIANT_SNIPPET % dict(repo=repo)], env=e, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and 'variants ok' in out.stdout, (out.stdout[-400:], out.stderr[-1200:])
+
