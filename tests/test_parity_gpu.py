@@ -43,18 +43,26 @@ def test_steps_match_reference_golden(config, golden):
 
 
 @pytest.mark.parametrize("mode", ["always", "off"])
-def test_full_steps_match_reference_golden_per_conv_algorithm(mode, golden):
+def test_full_steps_match_reference_golden_per_conv_algorithm(mode, golden, monkeypatch):
     """The `full` config's update steps against the REAL reference's golden vectors with the residual convs forced
     onto the Winograd kernels (forward, dgrad and weight gradient, also at this small batch) and onto the direct ones:
-    both sit inside the same tolerances ('auto', the default, is what the test above runs)."""
+    both sit inside the same tolerances ('auto', the default, is what the test above runs).  In the 'always' run the
+    discriminator trunk is also forced onto the batch-innermost kernels the bench-size batches use (csrc/chwn.hip; their
+    batch threshold is lifted), so the whole default bs=128 dispatch is checked against the reference at trainer level."""
     A = _adapter()
     from lsps_amd import ops
     prev = ops.get_winograd()
     ops.set_winograd(mode)
+    monkeypatch.setenv('LSPS_CHWN_MIN_N', '1' if mode == 'always' else '1000000')
+    ops.kernel_log_begin()
     try:
         R = cases.run_step_cases(A, 'full', lsps_ref)
     finally:
+        names = ops.kernel_log_end()
         ops.set_winograd(prev)
+    assert ('chwn_gemm_kernel' in names and 'chwn_wgrad_kernel' in names) == (mode == 'always'), sorted(set(names))
+    if mode == 'always':
+        assert 'wino4_f3x3_kernel' in names and 'wino4_w3x3_kernel' in names, sorted(set(names))
     g = {k: v for k, v in golden('full').items() if k.split('/')[0] in R}
     bad, worst = cases.compare(R, g, RTOL, grad_rtol=2e-2)
     print("worst rel err", worst)
