@@ -1647,7 +1647,11 @@ int lsps_convT2d_fwd(const float *x, const float *w, const float *bias, float *y
   LSPS_CHECK_ARG(Ho > 0 && Wo > 0, "convT2d_fwd: empty output");
   if (pw1_ok(Co, R, S, stride, pad, outpad, (long)H * W, x, y)) {
     const int HW4 = H * W / 4;
-    hipLaunchKernelGGL(pw1_fwd_kernel, dim3(ceil_div((long)N * HW4, 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+    if ((long)N * ceil_div(HW4, 1024) >= 2048)
+      hipLaunchKernelGGL(pw1_fwd_kernel<4>, dim3(N * ceil_div(HW4, 1024)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                       y, N, Ci, HW4, act, slope);
+    else
+      hipLaunchKernelGGL(pw1_fwd_kernel<2>, dim3(N * ceil_div(HW4, 512)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                        y, N, Ci, HW4, act, slope);
     LSPS_CHECK_LAUNCH("pw1_fwd");
     note_kernel("pw1_fwd_kernel");
@@ -1666,7 +1670,7 @@ int lsps_convT2d_dgrad(const float *dy, const float *w, float *dx, int N, int Ci
   const int Ho = (H - 1) * stride - 2 * pad + R + outpad, Wo = (W - 1) * stride - 2 * pad + S + outpad;
   if (pw1_ok(Co, R, S, stride, pad, outpad, (long)H * W, dy, dx)) {
     const int HW4 = H * W / 4;
-    hipLaunchKernelGGL(pw1_dgrad_kernel, dim3(ceil_div((long)N * HW4, 256)), dim3(256), 0, (hipStream_t)stream, dy, w, dx,
+    hipLaunchKernelGGL(pw1_dgrad_kernel, dim3(N * ceil_div(HW4, 1024)), dim3(256), 0, (hipStream_t)stream, dy, w, dx,
                        N, Ci, HW4);
     LSPS_CHECK_LAUNCH("pw1_dgrad");
     note_kernel("pw1_dgrad_kernel");
