@@ -34,10 +34,13 @@ template <bool BF16, int CC>
 __global__ __launch_bounds__(256, CC == 8 ? 2 : 3) void igemm_f3x3s2_kernel(FS2Params p) {
   constexpr int BM = 128, RC = CC * 9;
   constexpr int A4 = (RC * BM / 4 + 255) / 256;                    // float4 of weights per thread per chunk (9, or 4.5 -> 5)
-  constexpr bool A_RAGGED = (RC * BM / 4) % 256 != 0;
+  constexpr int A_LASTW = ((RC * BM / 4) % 256) ? ((RC * BM / 4) % 256) / 64 : 4;   // waves that take part in the last round
   constexpr int LINES = CC * FS2_ROWS;                          // 72 (channel, row) lines of 64 columns
   constexpr int B4 = (LINES * 16 + 255) / 256;                     // 5 float4 of input per thread per chunk (4.5)
-  __shared__ __attribute__((aligned(16))) float lds[RC * BM + CC * FS2_CH];
+  constexpr int B_LASTW = ((LINES * 16) % 256) ? ((LINES * 16) % 256) / 64 : 4;
+  constexpr int H_WAVES = (LINES + 63) / 64;                       // waves that fetch the halo column
+  static_assert((RC * BM / 4) % 64 == 0 && (LINES * 16) % 64 == 0, "the last staging round ends on a wave boundary");
+  __shared__ __attribute__((aligned(16))) float lds[RC * BM + CC * FS2_CH + 4];
   float *As = lds, *Bs = lds + RC * BM;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -47,25 +50,35 @@ __global__ __launch_bounds__(256, CC == 8 ? 2 : 3) void igemm_f3x3s2_kernel(FS2P
   const int rem = blockIdx.x - n * p.tiles_per_img;
   const int p0 = (rem / p.qblocks) * 4, q0 = (rem - (rem / p.qblocks) * p.qblocks) * 32;
   const int Hx = 2 * p.P, Wx = 2 * p.Q, HWx = Hx * Wx;
-  const float *xn = p.X + (long)n * p.Cx * HWx;
 
-  int b_lds[B4], b_off[B4];
-  bool b_use[B4], b_ok[B4];
+  // Staging without a branch or a 64-bit lane address: both operands come through buffer descriptors (uniform
+  // base + ONE 32-bit lane offset + a scalar chunk offset); a lane whose element lies outside the image carries an offset
+  // past num_records and gets 0 from the range check; the ragged last round of a staging loop ends on a wave boundary, so
+  // the only conditions left are wave-uniform.
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.X + (long)n * p.Cx * HWx), 0, p.Cx * HWx * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.Wp + m0), 0, (p.Cx * 9 * p.Mp - m0) * 4, 0x00020000);
+  const unsigned a_vo = (unsigned)((tid >> 5) * p.Mp + (tid & 31) * 4) * 4u;       // round i: + 8 i rows (uniform)
+  const int a_row8 = 8 * p.Mp * 4, a_chunk = RC * p.Mp * 4, b_chunk = CC * HWx * 4;
+
+  int b_lds[B4];
+  unsigned b_vo[B4];
 #pragma unroll
   for (int i = 0; i < B4; ++i) {
     const int u = tid + 256 * i;
-    b_use[i] = u < LINES * 16;
     const int line = u >> 4, c4 = u & 15;
     const int chn = line / FS2_ROWS, r = line - chn * FS2_ROWS;
-    const int ih = 2 * p0 - 1 + r;
-    b_ok[i] = b_use[i] && ih >= 0;                                 // ih <= 2 p0 + 7 < 2P always
+    const int ih = 2 * p0 - 1 + r;                                 // ih <= 2 p0 + 7 < 2P always
     b_lds[i] = chn * FS2_CH + r * FS2_ROW + 2 * c4;
-    b_off[i] = chn * HWx + ih * Wx + 2 * q0 + c4 * 4;
+    b_vo[i] = (u < LINES * 16 && ih >= 0) ? (unsigned)(chn * HWx + ih * Wx + 2 * q0 + c4 * 4) * 4u : OOB;
   }
-  const bool h_use = tid < LINES;                                   // column 2 q0 - 1 of every line
+  // column 2 q0 - 1 of every line; lanes beyond the last line fetch nothing and store into the spare slot
   const int h_chn = tid / FS2_ROWS, h_r = tid - h_chn * FS2_ROWS;
-  const bool h_ok = h_use && (2 * p0 - 1 + h_r) >= 0 && q0 > 0;
-  const int h_off = h_chn * HWx + (2 * p0 - 1 + h_r) * Wx + 2 * q0 - 1;
+  const bool h_ok = tid < LINES && (2 * p0 - 1 + h_r) >= 0 && q0 > 0;
+  const unsigned h_vo = h_ok ? (unsigned)(h_chn * HWx + (2 * p0 - 1 + h_r) * Wx + 2 * q0 - 1) * 4u : OOB;
+  const int h_lds = tid < LINES ? h_chn * FS2_CH + h_r * FS2_ROW : CC * FS2_CH;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -88,37 +101,30 @@ __global__ __launch_bounds__(256, CC == 8 ? 2 : 3) void igemm_f3x3s2_kernel(FS2P
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < A4; ++i)
-        if (!A_RAGGED || tid + 256 * i < RC * BM / 4) *reinterpret_cast<f32x4 *>(As + (tid + 256 * i) * 4) = areg[i];
+        if (i < A4 - 1 || wave < A_LASTW) *reinterpret_cast<f32x4 *>(As + (tid + 256 * i) * 4) = areg[i];
 #pragma unroll
       for (int i = 0; i < B4; ++i)
-        if (b_use[i]) {
+        if (i < B4 - 1 || wave < B_LASTW) {
           float *d = Bs + b_lds[i];
           d[33] = breg[i][0];                                      // E[2 c4]
           d[1] = breg[i][1];                                       // O'[2 c4 + 1]
           d[34] = breg[i][2];                                      // E[2 c4 + 1]
           d[2] = breg[i][3];                                       // O'[2 c4 + 2]
         }
-      if (h_use) Bs[h_chn * FS2_CH + h_r * FS2_ROW] = hreg;        // O'[0]
+      if (wave < H_WAVES) Bs[h_lds] = hreg;                        // O'[0]
       __syncthreads();
     }
     if (ch + 1 < nchunks) {
-      const float *wsrc = p.Wp + (long)(ch + 1) * RC * p.Mp + m0;
+      const int ao = (ch + 1) * a_chunk, bo = (ch + 1) * b_chunk;  // uniform
 #pragma unroll
-      for (int i = 0; i < A4; ++i) {
-        const int u = tid + 256 * i;
-        const int row = u >> 5, c4 = u & 31;
-        if (!A_RAGGED || u < RC * BM / 4) areg[i] = *reinterpret_cast<const f32x4 *>(wsrc + (long)row * p.Mp + c4 * 4);
-      }
-      const float *xc = xn + (long)(ch + 1) * CC * HWx;
+      for (int i = 0; i < A4; ++i)
+        if (i < A4 - 1 || wave < A_LASTW)
+          areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, a_vo, ao + i * a_row8, 0));
 #pragma unroll
-      for (int i = 0; i < B4; ++i) {
-        const float *src = b_ok[i] ? (xc + b_off[i]) : p.zero;
-        breg[i] = *reinterpret_cast<const f32x4 *>(src);
-      }
-      {
-        const float *src = h_ok ? (xc + h_off) : p.zero;
-        hreg = *src;
-      }
+      for (int i = 0; i < B4; ++i)
+        if (i < B4 - 1 || wave < B_LASTW)
+          breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, b_vo[i], bo, 0));
+      if (wave < H_WAVES) hreg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, h_vo, bo, 0));
     }
     if (ch >= 0 && BF16) {
       // bf16 MFMA mode: K = 16 = (2 taps) x (8 channels): lanes 0-31 carry tap 2g, lanes 32-63 tap 2g+1 (the fifth
@@ -234,26 +240,37 @@ __device__ __forceinline__ void ts2_body(const TS2Params &p, float *lds) {
   const int rem = blockIdx.x - n * p.tiles_per_img;
   const int p0 = (rem / p.qblocks) * TR, q0 = (rem - (rem / p.qblocks) * p.qblocks) * 32;
   const int HWs = p.Hs * p.Ws;
-  const float *xn = p.X + (long)n * p.Cx * HWs;
+
+  // branch-free staging through buffer descriptors, as in igemm_f3x3s2_kernel: rows past the bottom edge / the column past
+  // the right edge carry an out-of-range lane offset and read 0; the ragged last round ends on a wave boundary
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int B_REM = (TS_CC * ROWS * 8) % 256, B_LASTW = B_REM ? B_REM / 64 : 4;
+  constexpr int H_WAVES = (TS_CC * ROWS + 63) / 64;
+  static_assert(B_REM % 64 == 0, "the last staging round ends on a wave boundary");
+  static_assert((AROWS * BM / 4) % 256 == 0 && (BM == 128 || BM == 64), "weight rounds are full");
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.X + (long)n * p.Cx * HWs), 0, p.Cx * HWs * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.Wp + m0), 0, (p.Cx * 9 * p.Mp - m0) * 4, 0x00020000);
+  const unsigned a_vo = (unsigned)((tid / (BM / 4)) * p.Mp + (tid % (BM / 4)) * 4) * 4u;
+  const int mp4 = p.Mp * 4, a_chunk = 9 * TS_CC * mp4, b_chunk = TS_CC * HWs * 4;
 
   int b_lds[B4];
-  int b_off[B4];                                             // element offsets inside one 16-channel slab (< 2^31)
-  bool b_use[B4], b_ok[B4];
+  unsigned b_vo[B4];
 #pragma unroll
   for (int i = 0; i < B4; ++i) {
     const int u = tid + 256 * i;
-    b_use[i] = u < TS_CC * ROWS * 8;
     const int line = u >> 3, c4 = u & 7;
     const int chn = line / ROWS, r = line - chn * ROWS;
-    b_ok[i] = b_use[i] && (p0 + r) < p.Hs;
     b_lds[i] = chn * CHS + r * 34 + c4 * 4;
-    b_off[i] = chn * HWs + (p0 + r) * p.Ws + q0 + c4 * 4;
+    b_vo[i] = (u < TS_CC * ROWS * 8 && (p0 + r) < p.Hs) ? (unsigned)(chn * HWs + (p0 + r) * p.Ws + q0 + c4 * 4) * 4u : OOB;
   }
-  // column q0 + 32 (the right neighbour of the tile): one scalar per (channel, row) line
-  const bool h_use = tid < TS_CC * ROWS;
+  // column q0 + 32 (the right neighbour of the tile): one scalar per (channel, row) line; surplus lanes use the spare slot
   const int h_chn = tid / ROWS, h_r = tid - h_chn * ROWS;
+  const bool h_use = tid < TS_CC * ROWS;
   const bool h_ok = h_use && (p0 + h_r) < p.Hs && (q0 + 32) < p.Ws;
-  const int h_off = h_chn * HWs + (p0 + h_r) * p.Ws + q0 + 32;
+  const unsigned h_vo = h_ok ? (unsigned)(h_chn * HWs + (p0 + h_r) * p.Ws + q0 + 32) * 4u : OOB;
+  const int h_lds = h_use ? h_chn * CHS + h_r * 34 + 32 : TS_LDS_FLOATS - AROWS * BM;
 
   f32x16 acc[2][2][2];                                       // [m tile][row][column class]
 #pragma unroll
@@ -280,38 +297,32 @@ __device__ __forceinline__ void ts2_body(const TS2Params &p, float *lds) {
       for (int i = 0; i < A4; ++i) *reinterpret_cast<f32x4 *>(As + (tid + 256 * i) * 4) = areg[i];
 #pragma unroll
       for (int i = 0; i < B4; ++i)
-        if (b_use[i]) {
+        if (i < B4 - 1 || wave < B_LASTW) {
           float *d = Bs + b_lds[i];
           d[0] = breg[i][0];
           d[1] = breg[i][1];
           d[2] = breg[i][2];
           d[3] = breg[i][3];
         }
-      if (h_use) Bs[h_chn * CHS + h_r * 34 + 32] = hreg;
+      if (wave < H_WAVES) Bs[h_lds] = hreg;
       __syncthreads();
     }
     if (ch + 1 < nchunks) {
       // packed weights: rows [chunk of 16 channels][tap 0..8][16 channels]; this class uses taps 3..5 (a = 0) or
-      // 0..2 and 6..8 (a = 1)
-      const float *wsrc = p.Wp + (long)(ch + 1) * (9 * TS_CC) * p.Mp + m0;
+      // 0..2 and 6..8 (a = 1).  Round i of a thread covers local rows (256 i + tid) / (BM / 4): the tap is uniform per round.
+      const int ao = (ch + 1) * a_chunk, bo = (ch + 1) * b_chunk;
 #pragma unroll
       for (int i = 0; i < A4; ++i) {
-        const int u = tid + 256 * i;
-        const int row = u / (BM / 4), c4 = u - row * (BM / 4);
-        const int lt = row / TS_CC;
-        const int grow = (APAR ? (lt < 3 ? lt : lt + 3) : lt + 3) * TS_CC + (row - lt * TS_CC);
-        areg[i] = *reinterpret_cast<const f32x4 *>(wsrc + (long)grow * p.Mp + c4 * 4);
+        const int lrow0 = i * (1024 / BM);                     // first local row of the round (8 i or 16 i)
+        const int lt = lrow0 / TS_CC;
+        const int grow0 = (APAR ? (lt < 3 ? lt : lt + 3) : lt + 3) * TS_CC + (lrow0 - lt * TS_CC);
+        areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, a_vo, ao + grow0 * mp4, 0));
       }
-      const float *xc = xn + (long)(ch + 1) * TS_CC * HWs;
 #pragma unroll
-      for (int i = 0; i < B4; ++i) {
-        const float *src = b_ok[i] ? (xc + b_off[i]) : p.zero;
-        breg[i] = *reinterpret_cast<const f32x4 *>(src);
-      }
-      {
-        const float *src = h_ok ? (xc + h_off) : p.zero;
-        hreg = *src;
-      }
+      for (int i = 0; i < B4; ++i)
+        if (i < B4 - 1 || wave < B_LASTW)
+          breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, b_vo[i], bo, 0));
+      if (wave < H_WAVES) hreg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, h_vo, bo, 0));
     }
     if (ch >= 0 && BF16) {
       // bf16 MFMA mode: K = 16 = the chunk's 16 channels of one tap (lanes 0-31: channels 0-7, lanes 32-63: 8-15),
@@ -394,7 +405,7 @@ __device__ __forceinline__ void ts2_body(const TS2Params &p, float *lds) {
 
 template <int BM, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void igemm_t3x3s2_kernel(TS2Params p) {
-  __shared__ __attribute__((aligned(16))) float lds[TS_LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[TS_LDS_FLOATS + 4];    // + the spare slot of the halo store
   if (blockIdx.z == 0)
     ts2_body<0, BM, BF16>(p, lds);
   else
@@ -736,6 +747,38 @@ __global__ __launch_bounds__(512, 2) void igemm_w3x3s2_kernel(WS2Params p) {
   const float *Bp = Bs + (wn * 32 + l31) * WS2_CH + half;
   const int per_img = p.Hs * p.qblocks;
 
+  // Branch-free staging with a uniform chunk cursor (n, y, qb) instead of a division per chunk: the descriptors' bases carry
+  // the cursor (64-bit scalar arithmetic), a lane carries ONE 32-bit offset per load.  The big image's row 2y - 1 does not
+  // exist for y = 0 and the column 2 q0 - 1 not for q0 = 0: lanes of that row carry bit 31 in their offset (out of range for
+  // the descriptor -> 0), cleared by a uniform mask when the row exists.
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned a_vo[2], b_vo[6];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = tid + 512 * i;
+    a_vo[i] = (unsigned)((u >> 3) * HWs + (u & 7) * 4) * 4u;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int u = tid + 512 * i;
+    const int line = u >> 4, c4 = u & 15;
+    const int chn = line / 3, r = line - chn * 3;
+    b_vo[i] = ((unsigned)((long)chn * HWb + r * Wb + c4 * 4) * 4u) | (r == 0 ? OOB : 0u);
+  }
+  unsigned h_vo;
+  {
+    const int chn = tid / 3, r = tid - chn * 3;
+    h_vo = ((unsigned)((long)chn * HWb + r * Wb) * 4u) | (r == 0 ? OOB : 0u);
+  }
+  int cn = 0, cy = 0, cq = 0;                               // cursor of the chunk being FETCHED
+  {
+    const int nc = ch_begin;
+    cn = nc / per_img;
+    const int rem = nc - cn * per_img;
+    cy = rem / p.qblocks;
+    cq = rem - cy * p.qblocks;
+  }
+
   for (int ch = ch_begin - 1; ch < ch_end; ++ch) {
     if (ch >= ch_begin) {
       __syncthreads();
@@ -758,35 +801,33 @@ __global__ __launch_bounds__(512, 2) void igemm_w3x3s2_kernel(WS2Params p) {
         d[34] = breg[i][2];                              // E[2 c4 + 1]
         d[2] = breg[i][3];                               // O'[2 c4 + 2]
       }
-      if (tid < 192) Bs[tid * WS2_ROW] = hreg;           // O'[0]: the column left of the block (zero at the image edge)
+      if (wave < 3) Bs[tid * WS2_ROW] = hreg;            // O'[0]: the column left of the block (zero at the image edge)
       __syncthreads();
     }
     if (ch + 1 < ch_end) {
-      const int nc = ch + 1;
-      const int n = nc / per_img;
-      const int rem = nc - n * per_img;
-      const int y = rem / p.qblocks, q0 = (rem - y * p.qblocks) * 32;
-      const float *sb = p.Small + ((long)n * p.M + m0) * HWs + y * p.Ws + q0;
+      const int q0 = cq * 32;
+      const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float *>(p.Small + ((long)cn * p.M + m0) * HWs + cy * p.Ws), 0, 0x7fffffff, 0x00020000);
+      // base = row 2y - 1 of channel c0 (for y = 0 one row in front of the channel: only the masked lanes would touch it)
+      const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float *>(p.Big + ((long)cn * p.C + c0) * HWb + (long)(2 * cy - 1) * Wb), 0, 0x7fffffff, 0x00020000);
+      const unsigned rmask = cy > 0 ? 0x7fffffffu : 0xffffffffu;                // uniform
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int u = tid + 512 * i;
-        areg[i] = *reinterpret_cast<const f32x4 *>(sb + (long)(u >> 3) * HWs + (u & 7) * 4);
-      }
-      const float *bb = p.Big + ((long)n * p.C + c0) * HWb + 2 * q0;
+      for (int i = 0; i < 2; ++i)
+        areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, a_vo[i], q0 * 4, 0));
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int u = tid + 512 * i;
-        const int line = u >> 4, c4 = u & 15;
-        const int chn = line / 3, r = line - chn * 3;
-        const int rb = 2 * y - 1 + r;
-        const float *src = rb >= 0 ? (bb + (long)chn * HWb + (long)rb * Wb + c4 * 4) : p.zero;
-        breg[i] = *reinterpret_cast<const f32x4 *>(src);
+      for (int i = 0; i < 6; ++i)
+        breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, b_vo[i] & rmask, 2 * q0 * 4, 0));
+      if (wave < 3) {
+        const unsigned hm = q0 > 0 ? 0u : OOB;                                  // uniform
+        hreg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (h_vo & rmask) | hm, q0 > 0 ? 2 * q0 * 4 - 4 : 0, 0));
       }
-      if (tid < 192) {
-        const int chn = tid / 3, r = tid - chn * 3;
-        const int rb = 2 * y - 1 + r;
-        const float *src = (rb >= 0 && q0 > 0) ? (bb + (long)chn * HWb + (long)rb * Wb - 1) : p.zero;
-        hreg = *src;
+      if (++cq == p.qblocks) {
+        cq = 0;
+        if (++cy == p.Hs) {
+          cy = 0;
+          ++cn;
+        }
       }
     }
     if (ch >= ch_begin && BF16) {
