@@ -158,24 +158,32 @@ __global__ __launch_bounds__(256, CC == 8 ? 2 : 3) void igemm_f3x3s2_kernel(FS2P
       }
     }
     if (ch >= 0 && !BF16) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
+      // k-pair kk = (tap t, channel pair cp); the operands of pair kk + 1 are fetched from LDS BEFORE the four MFMAs of pair
+      // kk are issued (the compiler puts each read right in front of its first use otherwise).  Measured: 128.9 -> 130.9
+      // TFLOP/s in the step and 141 -> 124 registers; the same change on the transposed kernel bought nothing.
+      constexpr int NK = 9 * (CC / 2);
+      float a_nx[2], b_nx[2];
+      auto rd = [&](int kk) {
+        const int t = kk / (CC / 2), cp = kk - t * (CC / 2);
         const int tr = t / 3, ts = t - tr * 3;
         const int coff = ts == 1 ? 33 : (ts == 2 ? 1 : 0);
 #pragma unroll
-        for (int cp = 0; cp < CC / 2; ++cp) {
-          const int kk = t * (CC / 2) + cp;
-          float a[2], b[2];
+        for (int i = 0; i < 2; ++i) a_nx[i] = Ap[2 * kk * BM + i * 32];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) a[i] = Ap[2 * kk * BM + i * 32];
+        for (int j = 0; j < 2; ++j) b_nx[j] = Bp[2 * cp * FS2_CH + (2 * j + tr) * FS2_ROW + coff];
+      };
+      rd(0);
 #pragma unroll
-          for (int j = 0; j < 2; ++j) b[j] = Bp[2 * cp * FS2_CH + (2 * j + tr) * FS2_ROW + coff];
+      for (int kk = 0; kk < NK; ++kk) {
+        const float a[2] = {a_nx[0], a_nx[1]}, b[2] = {b_nx[0], b_nx[1]};
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 1 < NK) rd(kk + 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
   }
