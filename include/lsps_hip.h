@@ -99,6 +99,23 @@ int lsps_conv2d_wgrad(const float *x, const float *dy, float *dw, float *db /*nu
                       int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
                       void *ws, size_t ws_bytes, void *stream);
 
+/* ---- grouped conv -------------------------------------------------------------------------------------------------------
+ * nn.Conv2d(C, K, R, stride, pad, groups=G) of the ResNeXt block (reference common_net.py:111-132, `LeakyINSResNeXtBlock`:
+ * Conv2d(k*inplanes, k*inplanes, 3, 1, 1, groups=cardinality), used by `SharedResXGen`, lsps_nets.py:277-387).
+ * x [N,C,H,W], w [K, C/G, R, S], y / dy [N,K,P,Q]; group g maps channels [g C/G, (g+1) C/G) to [g K/G, (g+1) K/G).  One
+ * launch of the gather-GEMM kernels per group straight on the channel slices of the full tensors (sample strides C*H*W /
+ * K*P*Q): no slice copies, no concatenation.  Workspace: lsps_conv2d_workspace_bytes of the per-group geometry
+ * (N, C/G, H, W, K/G, ...).  dw [K,C/G,R,S] and the optional db [K] are overwritten. */
+int lsps_conv2d_grouped_fwd(const float *x, const float *w, const float *bias /*nullable*/, float *y,
+                            int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int groups,
+                            int act, float slope, void *ws, size_t ws_bytes, void *stream);
+int lsps_conv2d_grouped_dgrad(const float *dy, const float *w, float *dx,
+                              int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int groups,
+                              void *ws, size_t ws_bytes, void *stream);
+int lsps_conv2d_grouped_wgrad(const float *x, const float *dy, float *dw, float *db /*nullable*/,
+                              int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int groups,
+                              void *ws, size_t ws_bytes, void *stream);
+
 /* ---- 3x3 / stride 2 / pad 1 convs on small feature maps in batch-innermost layout [C][H][W][N] ("CHWN") ---------------
  * The discriminator trunk (reference lsps_nets.py:119-121 `_make_shared_net`: four LeakyReLUConv2d(tch, 2 tch, 3, 2, 1),
  * common_net.py:250-252) runs on 16x16 ... 2x2 maps with 128 ... 2048 channels; with the batch innermost every

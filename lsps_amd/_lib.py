@@ -34,6 +34,9 @@ _SIGNATURES = {
     'lsps_conv2d_dgrad_acc': (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
     'lsps_conv2d_dgrad_inbwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [c_float, _P, c_size_t, _P]),
     'lsps_conv2d_wgrad': (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
+    'lsps_conv2d_grouped_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 10 + [c_int, c_float, _P, c_size_t, _P]),
+    'lsps_conv2d_grouped_dgrad': (c_int, [_P, _P, _P] + [c_int] * 10 + [_P, c_size_t, _P]),
+    'lsps_conv2d_grouped_wgrad': (c_int, [_P, _P, _P, _P] + [c_int] * 10 + [_P, c_size_t, _P]),
     'lsps_transpose2d': (c_int, [_P, _P, c_long, c_long, _P]),
     'lsps_conv3x3s2_chwn_workspace_bytes': (c_size_t, [c_int] * 5),
     'lsps_conv3x3s2_chwn_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [c_int, c_float, _P, c_size_t, _P]),

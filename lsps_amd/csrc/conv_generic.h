@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
     gpw = rem - gph * p.PW;
   }
   const int ih0 = gph * p.ist, iw0 = gpw * p.ist;
-  const float *xb = p.X + ((long)gn * p.Cx * p.Hx + ih0) * p.Wx + iw0;
+  const float *xb = p.X + (long)gn * p.xns + (long)ih0 * p.Wx + iw0;
   unsigned long long mask = 0ull;
   for (int t = 0; t < p.taps.T; ++t) {
     const int ih = ih0 + p.taps.dh[t], iw = iw0 + p.taps.dw[t];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
     const int n = (int)(Jo / p.P);
     const int rem = (int)(Jo - (long)n * p.P);
     const int ph = rem / p.PW, pw = rem - ph * p.PW;
-    float *yb = p.Y + (long)n * p.M * p.HyWy + (long)(p.h0 + p.hs * ph) * p.Wy + (p.w0 + p.ws * pw);
+    float *yb = p.Y + (long)n * p.yns + (long)(p.h0 + p.hs * ph) * p.Wy + (p.w0 + p.ws * pw);
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f_kernel(FParams p) {
 __global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias,
                                                             float *__restrict__ y, int M, int P, long NPIX, int ksplit,
                                                             int act, float slope, int PW, int HyWy, int Wy, int h0, int hs,
-                                                            int w0, int ws) {
+                                                            int w0, int ws, long yns) {
   // part[z][m][pix] -> Y[n][m][h0 + hs*ph][w0 + ws*pw]  (pix = n*P + ph*PW + pw; the output lattice of one parity class of
   // the transposed direction, or the whole image with h0 = w0 = 0, hs = ws = 1)
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // over [M][NPIX]
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float *__restr
   const long n = pix / P;
   const int pp = (int)(pix - n * P);
   const int ph = pp / PW, pw = pp - ph * PW;
-  y[(n * M + m) * HyWy + (long)(h0 + hs * ph) * Wy + w0 + ws * pw] = apply_act(s, act, slope);
+  y[n * yns + (long)m * HyWy + (long)(h0 + hs * ph) * Wy + w0 + ws * pw] = apply_act(s, act, slope);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -360,8 +360,8 @@ __global__ __launch_bounds__(256) void igemm_w_kernel(WParams p) {
         const int ih = ih0 + p.taps.dh[t], iw = iw0 + p.taps.dw[t];
         if (pv && ih >= 0 && ih < p.Hx && iw >= 0 && iw < p.Wx) mask |= (1ull << t);
       }
-      const float *sb = p.Small + (long)n * p.M * p.P + pp;
-      const float *xb = p.Big + ((long)n * p.Cx * p.Hx + ih0) * p.Wx + iw0;
+      const float *sb = p.Small + (long)n * p.sns + pp;
+      const float *xb = p.Big + (long)n * p.bns + (long)ih0 * p.Wx + iw0;
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
         const int m = m0 + wave * RW + i;           // wave-uniform row

@@ -60,6 +60,8 @@ struct FParams {
   const int2 *gtab;              // [REDp] (element offset c*HxWx + toff[t], tap index t; t = 63 for padding rows)
   const float *zero;             // >= 1 float of zeros: where masked-out gathers read from
   int Cx, Hx, Wx, HxWx;          // gather source [N][Cx][Hx][Wx]
+  long xns, yns;                 // floats between samples of X / Y (= Cx*HxWx / M*HyWy unless X / Y are channel slices of wider
+                                 // tensors: the groups of a grouped conv)
   int PH, PW, P, NPIX;           // output pixel lattice per sample, P = PH*PW, NPIX = N*P
   int ist;                       // input step per lattice step
   int RED, REDp, Mp;             // RED = Cx*T ; packed weights are [REDp][Mp], zero padded
@@ -80,6 +82,7 @@ struct WParams {
   const int2 *jtab;              // [Jp = J rounded up to 128] (offset, tap) per column j = (c,t); tap 63 = padding
   const float *zero;
   int Cx, Hx, Wx, HxWx;          // Big = [N][Cx][Hx][Wx]
+  long sns, bns;                 // floats between samples of Small / Big (channel slices of wider tensors: grouped conv)
   int PH, PW, P, NPIX;           // Small = [N][M][PH][PW]
   int ist;
   int M, J;                      // J = Cx*T

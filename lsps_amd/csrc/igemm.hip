@@ -244,7 +244,7 @@ static int launch_f_split(FParams &p, int cfg, void *free_ws, size_t free_bytes,
       if (rc) return rc;
       const long total = (long)p.M * p.NPIX;
       hipLaunchKernelGGL(ksplit_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float *)p.part, p.bias, p.Y,
-                         p.M, p.P, (long)p.NPIX, ks, p.act, p.slope, p.PW, p.HyWy, p.Wy, p.h0, p.hs, p.w0, p.ws);
+                         p.M, p.P, (long)p.NPIX, ks, p.act, p.slope, p.PW, p.HyWy, p.Wy, p.h0, p.hs, p.w0, p.ws, p.yns);
       LSPS_CHECK_LAUNCH("ksplit_reduce");
       return 0;
     }
@@ -733,21 +733,11 @@ static int run_c1_fwd(const float *in, const float *W, const float *bias, float 
 // "forward direction": in = big image [N][Cb][Hb][Wb], out = small image [N][Cs][Hs][Ws]
 //   out[n][m][p][q] = sum_{c,r,s} W(m,c,r,s) * in[n][c][p*st-pad+r][q*st-pad+s]
 //   weight element address: W[m*sm + c*sc + r*S + s]
-static int run_forward_dir(const float *in, const float *W, const float *bias, float *out, int N, int Cb, int Hb, int Wb,
-                           int Cs, int Hs, int Ws, int R, int S, int st_, int pad, long sm, long sc, int act,
-                           float slope, void *ws, size_t ws_bytes, hipStream_t st) {
-#ifndef LSPS_NO_F3X3
-  if (f3x3_ok(Cb, Hb, Wb, R, S, st_, pad) && (Cs >= 128 || wino4_ok(N, Cb, Hb, Cs)))
-    return run_f3x3(in, W, bias, out, N, Cb, Hb, Cs, sm, sc, false, act, slope, ws, ws_bytes, st);
-#endif
-#ifndef LSPS_NO_F3X3S2
-  if (f3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad))
-    return run_f3x3s2(in, W, bias, out, N, Cb, Hs, Ws, Cs, sm, sc, act, slope, ws, ws_bytes, st);
-#endif
-#ifndef LSPS_NO_C1
-  if (c1_fwd_ok(Cb, Hb, Wb, Hs, Ws, R, S, st_, pad, sm))
-    return run_c1_fwd(in, W, bias, out, N, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad, act, slope, st);
-#endif
+// the gather-GEMM path of the forward direction; xns / yns = floats between samples of in / out (dense tensors: Cb*Hb*Wb and
+// Cs*Hs*Ws; a group of a grouped conv reads / writes a channel slice of a wider tensor)
+static int run_forward_generic(const float *in, const float *W, const float *bias, float *out, int N, int Cb, int Hb, int Wb,
+                               int Cs, int Hs, int Ws, int R, int S, int st_, int pad, long sm, long sc, int act,
+                               float slope, void *ws, size_t ws_bytes, hipStream_t st, long xns, long yns) {
   TapList l;
   l.T = R * S;
   for (int r = 0; r < R; ++r)
@@ -774,6 +764,8 @@ static int run_forward_dir(const float *in, const float *W, const float *bias, f
   p.Hx = Hb;
   p.Wx = Wb;
   p.HxWx = Hb * Wb;
+  p.xns = xns;
+  p.yns = yns;
   p.PH = Hs;
   p.PW = Ws;
   p.P = Hs * Ws;
@@ -794,6 +786,25 @@ static int run_forward_dir(const float *in, const float *W, const float *bias, f
   p.slope = slope;
   fill_taps(p.taps, l, Wb);
   return launch_f_split(p, choose_cfg(M, p.NPIX), (char *)ws + need, ws_bytes - need, st);
+}
+
+static int run_forward_dir(const float *in, const float *W, const float *bias, float *out, int N, int Cb, int Hb, int Wb,
+                           int Cs, int Hs, int Ws, int R, int S, int st_, int pad, long sm, long sc, int act,
+                           float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+#ifndef LSPS_NO_F3X3
+  if (f3x3_ok(Cb, Hb, Wb, R, S, st_, pad) && (Cs >= 128 || wino4_ok(N, Cb, Hb, Cs)))
+    return run_f3x3(in, W, bias, out, N, Cb, Hb, Cs, sm, sc, false, act, slope, ws, ws_bytes, st);
+#endif
+#ifndef LSPS_NO_F3X3S2
+  if (f3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad))
+    return run_f3x3s2(in, W, bias, out, N, Cb, Hs, Ws, Cs, sm, sc, act, slope, ws, ws_bytes, st);
+#endif
+#ifndef LSPS_NO_C1
+  if (c1_fwd_ok(Cb, Hb, Wb, Hs, Ws, R, S, st_, pad, sm))
+    return run_c1_fwd(in, W, bias, out, N, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad, act, slope, st);
+#endif
+  return run_forward_generic(in, W, bias, out, N, Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad, sm, sc, act, slope, ws, ws_bytes, st,
+                             (long)Cb * Hb * Wb, (long)Cs * Hs * Ws);
 }
 
 static bool t3x3s2_ok(int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad) {
@@ -906,18 +917,10 @@ static int run_t3x3s2(const float *in, const float *W, const float *bias, float 
 
 // "transposed direction": in = small image [N][Cs][Hs][Ws], out = big image [N][Cb][Hb][Wb]
 //   out[n][m][h][w] = sum_{c,r,s} W(m,c,r,s) * in[n][c][(h+pad-r)/st][(w+pad-s)/st]   (divisible, in range)
-static int run_transposed_dir(const float *in, const float *W, const float *bias, float *out, int N, int Cb, int Hb,
-                              int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad, long sm, long sc, int act,
-                              float slope, void *ws, size_t ws_bytes, hipStream_t st) {
-#ifndef LSPS_NO_F3X3
-  // stride-1 transposed conv == forward 3x3 conv with flipped taps (dh = pad - r)
-  if (f3x3_ok(Cs, Hs, Ws, R, S, st_, pad) && Hb == Hs && Wb == Ws && (Cb >= 128 || wino4_ok(N, Cs, Hs, Cb)))
-    return run_f3x3(in, W, bias, out, N, Cs, Hs, Cb, sm, sc, true, act, slope, ws, ws_bytes, st);
-#endif
-#ifndef LSPS_NO_T3X3S2
-  if (t3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad))
-    return run_t3x3s2(in, W, bias, out, N, Cs, Hs, Ws, Cb, sm, sc, act, slope, ws, ws_bytes, st);
-#endif
+// the gather-GEMM path of the transposed direction (one launch per output parity class); xns / yns as in run_forward_generic
+static int run_transposed_generic(const float *in, const float *W, const float *bias, float *out, int N, int Cb, int Hb,
+                                  int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad, long sm, long sc, int act,
+                                  float slope, void *ws, size_t ws_bytes, hipStream_t st, long xns, long yns) {
   const int M = Cb;
   const int Mp = (int)align_up(M, 128);
   size_t used = 0;
@@ -958,6 +961,8 @@ static int run_transposed_dir(const float *in, const float *W, const float *bias
       p.Hx = Hs;
       p.Wx = Ws;
       p.HxWx = Hs * Ws;
+      p.xns = xns;
+      p.yns = yns;
       p.PH = PH;
       p.PW = PW;
       p.P = PH * PW;
@@ -984,6 +989,22 @@ static int run_transposed_dir(const float *in, const float *W, const float *bias
       if (rc) return rc;
     }
   return 0;
+}
+
+static int run_transposed_dir(const float *in, const float *W, const float *bias, float *out, int N, int Cb, int Hb,
+                              int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad, long sm, long sc, int act,
+                              float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+#ifndef LSPS_NO_F3X3
+  // stride-1 transposed conv == forward 3x3 conv with flipped taps (dh = pad - r)
+  if (f3x3_ok(Cs, Hs, Ws, R, S, st_, pad) && Hb == Hs && Wb == Ws && (Cb >= 128 || wino4_ok(N, Cs, Hs, Cb)))
+    return run_f3x3(in, W, bias, out, N, Cs, Hs, Cb, sm, sc, true, act, slope, ws, ws_bytes, st);
+#endif
+#ifndef LSPS_NO_T3X3S2
+  if (t3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad))
+    return run_t3x3s2(in, W, bias, out, N, Cs, Hs, Ws, Cb, sm, sc, act, slope, ws, ws_bytes, st);
+#endif
+  return run_transposed_generic(in, W, bias, out, N, Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad, sm, sc, act, slope, ws, ws_bytes, st,
+                                (long)Cs * Hs * Ws, (long)Cb * Hb * Wb);
 }
 
 static int wgrad_tile(int M, int J) { return (M <= 64 && J <= 64) ? 64 : 128; }
@@ -1286,19 +1307,10 @@ static int run_c1_wgrad(const float *small, const float *big, float *dW, int N, 
 }
 
 // dW[m][(c,t)] = sum_{n,p,q} small[n][m][p][q] * big[n][c][p*st-pad+r][q*st-pad+s]
-static int run_wgrad(const float *small, const float *big, float *dW, int N, int Cb, int Hb, int Wb, int Cs, int Hs,
-                     int Ws, int R, int S, int st_, int pad, void *ws, size_t ws_bytes, hipStream_t st) {
-#ifndef LSPS_NO_W3X3
-  if (w3x3_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad)) return run_w3x3(small, big, dW, N, Cb, Hb, Cs, ws, ws_bytes, st);
-#endif
-#ifndef LSPS_NO_C1
-  if (c1_wgrad_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad))
-    return run_c1_wgrad(small, big, dW, N, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad, ws, ws_bytes, st);
-#endif
-#ifndef LSPS_NO_W3X3S2
-  if (w3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad))
-    return run_w3x3s2(small, big, dW, N, Cb, Cs, Hs, Ws, ws, ws_bytes, st);
-#endif
+// the gather-GEMM weight gradient; sns / bns = floats between samples of small / big (dense: Cs*Hs*Ws and Cb*Hb*Wb)
+static int run_wgrad_generic(const float *small, const float *big, float *dW, int N, int Cb, int Hb, int Wb, int Cs, int Hs,
+                             int Ws, int R, int S, int st_, int pad, void *ws, size_t ws_bytes, hipStream_t st, long sns,
+                             long bns) {
   WParams p;
   memset(&p, 0, sizeof(p));
   TapList l;
@@ -1315,6 +1327,8 @@ static int run_wgrad(const float *small, const float *big, float *dW, int N, int
   p.Hx = Hb;
   p.Wx = Wb;
   p.HxWx = Hb * Wb;
+  p.sns = sns;
+  p.bns = bns;
   p.PH = Hs;
   p.PW = Ws;
   p.P = Hs * Ws;
@@ -1364,6 +1378,23 @@ static int run_wgrad(const float *small, const float *big, float *dW, int N, int
     LSPS_CHECK_LAUNCH("reduce_partials");
   }
   return 0;
+}
+
+static int run_wgrad(const float *small, const float *big, float *dW, int N, int Cb, int Hb, int Wb, int Cs, int Hs,
+                     int Ws, int R, int S, int st_, int pad, void *ws, size_t ws_bytes, hipStream_t st) {
+#ifndef LSPS_NO_W3X3
+  if (w3x3_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad)) return run_w3x3(small, big, dW, N, Cb, Hb, Cs, ws, ws_bytes, st);
+#endif
+#ifndef LSPS_NO_C1
+  if (c1_wgrad_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad))
+    return run_c1_wgrad(small, big, dW, N, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad, ws, ws_bytes, st);
+#endif
+#ifndef LSPS_NO_W3X3S2
+  if (w3x3s2_ok(Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad))
+    return run_w3x3s2(small, big, dW, N, Cb, Cs, Hs, Ws, ws, ws_bytes, st);
+#endif
+  return run_wgrad_generic(small, big, dW, N, Cb, Hb, Wb, Cs, Hs, Ws, R, S, st_, pad, ws, ws_bytes, st, (long)Cs * Hs * Ws,
+                           (long)Cb * Hb * Wb);
 }
 
 #define BIAS_WS_BYTES ((size_t)1 << 20)   // head of every conv workspace: [S<=64][C<=4096] bias partials
@@ -1625,6 +1656,63 @@ int lsps_conv2d_wgrad(const float *x, const float *dy, float *dw, float *db, int
   int rc = run_wgrad(dy, x, dw, N, C, H, W, K, P, Q, R, S, stride, pad, (char *)ws + BIAS_WS_BYTES,
                      ws_bytes - BIAS_WS_BYTES, (hipStream_t)stream);
   if (rc) return rc;
+  if (db) return run_bias_grad(dy, db, N, K, P * Q, ws, ws_bytes, (hipStream_t)stream);
+  return 0;
+}
+
+static bool grouped_args_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int groups) {
+  return groups > 0 && C % groups == 0 && K % groups == 0 && conv_args_ok(N, C / groups, H, W, K / groups, R, S, stride, pad);
+}
+
+int lsps_conv2d_grouped_fwd(const float *x, const float *w, const float *bias, float *y, int N, int C, int H, int W, int K,
+                            int R, int S, int stride, int pad, int groups, int act, float slope, void *ws, size_t ws_bytes,
+                            void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(x && w && y && ws, "conv2d_grouped_fwd: null pointer");
+  LSPS_CHECK_ARG(grouped_args_ok(N, C, H, W, K, R, S, stride, pad, groups), "conv2d_grouped_fwd: unsupported geometry");
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  LSPS_CHECK_ARG(P > 0 && Q > 0, "conv2d_grouped_fwd: empty output");
+  const int cg = C / groups, kg = K / groups;
+  for (int g = 0; g < groups; ++g) {
+    int rc = run_forward_generic(x + (long)g * cg * H * W, w + (long)g * kg * cg * R * S, bias ? bias + g * kg : nullptr,
+                                 y + (long)g * kg * P * Q, N, cg, H, W, kg, P, Q, R, S, stride, pad, (long)cg * R * S, (long)R * S,
+                                 act, slope, ws, ws_bytes, (hipStream_t)stream, (long)C * H * W, (long)K * P * Q);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int lsps_conv2d_grouped_dgrad(const float *dy, const float *w, float *dx, int N, int C, int H, int W, int K, int R, int S,
+                              int stride, int pad, int groups, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(dy && w && dx && ws, "conv2d_grouped_dgrad: null pointer");
+  LSPS_CHECK_ARG(grouped_args_ok(N, C, H, W, K, R, S, stride, pad, groups), "conv2d_grouped_dgrad: unsupported geometry");
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  const int cg = C / groups, kg = K / groups;
+  for (int g = 0; g < groups; ++g) {
+    // out channel m = c: W[k][c][r][s] -> sm = R*S ; reduction channel k -> sc = (C/G)*R*S
+    int rc = run_transposed_generic(dy + (long)g * kg * P * Q, w + (long)g * kg * cg * R * S, nullptr, dx + (long)g * cg * H * W, N,
+                                    cg, H, W, kg, P, Q, R, S, stride, pad, (long)R * S, (long)cg * R * S, LSPS_ACT_NONE, 1.f, ws,
+                                    ws_bytes, (hipStream_t)stream, (long)K * P * Q, (long)C * H * W);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int lsps_conv2d_grouped_wgrad(const float *x, const float *dy, float *dw, float *db, int N, int C, int H, int W, int K, int R,
+                              int S, int stride, int pad, int groups, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(x && dy && dw && ws, "conv2d_grouped_wgrad: null pointer");
+  LSPS_CHECK_ARG(grouped_args_ok(N, C, H, W, K, R, S, stride, pad, groups), "conv2d_grouped_wgrad: unsupported geometry");
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  LSPS_CHECK_ARG(ws_bytes >= BIAS_WS_BYTES, "conv2d_grouped_wgrad: workspace too small");
+  const int cg = C / groups, kg = K / groups;
+  for (int g = 0; g < groups; ++g) {
+    int rc = run_wgrad_generic(dy + (long)g * kg * P * Q, x + (long)g * cg * H * W, dw + (long)g * kg * cg * R * S, N, cg, H, W, kg,
+                               P, Q, R, S, stride, pad, (char *)ws + BIAS_WS_BYTES, ws_bytes - BIAS_WS_BYTES,
+                               (hipStream_t)stream, (long)K * P * Q, (long)C * H * W);
+    if (rc) return rc;
+  }
   if (db) return run_bias_grad(dy, db, N, K, P * Q, ws, ws_bytes, (hipStream_t)stream);
   return 0;
 }

@@ -225,6 +225,62 @@ def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, slope=LRELU_SLOPE):
     return _Conv2dFn.apply(x, w, b, int(stride), int(pad), int(act), float(slope))
 
 
+class _Conv2dGroupedFn(torch.autograd.Function):
+    """nn.Conv2d(..., groups=G) — the 3x3 conv of LeakyINSResNeXtBlock (common_net.py:116).  One launch per group on the
+    channel slices of the full tensors (lsps_conv2d_grouped_*): no slice copies, no concatenation."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, groups):
+        L = _lib.lib()
+        x, w = _c(x), _c(w)
+        N, C, H, W = x.shape
+        K, Cg, R, S = w.shape
+        assert C == Cg * groups and K % groups == 0, "channel / group mismatch"
+        P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
+        y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
+        ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, Cg, H, W, K // groups, R, S, stride, pad), x.device)
+        with profiler.span(2.0 * N * K * P * Q * Cg * R * S):
+            _lib.check(L.lsps_conv2d_grouped_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, C, H, W, K, R, S, stride,
+                                                 pad, groups, ACT_NONE, 1.0, ws, wsb, _lib.stream()), 'conv2d_grouped_fwd')
+        ctx.geom = (N, C, H, W, K, R, S, stride, pad, groups)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w = ctx.saved_tensors
+        N, C, H, W, K, R, S, stride, pad, groups = ctx.geom
+        dy = _c(dy)
+        st = _lib.stream()
+        flops = 2.0 * N * K * dy.shape[2] * dy.shape[3] * (C // groups) * R * S
+        ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C // groups, H, W, K // groups, R, S, stride, pad), x.device)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            with profiler.span(flops):
+                _lib.check(L.lsps_conv2d_grouped_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, C, H, W, K, R, S, stride, pad,
+                                                       groups, ws, wsb, st), 'conv2d_grouped_dgrad')
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = torch.empty(K, dtype=torch.float32, device=x.device)
+            with profiler.span(flops):
+                _lib.check(L.lsps_conv2d_grouped_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), N, C, H, W, K, R, S,
+                                                       stride, pad, groups, ws, wsb, st), 'conv2d_grouped_wgrad')
+        return dx, dw, db, None, None, None
+
+
+def conv2d_grouped(x, w, b=None, stride=1, pad=0, groups=1):
+    if groups == 1:
+        return conv2d(x, w, b, stride, pad)
+    if x.shape[0] == 0:
+        return _empty(x, (0, w.shape[0], conv_out_size(x.shape[2], w.shape[2], stride, pad),
+                          conv_out_size(x.shape[3], w.shape[3], stride, pad)), w, b)
+    return _Conv2dGroupedFn.apply(x, w, b, int(stride), int(pad), int(groups))
+
+
 # ------------------------------------------------------------------------------------------
 # ConvTranspose2d
 # ------------------------------------------------------------------------------------------

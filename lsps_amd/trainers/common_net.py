@@ -184,7 +184,7 @@ class LeakyReLULinear(nn.Module):
 # ---------------------------------------------------------------------------------------------
 class Conv2dGrouped(nn.Module):
     """Grouped 3x3 conv of the ResNeXt block (common_net.py:116): weight (n_out, n_in/groups, k, k).
-    Runs one lsps_conv2d launch per group on a contiguous channel slice (copy = glue; variant is unused)."""
+    ops.conv2d_grouped: one launch per group on the channel slices of the full tensors (lsps_conv2d_grouped_*)."""
 
     def __init__(self, n_in, n_out, kernel_size, stride=1, padding=0, groups=1, bias=True):
         super(Conv2dGrouped, self).__init__()
@@ -195,14 +195,8 @@ class Conv2dGrouped(nn.Module):
         _default_reset(self.weight, self.bias, (n_in // groups) * kernel_size * kernel_size)
 
     def forward(self, x, use_bias=True):
-        g = self.groups
-        cin, cout = x.size(1) // g, self.weight.size(0) // g
-        outs = []
-        for i in range(g):
-            b = self.bias[i * cout:(i + 1) * cout] if (use_bias and self.bias is not None) else None
-            outs.append(ops.conv2d(x[:, i * cin:(i + 1) * cin].contiguous(), self.weight[i * cout:(i + 1) * cout], b,
-                                   self.stride, self.padding))
-        return torch.cat(outs, 1)
+        b = self.bias if (use_bias and self.bias is not None) else None
+        return ops.conv2d_grouped(x, self.weight, b, self.stride, self.padding, self.groups)
 
 
 class LeakyINSResNeXtBlock(nn.Module):

@@ -106,6 +106,40 @@ def test_conv2d_fwd_dgrad_wgrad(case, act):
     assert errs['y'] < 1e-4 and errs['dx'] < tol and errs['dw'] < 2 * tol and errs['db'] < 2 * tol, errs
 
 
+# (N, C, H, W, K, R, stride, pad, groups)
+GROUPED_CASES = [
+    (2, 512, 32, 32, 512, 3, 1, 1, 8),   # LeakyINSResNeXtBlock at full width: k * inplanes = 512, cardinality 8 (common_net.py:116)
+    (3, 16, 32, 32, 16, 3, 1, 1, 8),     # the tiny-width golden geometry (2 channels per group)
+    (2, 12, 9, 7, 18, 3, 2, 1, 3),       # ragged, stride 2, C/G != K/G
+    (1, 96, 8, 8, 192, 1, 1, 0, 2),      # 1x1 grouped, K/G = 96
+    (2, 8, 6, 6, 8, 3, 1, 1, 1),         # groups = 1 falls through to the dense op
+]
+
+
+@pytest.mark.parametrize("case", GROUPED_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("bias", [True, False])
+def test_conv2d_grouped_fwd_dgrad_wgrad(case, bias):
+    """lsps_conv2d_grouped_{fwd,dgrad,wgrad} (channel-slice launches, no copies) against F.conv2d(groups=G)."""
+    _need_gpu()
+    from lsps_amd import ops
+    N, C, H, W, K, R, st, pad, G = case
+    x = _rand(N, C, H, W, seed=1).requires_grad_(True)
+    w = _rand(K, C // G, R, R, seed=2, scale=0.1).requires_grad_(True)
+    b = _rand(K, seed=3, scale=0.1).requires_grad_(True) if bias else None
+    y_ref = F.conv2d(x, w, b, stride=st, padding=pad, groups=G)
+    gy = _rand(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+    xd, wd = (t.detach().cuda().requires_grad_(True) for t in (x, w))
+    bd = b.detach().cuda().requires_grad_(True) if bias else None
+    y = ops.conv2d_grouped(xd, wd, bd, st, pad, G)
+    y.backward(gy.cuda())
+    assert y.shape == y_ref.shape
+    errs = dict(y=_rel(y, y_ref), dx=_rel(xd.grad, x.grad), dw=_rel(wd.grad, w.grad))
+    if bias:
+        errs['db'] = _rel(bd.grad, b.grad)
+    assert all(e < 2e-4 for e in errs.values()), errs
+
+
 # (N, Ci, H, W, Co, R, stride, pad, outpad)
 CONVT_CASES = [
     (2, 256, 32, 32, 128, 3, 2, 1, 1),   # gen up 1
