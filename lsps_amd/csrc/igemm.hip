@@ -592,7 +592,9 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
 #define FS2_DEFAULT_CC 4
 static bool f3x3s2_ok(int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad) {
   return R == 3 && S == 3 && st_ == 2 && pad == 1 && Hb == 2 * Hs && Wb == 2 * Ws && (Ws % 32) == 0 && (Hs % 4) == 0 &&
-         (Cb % F3_CC) == 0 && Cs >= 128 && (long)F3_CC * Hb * Wb < (1L << 31);
+         (Cb % F3_CC) == 0 && Cs >= 128 &&
+         // one image / the packed weights are addressed by 32-bit byte offsets off a buffer descriptor
+         (long)Cb * Hb * Wb * 4 < (1L << 31) && (long)Cb * 9 * align_up(Cs, 128) * 4 < (1L << 31);
 }
 
 // in [N][Cb][2Hs][2Ws] -> out [N][M][Hs][Ws]
@@ -810,7 +812,8 @@ static int run_forward_dir(const float *in, const float *W, const float *bias, f
 static bool t3x3s2_ok(int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad) {
   const int tr = Cb >= 128 ? 4 : 8;
   return R == 3 && S == 3 && st_ == 2 && pad == 1 && Hb == 2 * Hs && Wb == 2 * Ws && (Ws % 32) == 0 && (Hs % tr) == 0 &&
-         (Cs % TS_CC) == 0 && Cb >= 64;
+         (Cs % TS_CC) == 0 && Cb >= 64 &&
+         (long)Cs * Hs * Ws * 4 < (1L << 31) && (long)Cs * 9 * align_up(Cb, 128) * 4 < (1L << 31);   // 32-bit descriptor offsets
 }
 
 // in [N][Cs][Hs][Ws] -> out [N][M][2Hs][2Ws]
@@ -1191,7 +1194,7 @@ static int run_w3x3(const float *dy, const float *x, float *dW, int N, int C, in
 
 static bool w3x3s2_ok(int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad) {
   return R == 3 && S == 3 && st_ == 2 && pad == 1 && Hb == 2 * Hs && Wb == 2 * Ws && (Ws % 32) == 0 && (Cb % 64) == 0 &&
-         (Cs % 128) == 0;
+         (Cs % 128) == 0 && (long)64 * Hb * Wb * 4 < (1L << 31);   // 64 big channels within a 32-bit lane offset
 }
 
 static int w3x3s2_splits(int M, int C, int nchunks) {
