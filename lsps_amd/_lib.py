@@ -124,19 +124,28 @@ def stream():
 
 
 _workspaces = {}
+_retired = []          # buffers outgrown DURING a stream capture: the captured kernels keep their addresses
 
 
 def workspace(nbytes, device):
     """One scratch buffer per (device, stream), grown on demand: ops on one stream run in order, so they share it; a second
-    stream (the trainer overlaps independent branches of a step) gets its own."""
+    stream (the trainer overlaps independent branches of a step, a hipGraph capture runs on its own stream) gets its own.
+    While the stream is being captured nothing may synchronise: the outgrown buffer is kept alive instead (its address is
+    baked into the kernels captured so far) and a fresh stream starts at the size of the largest buffer of the device."""
     import torch
     cur = torch.cuda.current_stream(device)
     key = (device.type, device.index, cur.cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
+        capturing = torch.cuda.is_current_stream_capturing()
         if buf is not None:
-            cur.synchronize()                           # outstanding users of the old buffer
+            if capturing:
+                _retired.append(buf)
+            else:
+                cur.synchronize()                       # outstanding users of the old buffer
         nbytes = max(int(nbytes * 1.25), 1 << 20)
+        if buf is None:
+            nbytes = max([nbytes] + [b.numel() for k, b in _workspaces.items() if k[:2] == key[:2]])
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf.data_ptr(), buf.numel()

@@ -165,6 +165,34 @@ def test_update_steps_are_bitwise_deterministic():
             assert np.array_equal(outs[0][net][k], outs[1][net][k]), k
 
 
+def test_workspace_grows_inside_a_graph_capture():
+    """The scratch buffer of a stream may have to grow while that stream is being captured (full-width nets at bs=8: the
+    reduction-split partials of the residual convs need more than the first conv of the step): no synchronisation is allowed
+    there, the outgrown buffer must stay alive for the kernels captured so far, and the replay must still be right."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from lsps_amd import _lib, ops
+    dev = torch.device('cuda', 0)
+    x = torch.randn(2, 8, 16, 32, device=dev)
+    w1 = torch.randn(8, 8, 3, 3, device=dev) * 0.1
+    big = torch.randn(2, 64, 32, 32, device=dev)
+    w2 = torch.randn(64, 64, 3, 3, device=dev) * 0.1
+    ref1, ref2 = ops.conv2d(x, w1, None, 1, 1), ops.conv2d(big, w2, None, 1, 1)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cap = torch.cuda.current_stream(dev).cuda_stream
+        p0, n0 = _lib.workspace(1 << 20, dev)
+        y1 = ops.conv2d(x, w1, None, 1, 1)
+        p1, n1 = _lib.workspace(n0 + (32 << 20), dev)    # grows during capture
+        assert n1 >= n0 + (32 << 20) and p1 != p0
+        y2 = ops.conv2d(big, w2, None, 1, 1)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y1, ref1) and torch.equal(y2, ref2)
+    assert any(k[2] == cap for k in _lib._workspaces)
+
+
 def test_hip_graph_replay_matches_eager_bitwise():
     """`use_graphs(True)`: per call signature the first call is eager, the second is captured into a hipGraph, later ones
     replay it.  Three rounds of dis_update + gen_update + post_update(mode 3) on DIFFERENT inputs / injected noise each
