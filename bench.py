@@ -296,12 +296,32 @@ def main():
             ops.set_math_mode('bf16')
             t_bf16 = timed(pretrain_step, 2)
             ops.set_math_mode('f32')
+        # the reference's own shipped batch size (exps/*.yaml `batch_size: 32`), eager and replayed from hipGraphs
+        t_ref_bs = t_ref_bs_graph = None
+        ref_bs = 32
+        if args.dtype == 'f32' and args.batch >= ref_bs:
+            b32 = {k: v[:ref_bs].contiguous() for k, v in b.items()}
+
+            def step32():
+                tr.dis_update(b32['xa'], b32['la'], b32['xb'], b32['lb'], b32['ca'], b32['cb'], hp)
+                tr.gen_update(b32['xa'], b32['la'], b32['xb'], b32['lb'], hp)
+            t_ref_bs = timed(step32, 5)
+            tr.use_graphs(True)
+            step32()                    # captures (the eager timing above was the warm-up of these signatures)
+            t_ref_bs_graph = timed(step32, 10)
+            tr.use_graphs(False)
         extra = {'estimate3_step_bs%d' % args.batch: {'steps_per_s': 1.0 / t_est, 'ms_per_step': 1e3 * t_est,
                                                        'hip_graph': True, 'eager_ms_per_step': 1e3 * t_est_eager,
                                                        'algorithmic_tflop_per_step': 0.579 * args.batch / 128.0,
                                                        'mfma_floor_ms': 0.579 * args.batch / 128.0 / F32_MFMA_PEAK_TFLOPS * 1e3},
                  'gen_forward_bs%d' % args.batch: {'calls_per_s': 1.0 / t_fwd, 'ms_per_call': 1e3 * t_fwd,
                                                    'tflops': 7.76 * args.batch / 128.0 / t_fwd}}
+        if t_ref_bs:
+            extra['pretrain_step_bs%d_reference_yaml_batch' % ref_bs] = {
+                'ms_per_step': 1e3 * t_ref_bs, 'steps_per_s': 1.0 / t_ref_bs, 'hip_graph_ms_per_step': 1e3 * t_ref_bs_graph,
+                'hip_graph_steps_per_s': 1.0 / t_ref_bs_graph,
+                'note': 'same pretrain step at the batch size the shipped exps/*.yaml train with (32 per domain); '
+                        'LSPSTrainer.use_graphs (depth_train.py --graphs) replays it from hipGraphs'}
         if t_bf16:
             extra['pretrain_step_bf16_mfma_bs%d' % args.batch] = {
                 'steps_per_s': 1.0 / t_bf16, 'ms_per_step': 1e3 * t_bf16,

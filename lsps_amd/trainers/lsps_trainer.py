@@ -199,6 +199,7 @@ class LSPSTrainer(nn.Module):
         if not on:
             self._graphs.clear()
             self._graph_seen.clear()
+            self._graph_pool = None         # its graphs are gone: a later use_graphs(True) starts a fresh memory pool
         return self
 
     def _graphed(self, name, eager, args, kwargs):

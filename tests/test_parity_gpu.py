@@ -195,7 +195,7 @@ def test_workspace_grows_inside_a_graph_capture():
 
 def test_hip_graph_replay_matches_eager_bitwise():
     """`use_graphs(True)`: per call signature the first call is eager, the second is captured into a hipGraph, later ones
-    replay it.  Three rounds of dis_update + gen_update + post_update(mode 3) on DIFFERENT inputs / injected noise each
+    replay it.  Five rounds of dis_update + gen_update + post_update(mode 3) on DIFFERENT inputs / injected noise each
     round (so a replay that read stale static buffers would show) give bit-identical loss scalars and weights to the eager
     trainer, and the graphs really were replayed."""
     A = _adapter()
@@ -209,7 +209,10 @@ def test_hip_graph_replay_matches_eager_bitwise():
         tr.use_graphs(graphed)
         A.set_train(tr, True)
         trace = []
-        for rnd in range(3):
+        for rnd in range(5):
+            if graphed and rnd == 3:            # graphs off and on again: the old graphs and their memory pool are gone,
+                tr.use_graphs(False)            # round 3 runs eagerly, round 4 captures into a fresh pool
+                tr.use_graphs(True)
             b = cases.make_inputs(4)
             b = {k: (v * (1.0 - 0.1 * rnd)).astype(v.dtype) if k in ('xa', 'xb') else v for k, v in b.items()}
             A.dis_update(tr, b, hp, cases.noise(lat2, 10 + rnd))
