@@ -22,5 +22,5 @@ for f in sys.argv[1:]:
     tot = 0
     for k, v in sorted(r['per_kernel'].items(), key=lambda kv: -kv[1]['total_ms']):
         tot += v['total_ms']
-        print('     %-28s calls %4d  %8.1f ms/step  avg %.3f  %.1f TF' % (k, v['calls'], v['total_ms'] / j['steps'], v['avg_ms'], v['tflops']))
-    print('     sum of conv spans per step %.1f ms' % (tot / j['steps']))
+        print('     %-28s calls %4d  %8.1f ms/step  avg %.3f  %.1f TF' % (k, v['calls'], v['total_ms'] / r.get('per_kernel_steps', j['steps']), v['avg_ms'], v['tflops']))
+    print('     sum of conv spans per step %.1f ms' % (tot / r.get('per_kernel_steps', j['steps'])))
