@@ -144,6 +144,83 @@ def test_full_batch_properties():
         assert float((post_big[40:44] - post_small).abs().max()) <= 1e-4 * float(post_big.abs().max())
 
 
+def test_full_size_step_gradients_equal_the_mean_of_chunk_gradients():
+    """BASELINE's full size (bs=128 per domain, full width), backward included: every loss of dis_update / gen_update is a
+    batch mean and InstanceNorm has no batch statistics, so the gradients of the 128-sample step are the MEAN of the gradients
+    of its sixteen 8-sample chunks (same weights, the chunks' rows of the same noise), and so are the loss scalars.  The full
+    step runs the default dispatch of the bench (F(4x4,3x3) kernels with the fused norms, XCD-aware mappings, the stride-2
+    kernels at full grids, the batch-innermost trunk); the chunks run the small-grid paths that the reference's golden
+    vectors pin at N = 2 ... 8: a wrong dgrad / wgrad / norm-backward at full size shows as a broken mean."""
+    A = _adapter()
+    hp = cases.hp_for('full')
+    sds = cases.make_weights(hp, lsps_ref)
+    n, ch = 128, 8
+    b = cases.make_inputs(n)
+    lat2, lat1 = cases.latent_shape(hp, 2 * n), cases.latent_shape(hp, n)
+    nz_d = cases.noise(lat2, 11)
+    nz_g = (cases.noise(lat2, 21), cases.noise(lat1, 31), cases.noise(lat1, 41))
+
+    def rows2(z, j):                     # rows of chunk j of a [2n] tensor laid out (domain a | domain b)
+        return np.concatenate((z[j * ch:(j + 1) * ch], z[n + j * ch:n + (j + 1) * ch]), 0)
+
+    def reload(tr):
+        for net in ('gen', 'dis', 'vae', 'map'):
+            getattr(tr, net).load_state_dict({k: torch.as_tensor(v) for k, v in sds[net].items()})
+
+    tr = A.make_trainer(hp, sds)
+    A.set_train(tr, True)
+    A.dis_update(tr, b, hp, nz_d)
+    full = dict(dis=A.grads(tr, 'dis'), dis_s=A.scalars(tr))
+    reload(tr)
+    A.gen_update(tr, b, hp, nz_g)
+    full.update(gen=A.grads(tr, 'gen'), gen_s=A.scalars(tr))
+    acc = dict(dis=None, gen=None, dis_s=None, gen_s=None)
+
+    def add(key, val):
+        if acc[key] is None:
+            acc[key] = {k: np.asarray(v, np.float64).copy() for k, v in val.items() if v is not None}
+        else:
+            for k in acc[key]:
+                acc[key][k] += val[k]
+
+    for j in range(n // ch):
+        bj = {k: v[j * ch:(j + 1) * ch] for k, v in b.items()}
+        reload(tr)
+        A.dis_update(tr, bj, hp, rows2(nz_d, j))
+        add('dis', A.grads(tr, 'dis'))
+        add('dis_s', A.scalars(tr))
+        reload(tr)
+        A.gen_update(tr, bj, hp, (rows2(nz_g[0], j), nz_g[1][j * ch:(j + 1) * ch], nz_g[2][j * ch:(j + 1) * ch]))
+        add('gen', A.grads(tr, 'gen'))
+        add('gen_s', A.scalars(tr))
+    k_chunks = float(n // ch)
+    worst = {}
+    errs = []
+    for net in ('dis', 'gen'):
+        for name, g in full[net].items():
+            if g is None or name not in acc[net]:
+                continue
+            mean = acc[net][name] / k_chunks
+            scale = max(float(np.abs(mean).max()), 1e-12)
+            err = float(np.abs(np.asarray(g, np.float64) - mean).max()) / scale
+            worst[net] = max(worst.get(net, 0.0), err)
+            errs.append((err, net, name))
+    # Tolerance: the two sides differ by fp32 round-off of different algorithms (F(4x4,3x3) vs direct / F(2x2,3x3): ~1e-5 per
+    # conv, 28 convs deep) and the gradients are sums of signed terms that cancel (the feature-matching L1 loss feeds sign()
+    # into the last trunk layers: measured 1.5e-3 of the tensor's abs-max there, median over all tensors 1e-4).  A wrong
+    # kernel is off by O(0.1 .. 1).  The golden step-gradient bound of tests/golden/cases.py is 2e-2.
+    errs.sort(reverse=True)
+    assert errs[0][0] <= 5e-3, errs[:5]
+    assert errs[len(errs) // 10][0] <= 5e-4, errs[len(errs) // 10]          # 90 % of the tensors
+    for key, names in (('dis_s', ('dis_loss', 'dis_ad_loss', 'dis_feat_loss', 'dis_true_acc', 'dis_fake_acc')),
+                       ('gen_s', ('gen_total_loss',))):
+        for name in names:
+            if name in full[key]:
+                m = acc[key][name] / k_chunks
+                assert abs(float(full[key][name]) - float(m)) <= 1e-3 * max(abs(float(m)), 1e-6), (name, full[key][name], m)
+    assert worst['dis'] > 0.0 and worst['gen'] > 0.0          # different kernels really ran (not the same bits twice)
+
+
 def test_update_steps_are_bitwise_deterministic():
     """No atomics anywhere on the path (split reductions are two-stage): the same step from the same state
     gives bit-identical losses and weights."""
