@@ -1100,7 +1100,9 @@ static int run_wino_w(const float *dy, const float *x, float *dW, int N, int C, 
 // F(4x4,3x3) form of the same weight gradient (conv_wino4w.h): one 256-thread workgroup per CU owns a 64 k x 32 c block of
 // all 36 positions; the tile rows (4 image rows each) are split over 256 / blocks workgroups, a multiple of 8 where
 // possible (one split per XCD group).  LSPS_WINO4W=0 keeps the F(2x2,3x3) kernel (A/B comparisons).
-#define W4W_DEFAULT_WAVES 4
+// 8 waves (KH = 1: two waves per SIMD, 9 accumulator tiles each) measured 6 - 7 % faster than 4 (KH = 2) in the step at every
+// batch size from 32 to 256 per domain (round 2, profiles/r2t_wino4w_waves.txt)
+#define W4W_DEFAULT_WAVES 8
 static int wino4_w_splits(int M, int C, int ntr) {
   int s = 256 / ((M / 64) * (C / 32));
   if (s > ntr) s = ntr;
