@@ -23,8 +23,9 @@ namespace lsps {
 // of 3x3: wp = 2 bi + bj) x 2 halves of the image's 64 tiles (wt: tile rows 4wt .. 4wt+3).  A wave holds 9 accumulator
 // tiles (144 registers, two waves per SIMD).  MFMA operand layout (32x32x2): lane l supplies A[k = l%32][c = l/32] and
 // B[c = l/32][tile = l%32], so lane l transforms ONE tile of ONE channel per k-step: it reads the 5 raw rows x 6 columns
-// its position block needs (ds_read_b128 + ds_read_b64 per row, row stride 40 floats: conflict-free b128), forms the 3
-// rows of B^T d (pass 1, one column per MFMA gap) and the 3 columns it owns (pass 2): 48 VALU ops per 9 MFMAs.
+// its position block needs (ds_read_b128 + ds_read_b64 per row, row stride 40 floats: conflict-free b128), turns each row
+// into the 3 columns it owns as the row arrives (pass A, one row per MFMA gap) and combines the rows (pass B): 48 VALU ops
+// per 9 MFMAs.
 // The transform of k-step s+1 is issued between the MFMAs of k-step s (order pinned with sched_barrier): a 64-cycle f32
 // MFMA leaves ~10 free issue slots, plain (not packed) f32 VALU ops are the cheap fillers (MI355X_MICROARCH.md).
 // The A operands (U) go L2 -> registers, 9 floats per lane per k-step (2 x 16 B + 4 B, coalesced), one k-step ahead.
@@ -157,12 +158,12 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
   const unsigned s_off = (unsigned)((tid >> 8) * HW + ((tid >> 3) & 31) * 32 + (tid & 7) * 4) * 4u;
   f32x4 sreg[NSEG];
   auto load_seg = [&](int chunk, int i) {
-#ifndef W4_ABL_NOSTAGE
+#if !defined(W4_ABL_NOSTAGE) && !defined(W4_ABL_NOSTLD)
     sreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, s_off, (chunk * W4_RC + 2 * i) * HW * 4, 0));
 #endif
   };
   auto store_seg = [&](float *buf, int i) {
-#ifndef W4_ABL_NOSTAGE
+#if !defined(W4_ABL_NOSTAGE) && !defined(W4_ABL_NOSTST)
     float *d = buf + s_lds + 2 * i * W4_CH;
     d[0] = sreg[i][0];
     *reinterpret_cast<f32x2 *>(d + 1) = f32x2{sreg[i][1], sreg[i][2]};
@@ -210,65 +211,30 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
     const float *rd = w4_lds + half * W4_CH + (16 * wt + 4 * tr + BI) * W4_LDW + 4 * tc;
     f32x4 r4[5];
     f32x2 r2[5];
-#ifdef W4_STREAM_P2
-    float T[3];
-#else
-    float P[3][5];
+    float Q[5][3];
+    // V = B^T d B row-first: pass A turns raw row l (six columns, ONE ds_read_b128 + ds_read_b64) into the block's three
+    // columns Q[l][0..2] = sum_x B^T[3 BJ + j][x] d[l][x] as soon as that row has arrived; pass B combines the five rows per
+    // column, V[3 BI + i][3 BJ + j] = sum_l B^T[3 BI + i][l] Q[l][j].  Same 48 ops per 9 MFMAs as column-first, but the ten
+    // LDS reads of a k-step are no longer needed all at once: one row per MFMA gap, consumed two gaps later.  (Column-first
+    // issued them as two bursts of five that all eight waves of the workgroup - in lockstep after every barrier - sent at the
+    // same moment; without the reads that kernel ran 25 % faster.)
+    auto read_row = [&](int bo, int g, int l) {
+#ifndef W4_ABL_NOLDS
+      r4[l] = *(lp4)(rd + bo + 2 * g * W4_CH + l * W4_LDW);
+      r2[l] = *(lp2)(rd + bo + 2 * g * W4_CH + l * W4_LDW + 4);
 #endif
-    // raw rows of one k-step: channel pair g of row buffer `bo` (both compile-time: immediate offsets)
-    auto read_raw = [&](int bo, int g) {
-#ifdef W4_ABL_NOLDS
-      return;
-#endif
-#pragma unroll
-      for (int l = 0; l < 5; ++l) {
-        r4[l] = *(lp4)(rd + bo + 2 * g * W4_CH + l * W4_LDW);
-        r2[l] = *(lp2)(rd + bo + 2 * g * W4_CH + l * W4_LDW + 4);
-      }
     };
     auto col = [&](int l, int x) -> float { return x < 4 ? r4[l][x] : r2[l][x - 4]; };
-    // pass 1: the block's three rows of B^T d for column x = BJ + ci of the 5 columns it needs
-    auto pass1 = [&](int ci) {
-#ifdef W4_ABL_NOXF
-      return;
-#endif
-      const int x = BJ + ci;
-#ifdef W4_STREAM_P2
-      w4_xf<BI>(col(0, x), col(1, x), col(2, x), col(3, x), col(4, x), T[0], T[1], T[2]);
-#else
-      w4_xf<BI>(col(0, x), col(1, x), col(2, x), col(3, x), col(4, x), P[0][ci], P[1][ci], P[2][ci]);
+    auto passA = [&](int l) {
+#ifndef W4_ABL_NOXF
+      w4_xf<BJ>(col(l, BJ), col(l, BJ + 1), col(l, BJ + 2), col(l, BJ + 3), col(l, BJ + 4), Q[l][0], Q[l][1], Q[l][2]);
 #endif
     };
-#ifdef W4_STREAM_P2
-    // pass 2, streamed (experiment): column ci's contribution to the block's three columns of V; 11 FMAs per row instead
-    // of the factored 6 ops, but the 3 x 5 intermediate is never kept (12 registers less)
-    auto pass2s = [&](int ci) {
-#ifdef W4_ABL_NOXF
-      return;
+    auto passB = [&](int j) {
+#ifndef W4_ABL_NOXF
+      w4_xf<BI>(Q[0][j], Q[1][j], Q[2][j], Q[3][j], Q[4][j], vn[j], vn[3 + j], vn[6 + j]);
 #endif
-      constexpr float K0[3][5] = {{4.f, 0.f, -5.f, 0.f, 1.f}, {0.f, -4.f, -4.f, 1.f, 1.f}, {0.f, 4.f, -4.f, -1.f, 1.f}};
-      constexpr float K1[3][5] = {{-2.f, -1.f, 2.f, 1.f, 0.f}, {2.f, -1.f, -2.f, 1.f, 0.f}, {4.f, 0.f, -5.f, 0.f, 1.f}};
-#pragma unroll
-      for (int il = 0; il < 3; ++il)
-#pragma unroll
-        for (int jl = 0; jl < 3; ++jl) {
-          const float k = BJ ? K1[jl][ci] : K0[jl][ci];
-          bool first = true;
-#pragma unroll
-          for (int cj = 0; cj < 5; ++cj)
-            if (cj < ci && (BJ ? K1[jl][cj] : K0[jl][cj]) != 0.f) first = false;
-          if (k != 0.f) vn[il * 3 + jl] = first ? k * T[il] : fmaf(k, T[il], vn[il * 3 + jl]);
-        }
     };
-#else
-    // pass 2: the block's three columns of row il
-    auto pass2 = [&](int il) {
-#ifdef W4_ABL_NOXF
-      return;
-#endif
-      w4_xf<BJ>(P[il][0], P[il][1], P[il][2], P[il][3], P[il][4], vn[il * 3], vn[il * 3 + 1], vn[il * 3 + 2]);
-    };
-#endif
     auto mma = [&](int q) {
       const float a = q < 4 ? ac8[0][q] : (q < 8 ? ac8[1][q - 4] : ac1);
       acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vc[q], acc[q], 0, 0, 0);
@@ -280,67 +246,52 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
       ac8[1] = an8[1];
       ac1 = an1;
     };
-    // one k-step: 9 MFMAs on (ac, vc); between them the transform of the NEXT k-step's raw rows (buffer bo, pair g) -> vn
+    auto load_u_part = [&](int step, int part) {
+#ifndef W4_ABL_NOU
+      const int so = step * (W4_UREC * 4);                       // uniform
+      if (part == 0) an8[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, u8_off, so, 0));
+      if (part == 1) an8[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, u8_off + 16, so, 0));
+      if (part == 2) an1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, u1_off, so, 0));
+#endif
+    };
     // One k-step: 9 MFMAs on (ac, vc); the gaps between them carry the transform of the NEXT k-step's raw rows (row buffer
-    // bo, channel pair g) into vn, that step's U loads, and a share of the row staging (STAGE 1: this thread's four
-    // segments of chunk `sc` go from registers into row buffer `sb`, one per gap; STAGE 2: the loads of chunk `sc`, one per
-    // gap).  Nothing is issued in bursts: an in-order wave that queues ten LDS reads or twelve LDS writes back to back
-    // stalls on the LDS / TA queues with the matrix pipe idle behind it, and the eight waves of a workgroup reach such
-    // points together (measured: bursts -> spread = see DESIGN).  The step opens with an MFMA and only one short pass-2
-    // row trails the last one.
+    // bo, channel pair g) into vn, that step's U loads (one per gap, right at the start: they have the whole k-step to
+    // arrive), and a share of the row staging (STAGE 1: this thread's four segments of chunk `sc` go from registers into row
+    // buffer `sb`; STAGE 2: the loads of chunk `sc`), one per gap.  Nothing is issued in bursts: an in-order wave that
+    // queues ten LDS reads or twelve LDS writes back to back stalls on the LDS / TA queues with the matrix pipe idle behind
+    // it, and the eight waves of a workgroup reach such points together.
     auto step = [&](int bo, int g, int ustep, auto stage_c, int sb, int sc) {
       constexpr int STAGE = decltype(stage_c)::value;
-      __builtin_amdgcn_sched_barrier(0);
-      mma(0);
-      __builtin_amdgcn_sched_barrier(0);
-#ifndef W4_ABL_NOLDS
+      auto stage = [&](int i) {
+        if (STAGE == 1) store_seg(w4_lds + sb, i);
+        if (STAGE == 2) load_seg(sc, i);
+      };
 #pragma unroll
-      for (int l = 0; l < 5; ++l) r4[l] = *(lp4)(rd + bo + 2 * g * W4_CH + l * W4_LDW);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      mma(1);
-      __builtin_amdgcn_sched_barrier(0);
-#ifndef W4_ABL_NOLDS
-#pragma unroll
-      for (int l = 0; l < 5; ++l) r2[l] = *(lp2)(rd + bo + 2 * g * W4_CH + l * W4_LDW + 4);
-#endif
-      load_u(ustep);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ci = 0; ci < 5; ++ci) {
-        mma(2 + ci);
+      for (int q = 0; q < 9; ++q) {
         __builtin_amdgcn_sched_barrier(0);
-        pass1(ci);
-        if (STAGE == 1 && ci >= 1) store_seg(w4_lds + sb, ci - 1);
-        if (STAGE == 2 && ci >= 1) load_seg(sc, ci - 1);
+        mma(q);
         __builtin_amdgcn_sched_barrier(0);
+        if (q < 5) read_row(bo, g, q);
+        if (q < 3) load_u_part(ustep, q);
+        if (q >= 2 && q < 7) passA(q - 2);
+        if (q >= 3 && q < 7) stage(q - 3);
+        if (q == 7) {
+          passB(0);
+          passB(1);
+        }
+        if (q == 8) passB(2);
       }
-      mma(7);
-      __builtin_amdgcn_sched_barrier(0);
-      pass2(0);
-      pass2(1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(8);
-      __builtin_amdgcn_sched_barrier(0);
-      pass2(2);
       __builtin_amdgcn_sched_barrier(0);
       rotate();
     };
     // V(0): transform of k-step 0 (no MFMAs yet)
-    read_raw(0, 0);
-#ifdef W4_STREAM_P2
 #pragma unroll
-    for (int ci = 0; ci < 5; ++ci) {
-      pass1(ci);
-      pass2s(ci);
-    }
-#else
+    for (int l = 0; l < 5; ++l) read_row(0, 0, l);
 #pragma unroll
-    for (int ci = 0; ci < 5; ++ci) pass1(ci);
-    pass2(0);
-    pass2(1);
-    pass2(2);
-#endif
+    for (int l = 0; l < 5; ++l) passA(l);
+    passB(0);
+    passB(1);
+    passB(2);
     rotate();                                    // (ac <- U(0), loaded in the prologue)
     // chunk c (k-steps 4c .. 4c+3) lives in buffer c & 1.  K-step s transforms k-step s+1: the first three steps of a
     // chunk stay inside it (channel pairs 1..3); then chunk c+1 is stored and published and chunk c+2 requested; the
