@@ -33,6 +33,9 @@ namespace lsps {
 // + residual) happen in the epilogue on registers: the pre-norm tensor never reaches HBM and the separate
 // read-modify-write pass of inorm_fwd_kernel disappears (reference: common_net.py:166-171, 177-181).
 // -------------------------------------------------------------------------------------------
+#ifndef W4_AHEAD
+#define W4_AHEAD 2                       // MFMA gaps between the LDS read of a raw row and its pass A (see step())
+#endif
 #define W4_LDW 40                        // floats per staged row: [halo][32 pixels][halo][6 pad]; 4 rows = 32 banks (mod 64)
 #define W4_ROWS 34                       // 32 image rows + 2 halo rows
 #define W4_CH (W4_ROWS * W4_LDW)         // floats per staged channel
@@ -273,12 +276,14 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
         __builtin_amdgcn_sched_barrier(0);
         if (q < 5) read_row(bo, g, q);
         if (q < 3) load_u_part(ustep, q);
-        if (q >= 2 && q < 7) passA(q - 2);
+        if (q >= W4_AHEAD && q < 5 + W4_AHEAD) passA(q - W4_AHEAD);
         if (q >= 3 && q < 7) stage(q - 3);
-        if (q == 7) {
+        if (W4_AHEAD <= 2 && q == 7) {
           passB(0);
           passB(1);
         }
+        if (W4_AHEAD == 3 && q == 7) passB(0);
+        if (W4_AHEAD == 3 && q == 8) passB(1);
         if (q == 8) passB(2);
       }
       __builtin_amdgcn_sched_barrier(0);
