@@ -361,7 +361,7 @@ def main():
         roofline = None
         traffic = None
         traffic_file = None
-        for tf in ('r2_traffic.json', 'r1_traffic.json'):   # PMC traffic is collected offline (rocprofv3 --pmc cannot run inside the timed bench)
+        for tf in ('r2t_traffic.json', 'r2_traffic.json', 'r1_traffic.json'):   # PMC traffic is collected offline (rocprofv3 --pmc cannot run inside the timed bench)
             try:
                 with open(os.path.join(REPO, 'profiles', tf)) as f:
                     tj = json.load(f).get(dom_name)
