@@ -106,6 +106,55 @@ def test_conv2d_fwd_dgrad_wgrad(case, act):
     assert errs['y'] < 1e-4 and errs['dx'] < tol and errs['dw'] < 2 * tol and errs['db'] < 2 * tol, errs
 
 
+def test_stride2_kernels_seeded_random_shapes():
+    """3x3 / stride 2 / pad 1 Conv2d and ConvTranspose2d (forward, dgrad, wgrad) on seeded random geometries around the
+    dispatch boundaries of the specialised stride-2 kernels (1 ... 5 images, 8 ... 144 channels, 1 ... 4 column blocks, output
+    heights that are / are not multiples of the row tiles): the buffer-descriptor staging (out-of-range offsets for the
+    padding, wave-uniform ragged rounds, the wgrad's chunk cursor across rows and images) against torch."""
+    _need_gpu()
+    import random
+    from lsps_amd import ops
+    rng = random.Random(20260929)
+    seen = set()
+    for trial in range(14):
+        N = rng.choice([1, 2, 3, 5])
+        C = rng.choice([8, 16, 24, 64, 72, 128, 144])
+        K = rng.choice([64, 128, 192, 256])
+        Hs = rng.choice([4, 8, 12, 16, 20])
+        Ws = rng.choice([32, 64, 96, 128])
+        if N * C * 4 * Hs * Ws > 12e6:
+            continue
+        x = _rand(N, C, 2 * Hs, 2 * Ws, seed=100 + trial).requires_grad_(True)
+        w = _rand(K, C, 3, 3, seed=200 + trial, scale=0.1).requires_grad_(True)
+        b = _rand(K, seed=300 + trial, scale=0.1).requires_grad_(True)
+        y = F.conv2d(x, w, b, stride=2, padding=1)
+        gy = _rand(*y.shape, seed=400 + trial)
+        y.backward(gy)
+        xd, wd, bd = (t.detach().cuda().requires_grad_(True) for t in (x, w, b))
+        ops.kernel_log_begin()
+        yd = ops.conv2d(xd, wd, bd, 2, 1)
+        yd.backward(gy.cuda())
+        seen.update(ops.kernel_log_end())
+        errs = (_rel(yd, y), _rel(xd.grad, x.grad), _rel(wd.grad, w.grad), _rel(bd.grad, b.grad))
+        assert max(errs) < 2e-4, ('conv', (N, C, Hs, Ws, K), errs)
+        Ci, Co = rng.choice([16, 32, 128, 144, 256]), rng.choice([64, 128, 192])
+        if N * Ci * Hs * Ws > 4e6:
+            continue
+        xs = _rand(N, Ci, Hs, Ws, seed=500 + trial).requires_grad_(True)
+        wt = _rand(Ci, Co, 3, 3, seed=600 + trial, scale=0.1).requires_grad_(True)
+        yt = F.conv_transpose2d(xs, wt, None, stride=2, padding=1, output_padding=1)
+        gt = _rand(*yt.shape, seed=700 + trial)
+        yt.backward(gt)
+        xsd, wtd = (t.detach().cuda().requires_grad_(True) for t in (xs, wt))
+        ops.kernel_log_begin()
+        ytd = ops.conv_transpose2d(xsd, wtd, None, 2, 1, 1)
+        ytd.backward(gt.cuda())
+        seen.update(ops.kernel_log_end())
+        errs = (_rel(ytd, yt), _rel(xsd.grad, xs.grad), _rel(wtd.grad, wt.grad))
+        assert max(errs) < 2e-4, ('convT', (N, Ci, Hs, Ws, Co), errs)
+    assert {'igemm_f3x3s2_kernel', 'igemm_t3x3s2_kernel', 'igemm_w3x3s2_kernel'} <= seen, seen
+
+
 # (N, C, H, W, K, R, stride, pad, groups)
 GROUPED_CASES = [
     (2, 512, 32, 32, 512, 3, 1, 1, 8),   # LeakyINSResNeXtBlock at full width: k * inplanes = 512, cardinality 8 (common_net.py:116)
