@@ -83,6 +83,17 @@ __global__ __launch_bounds__(256, 2) void c1_fwd_kernel(C1Params p) {
   const long PQ = (long)p.P * p.Q;
   const bool lrelu = p.act == LSPS_ACT_LRELU, other = p.act != LSPS_ACT_LRELU && p.act != LSPS_ACT_NONE;
   const bool full = m0 + 64 <= p.K;
+  // Epilogue kept off the datapath the MFMAs need (round 2 PMC: 2.65 VALU per MFMA here, the matrix pipe 61 % busy): the
+  // bias lives in registers (the accumulators start from it), LeakyReLU with 0 <= slope <= 1 is max(v, slope v), and the
+  // stores go through a buffer descriptor: lane offset = pixel (+ the lane half's four channels), channel = scalar offset.
+  const bool fast = full && (p.act == LSPS_ACT_NONE || (lrelu && p.slope >= 0.f && p.slope <= 1.f)) && 64 * PQ * 4 < (1L << 31);
+  float bias_r[2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[i][r] = bl[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.Y + ((long)n * p.K + m0) * PQ, 0, 0x7fffffff, 0x00020000);
+  const int pq4 = (int)PQ * 4;
   for (int seg = wave; seg < nseg; seg += 4) {
     const int pr = seg / qblocks, q0 = (seg - pr * qblocks) * 32;
     const float *Bp = xs + pr * p.stride * p.LW + (q0 + l31) * p.stride;
@@ -90,12 +101,24 @@ __global__ __launch_bounds__(256, 2) void c1_fwd_kernel(C1Params p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][r] = fast ? bias_r[i][r] : 0.f;
 #pragma unroll
     for (int ks = 0; ks < C1_KS; ++ks) {
       const float b = Bp[boff[ks]];
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][i], b, acc[i], 0, 0, 0);
+    }
+    if (fast) {                                              // wave-uniform
+      const unsigned vo = (unsigned)(((p0 + pr) * p.Q + q0 + l31) * 4 + half * 4 * pq4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][r];
+          if (lrelu) v = fmaxf(v, v * p.slope);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, vo, (i * 32 + (r & 3) + 8 * (r >> 2)) * pq4, 0);
+        }
+      continue;
     }
     float *yb = p.Y + ((long)n * p.K + m0) * PQ + (long)(p0 + pr) * p.Q + q0 + l31;
 #pragma unroll
