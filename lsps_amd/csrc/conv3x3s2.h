@@ -189,6 +189,35 @@ __global__ __launch_bounds__(256, CC == 8 ? 2 : 3) void igemm_f3x3s2_kernel(FS2P
   }
 
   const long PQ = (long)p.P * p.Q;
+  // Epilogue with little VALU (it runs on the datapath the MFMAs of the other workgroups need): when the output channels come
+  // in whole groups of 8 (validity is then wave-uniform per register) the bias is fetched once per register instead of per
+  // store, LeakyReLU with 0 <= slope <= 1 is max(v, slope v), and the stores go through a buffer descriptor (lane offset =
+  // pixel + the lane half's four channels, channel = scalar offset): no 64-bit lane address, no per-lane branch.
+  const bool lrelu01 = p.act == LSPS_ACT_LRELU && p.slope >= 0.f && p.slope <= 1.f;
+  if ((p.M & 7) == 0 && (p.act == LSPS_ACT_NONE || lrelu01) && (long)p.M * PQ * 4 < (1L << 31)) {
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.Y + (long)n * p.M * PQ, 0, p.M * (int)PQ * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.bias ? p.bias : p.Y), 0,
+                                                                       p.bias ? p.M * 4 : 0, 0x00020000);
+    const int pq4 = (int)PQ * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mu = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);      // + 4 half: uniform validity (M % 8 == 0)
+        if (mu >= p.M) continue;
+        // (no bias: the descriptor has 0 records and the load returns 0)
+        const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (unsigned)(half * 16), mu * 4, 0));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float v = acc[i][j][r] + bv;
+          if (lrelu01) v = fmaxf(v, v * p.slope);
+          const unsigned vo = (unsigned)(((p0 + wn * 2 + j) * p.Q + q0 + l31) * 4 + half * 4 * pq4);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, vo, mu * pq4, 0);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     float *yb = p.Y + (long)n * p.M * PQ + (long)(p0 + wn * 2 + j) * p.Q + q0 + l31;
@@ -385,6 +414,38 @@ __device__ __forceinline__ void ts2_body(const TS2Params &p, float *lds) {
 
   const int Wb = 2 * p.Ws;
   const long HWb = 4L * HWs;
+  // low-VALU epilogue as in igemm_f3x3s2_kernel: bias once per register, max-form LeakyReLU, descriptor stores (float2 = the
+  // two column classes of one output pixel pair)
+  const bool lrelu01 = p.act == LSPS_ACT_LRELU && p.slope >= 0.f && p.slope <= 1.f;
+  if ((p.M & 7) == 0 && (p.act == LSPS_ACT_NONE || lrelu01) && (long)p.M * HWb * 4 < (1L << 31)) {
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.Y + (long)n * p.M * HWb, 0, p.M * (int)HWb * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.bias ? p.bias : p.Y), 0,
+                                                                       p.bias ? p.M * 4 : 0, 0x00020000);
+    const int hw4 = (int)HWb * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mu = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);
+        if (mu >= p.M) continue;
+        const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (unsigned)(half * 16), mu * 4, 0));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float v0 = acc[i][j][0][r] + bv, v1 = acc[i][j][1][r] + bv;
+          if (lrelu01) {
+            v0 = fmaxf(v0, v0 * p.slope);
+            v1 = fmaxf(v1, v1 * p.slope);
+          }
+          const int orow = 2 * (p0 + wn * 2 + j) + APAR;
+          const unsigned vo = (unsigned)((orow * Wb + 2 * (q0 + l31)) * 4 + half * 4 * hw4);
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)}, yrs, vo,
+                                                mu * hw4, 0);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int orow = 2 * (p0 + wn * 2 + j) + APAR;
