@@ -42,6 +42,11 @@ def make_device_batch(n, device, seed_offset=0, label_dim=108):
     return dict(xa=t(xa), la=t(la), ca=t(ca), xb=t(xb), lb=t(lb), cb=t(cb))
 
 
+def ldist_default_bucket():
+    from lsps_amd import dist as ldist
+    return ldist.DEFAULT_BUCKET_BYTES
+
+
 def _cpu_model():
     try:
         with open('/proc/cpuinfo') as f:
@@ -53,7 +58,7 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(hp, pretrain_batch=16, timed=3):
+def cpu_baseline(hp, pretrain_batch=16, timed=3, full_bs128=False):
     """The oracle (CPU restatement of the reference, literal backward scope: it back-propagates into the generator in
     dis_update / post_update and computes the discriminator weight gradients in gen_update exactly like the reference)
     timed on this host's physical cores, as BASELINE.md section 3 prescribes: 1 warm-up + `timed` steps, min and median;
@@ -105,6 +110,19 @@ def cpu_baseline(hp, pretrain_batch=16, timed=3):
         return ts
 
     tp = run_timed(pretrain, b)
+    # is the x (128 / n) scaling of `value` fair?  One step at TWICE the timed batch (own warm-up only if cheap): seconds
+    # per sample there over seconds per sample at n; < 1 means larger batches run more efficiently on this host and the
+    # extrapolated baseline is pessimistic (i.e. the GPU/CPU ratio is overstated by that factor), > 1 the opposite
+    lin = None
+    if min(tp) < 30.0:
+        b2 = batch(2 * n)
+        t2 = min(pretrain(b2), pretrain(b2)) if min(tp) < 8.0 else pretrain(b2)
+        lin = {'batch_per_domain': 2 * n, 's_per_step': t2, 's_per_sample_over_that_at_timed_batch': (t2 / (2 * n)) / (min(tp) / n)}
+    full = None
+    if full_bs128:                                         # --cpu-baseline-bs128: ONE literal bs=128 step (minutes, ~50 GB)
+        bf = batch(128)
+        full = {'batch_per_domain': 128, 's_per_step': pretrain(bf), 'extrapolated': False}
+        full['steps_per_s'] = 1.0 / full['s_per_step']
     b128 = batch(128)
     estimate3(b128)
     te = run_timed(estimate3, b128)
@@ -112,6 +130,7 @@ def cpu_baseline(hp, pretrain_batch=16, timed=3):
                 extrapolated=True,
                 pretrain={'batch_per_domain': n, 'timed_steps': len(tp), 'min_s': min(tp), 'median_s': statistics.median(tp),
                           'steps_per_s_at_bs128_linear_extrapolation': (1.0 / min(tp)) * (n / 128.0)},
+                pretrain_linearity_check=lin, pretrain_bs128_direct=full,
                 estimate3_bs128={'timed_steps': len(te), 'min_s': min(te), 'median_s': statistics.median(te),
                                  'steps_per_s': 1.0 / min(te), 'extrapolated': False},
                 sample='oracle/lsps_ref.py RefTrainer(literal=True), torch %s CPU, %d threads on %s: 1 warm-up + %d timed '
@@ -150,6 +169,8 @@ def main():
     ap.add_argument('--exp', default='nnyu', choices=['nnyu', 'nicvl'],
                     help="exps/<exp>.yaml: 'nicvl' with --dtype bf16 --batch 256 is BASELINE config 5 on one GPU")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-bs128', action='store_true',
+                    help='additionally time ONE literal bs=128 pretrain step of the CPU oracle (minutes, ~50 GB of host memory)')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary workloads (estimate3, fwd-only)')
     ap.add_argument('--graphs', action='store_true',
                     help='replay the pretrain step from hipGraphs (LSPSTrainer.use_graphs); the per-kernel HIP events cannot be '
@@ -239,6 +260,7 @@ def main():
             dom_warm = max(warm, key=lambda k: warm[k]['total_ms'])
             ops.profiler.restrict_to(dom_warm)
     for r_ in tr._reducers.values():
+        r_.collect_stats = True         # HIP events around the waits in finish() (off in training runs)
         r_.take_stats()                 # count the gradient exchange of the timed region only
     ops.profiler.reset()
     barrier()
@@ -273,7 +295,7 @@ def main():
     if dist.is_initialized():
         rs = {k: r.take_stats() for k, r in tr._reducers.items() if k in ('dis', 'gen')}
         dp_stats = {'backend': 'rccl' if args.backend == 'nccl' else 'gloo',
-                    'bucket_mib': int(os.environ.get('LSPS_BUCKET_BYTES', 32 << 20)) / float(1 << 20),
+                    'bucket_mib': int(os.environ.get('LSPS_BUCKET_BYTES', ldist_default_bucket())) / float(1 << 20),
                     'allreduce_exposed_ms_per_step': sum(r['exposed_ms'] for r in rs.values()) / args.steps,
                     'allreduce_mb_per_step': sum(r['bytes'] for r in rs.values()) / args.steps / 1e6,
                     'per_update': {('dis_update' if k == 'dis' else 'gen_update'): {
@@ -291,19 +313,25 @@ def main():
         return (time.perf_counter() - t1) / k
 
     extra = {}
-    if not args.no_extra and world > 1:
+    dp_graph_pending = None
+    if not args.no_extra and (world > 1 or dist.is_initialized()):
         # the literal wording of BASELINE's metric (`estimate3` step) under data parallelism: 128 samples per domain per
         # rank, discriminator gradients all-reduced, the global first-4 feature term broadcast (lsps_trainer.post_update)
-        t_est = timed(lambda: tr.post_update(b['xa'], b['la'], b['xb'], b['lb'], b['ca'], b['cb'], 3, hp), 10)
+        est_dp = lambda: tr.post_update(b['xa'], b['la'], b['xb'], b['lb'], b['ca'], b['cb'], 3, hp)   # noqa: E731
+        t_est = timed(est_dp, 10)
         te = torch.tensor([t_est], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         t_est = float(te.item())
         r = tr._reducers['dis'].take_stats()
         extra = {'estimate3_step_bs%d_per_gpu' % args.batch: {
-            'steps_per_s': world / t_est, 'ms_per_step': 1e3 * t_est, 'n_gpus': world,
+            'steps_per_s': world / t_est, 'ms_per_step': 1e3 * t_est, 'n_gpus': world, 'hip_graph': False,
             'buckets_per_step': r['buckets'] / max(r['steps'], 1),
             'launched_during_backward_per_step': r['early'] / max(r['steps'], 1),
+            'allreduce_mb_per_step': r['bytes'] / max(r['steps'], 1) / 1e6,
             'allreduce_exposed_ms_per_step': r['exposed_ms'] / max(r['steps'], 1)}}
+        from lsps_amd import dist as ldist
+        if ldist.capturable() and os.environ.get('LSPS_BENCH_DP_GRAPHS', '1') != '0':
+            dp_graph_pending = est_dp       # measured LAST, behind a watchdog (see the end of main)
     if not args.no_extra and world == 1:
         est_step = lambda: tr.post_update(b['xa'], b['la'], b['xb'], b['lb'], b['ca'], b['cb'], 3, hp)   # noqa: E731
         t_est_eager = timed(est_step, 10)
@@ -381,7 +409,10 @@ def main():
                                                                 ' (fused Winograd F(4x4,3x3) conv + InstanceNorm epilogue on %s)')
                                                                if wino else ' (implicit-GEMM conv on %s)') % mfma,
                         'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
-                        'frac': dom['tflops'] / peak, 'traffic': traffic,
+                        # frac = the fraction of the matrix pipe's peak the kernel ISSUES (<= 1); a Winograd kernel issues
+                        # 1/2.25 (F2) resp. 1/4 (F4) of the algorithmic multiplies `achieved` counts
+                        'frac': dom['tflops'] / (wino_x if wino else 1.0) / peak,
+                        'algorithmic_frac': dom['tflops'] / peak, 'traffic': traffic,
                         'traffic_note': 'HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE KB, calibrated), '
                                         'profiles/%s; scaled to this run\'s mean launch size' % (traffic_file or 'r2_traffic.json'),
                         'launches': dom['launches'], 'avg_launch_ms': dom['avg_ms'],
@@ -400,11 +431,19 @@ def main():
                 # achieved / 2.25 resp. / 4
                 roofline['mfma_issued_tflops'] = dom['tflops'] / wino_x
                 roofline['mfma_issued_frac'] = dom['tflops'] / wino_x / peak
-                roofline['note'] = ('frac > 1 is not a measurement error: Winograd F(%s,3x3) needs %.2fx fewer multiplies '
-                                    'than the algorithmic count that `achieved` is defined on; mfma_issued_frac is the '
-                                    'utilisation of the f32 MFMA pipe (its sustained ceiling is 0.874, '
+                roofline['note'] = ('algorithmic_frac > 1 is not a measurement error: Winograd F(%s,3x3) needs %.2fx fewer '
+                                    'multiplies than the algorithmic count that `achieved` is defined on; frac (= '
+                                    'mfma_issued_frac) is the utilisation of the MFMA pipe (f32: sustained ceiling 0.874, '
                                     'profiles/r1i_mfma_sustained_probe.txt; plain VALU does not overlap the f32 MFMA, '
                                     'profiles/r2_mfma_valu_overlap.txt)' % ('2x2' if wino_x == 2.25 else '4x4', wino_x))
+        # whole step: MFMA flops actually ISSUED by all conv kernels (algorithmic / 2.25 for the F2, / 4 for the F4 Winograd
+        # kernels, algorithmic otherwise; from the fully profiled pass) over the step time, against the pipe's peak
+        step_issued_frac = None
+        if prof_all:
+            wx = {'wino_f3x3_kernel': 2.25, 'wino_w3x3_kernel': 2.25, 'wino4_f3x3_kernel': 4.0, 'wino4_w3x3_kernel': 4.0,
+                  'wino_f3x3_bf16_kernel': 2.25, 'wino_f3x3_in_bf16_kernel': 2.25}
+            issued = sum(a['tflops'] * a['total_ms'] * 1e9 / wx.get(k, 1.0) for k, a in prof_all.items()) / prof_all_steps
+            step_issued_frac = issued / (elapsed / args.steps) / (peak * 1e12)
         out = {
             'metric': 'depth_train steps/sec (128x128x1, bs=128)', 'value': world * args.steps / elapsed,
             'unit': 'steps/s',
@@ -416,15 +455,48 @@ def main():
                        'parallelism': 'dp%d' % world,
                        'unit_of_work': 'one bs=%d step; value = n_gpus * steps / time (aggregate over ranks)' % args.batch, 'algorithmic_tflop_per_step_per_gpu': 50.0 * args.batch / 128.0},
             'step_tflops_per_gpu': 50.0 * args.batch / 128.0 / (elapsed / args.steps),
+            'step_mfma_issued_frac': step_issued_frac,
             'global_iterations_per_s': args.steps / elapsed,
             'roofline': roofline, 'data_parallel': dp_stats, 'other_workloads': extra,
         }
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cb = cpu_baseline(hp)
+            out['cpu_baseline'] = cb = cpu_baseline(hp, full_bs128=args.cpu_baseline_bs128)
             out['speedup_vs_cpu_baseline'] = out['value'] / cb['value']
             est = extra.get('estimate3_step_bs%d' % args.batch)
             if est and args.batch == 128:      # the one comparison with no extrapolation on either side
                 out['estimate3_speedup_vs_cpu_baseline'] = est['steps_per_s'] / cb['estimate3_bs128']['steps_per_s']
+    if dp_graph_pending is not None:
+        # data-parallel estimate3 step replayed from a hipGraph with the RCCL all-reduces captured inside.  If the capture or
+        # a replayed collective were to hang on some RCCL build, the line measured so far must still come out: a watchdog
+        # prints it and ends the process.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out['other_workloads']['estimate3_step_bs%d_per_gpu' % args.batch]['hip_graph_error'] = 'watchdog: no result within 180 s'
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(180.0, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            tr.use_graphs(True)
+            dp_graph_pending()              # the eager timing above was the warm-up of this signature: this call captures
+            t_g = timed(dp_graph_pending, 20)
+            tg = torch.tensor([t_g], dtype=torch.float64, device=dev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            if rank == 0:
+                e_ = out['other_workloads']['estimate3_step_bs%d_per_gpu' % args.batch]
+                e_['eager_ms_per_step'] = e_['ms_per_step']
+                e_['ms_per_step'] = 1e3 * float(tg.item())
+                e_['steps_per_s'] = world / float(tg.item())
+                e_['hip_graph'] = True
+        except Exception as ex:            # noqa: BLE001  (report, keep the eager numbers)
+            if rank == 0:
+                out['other_workloads']['estimate3_step_bs%d_per_gpu' % args.batch]['hip_graph_error'] = repr(ex)[:300]
+        finally:
+            dog.cancel()
+            tr.use_graphs(False)
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:

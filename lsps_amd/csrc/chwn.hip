@@ -520,16 +520,7 @@ int lsps_conv3x3s2_chwn_dgrad(const float *dy, const float *w, float *dx, int N,
   LSPS_CHECK_ARG((size_t)C * 9 * sizeof(float) <= 160 * 1024, "conv3x3s2_chwn_dgrad: more than 4551 input channels");
   hipStream_t st = (hipStream_t)stream;
   float *Wt = (float *)ws, *part = Wt + (size_t)9 * C * K;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chwn_pack_t_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(chwn_pack_t): %s", hipGetErrorString(e));
-      return LSPS_E_HIP;
-    }
-    attr_set = true;
-  }
+  if (int rc = lds_optin(reinterpret_cast<const void *>(chwn_pack_t_kernel), 160 * 1024, "chwn_pack_t")) return rc;
   hipLaunchKernelGGL(chwn_pack_t_kernel, dim3(K), dim3(256), (size_t)C * 9 * sizeof(float), st, w, Wt, K, C);
   LSPS_CHECK_LAUNCH("chwn_pack_t");
   return chwn_run_gemm(Wt, dy, nullptr, dx, C, K, N, H / 2, W / 2, H, W, 1, LSPS_ACT_NONE, 1.f, part, st);
@@ -554,16 +545,7 @@ int lsps_conv3x3s2_chwn_wgrad(const float *x, const float *dy, float *dw, int N,
   p.P = H / 2;
   p.Q = W / 2;
   p.splits = chwn_wgrad_splits(K, C, N, p.P, p.Q);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chwn_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)CW_LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(chwn_wgrad): %s", hipGetErrorString(e));
-      return LSPS_E_HIP;
-    }
-    attr_set = true;
-  }
+  if (int rc = lds_optin(reinterpret_cast<const void *>(chwn_wgrad_kernel), (int)CW_LDS_BYTES, "chwn_wgrad")) return rc;
   hipLaunchKernelGGL(chwn_wgrad_kernel, dim3(ceil_div(C, 128), ceil_div(K, 128), 9 * p.splits), dim3(256), CW_LDS_BYTES, st, p);
   LSPS_CHECK_LAUNCH("chwn_wgrad");
   hipLaunchKernelGGL(chwn_wgrad_reduce_kernel, dim3(ceil_div((long)K * C, 256)), dim3(256), 0, st, (const float *)p.part, dw,

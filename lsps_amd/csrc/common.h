@@ -26,6 +26,11 @@ void set_error(const char *fmt, ...);
     }                                                                      \
   } while (0)
 
+// Opt-in for > 64 KB of dynamic LDS.  The attribute is PER DEVICE (a process that touches a second GPU must set it there
+// too) and launches may come from two host threads (the main stream's and the autograd worker's): remembered per
+// (kernel, device) under a mutex.
+int lds_optin(const void *kernel, int bytes, const char *name);
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 

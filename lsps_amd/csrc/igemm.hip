@@ -32,6 +32,8 @@
 #include "common.h"
 #include <stdarg.h>
 #include <string.h>
+#include <mutex>
+#include <vector>
 
 #include "conv_types.h"
 #include "conv_generic.h"
@@ -49,6 +51,27 @@ void set_error(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+int lds_optin(const void *kernel, int bytes, const char *name) {
+  struct Seen {
+    const void *fn;
+    int dev;
+  };
+  static std::mutex mu;
+  static std::vector<Seen> seen;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const Seen &s : seen)
+    if (s.fn == kernel && s.dev == dev) return 0;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(%s, %d bytes of LDS, device %d): %s", name, bytes, dev, hipGetErrorString(e));
+    return LSPS_E_HIP;
+  }
+  seen.push_back({kernel, dev});
+  return 0;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -345,16 +368,7 @@ static int run_wino4(const float *in, const float *W, const float *bias, float *
 static int run_wino(const float *in, const float *W, const float *bias, float *out, int N, int Cin, int H, int M, long sm,
                     long sc, const TapList &l, int act, float slope, void *ws, size_t ws_bytes, hipStream_t st,
                     const float *addend) {
-  static bool attr_set = false;
-  if (!attr_set) {                        // 94 KB of LDS: dynamic + opt-in
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_f3x3_kernel<2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS_BYTES(2));
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(wino_f3x3): %s", hipGetErrorString(e));
-      return LSPS_E_HIP;
-    }
-    attr_set = true;
-  }
+  if (int rc = lds_optin(reinterpret_cast<const void *>(wino_f3x3_kernel<2>), (int)WN_LDS_BYTES(2), "wino_f3x3")) return rc;
   const size_t need = (size_t)16 * Cin * M * sizeof(float);
   PackKey k = {W, M, M, Cin * 16, Cin * 16, 9, H * 32, 32, /*cc: marks the Winograd layout*/ 1 << 20, sm, sc, 2166136261u};
   for (int i = 0; i < 9; ++i) k.taphash = (k.taphash ^ (unsigned)(l.idx[i] * 961 + i)) * 16777619u;
@@ -1062,16 +1076,7 @@ static bool wino_w_ok(int N, int C, int H, int M) {
 
 static int run_wino_w(const float *dy, const float *x, float *dW, int N, int C, int H, int M, void *ws, size_t ws_bytes,
                       hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {                        // 102 KB of LDS: dynamic + opt-in
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_w3x3_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)WW_LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(wino_w3x3): %s", hipGetErrorString(e));
-      return LSPS_E_HIP;
-    }
-    attr_set = true;
-  }
+  if (int rc = lds_optin(reinterpret_cast<const void *>(wino_w3x3_kernel), (int)WW_LDS_BYTES, "wino_w3x3")) return rc;
   if (wino_w_ws_bytes(N, M, C, H) > ws_bytes) {
     set_error("wgrad workspace too small: need %zu, have %zu", wino_w_ws_bytes(N, M, C, H), ws_bytes);
     return LSPS_E_WS;
@@ -1213,19 +1218,7 @@ static size_t w3x3s2_ws_bytes(int N, int M, int C, int Hs, int Ws) {
 
 static int run_w3x3s2(const float *small, const float *big, float *dW, int N, int C, int M, int Hs, int Ws, void *ws,
                       size_t ws_bytes, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {                        // 67 KB of LDS: above the 64 KB static limit, so dynamic + opt-in
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_w3x3s2_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS2_LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_w3x3s2_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS2_LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(igemm_w3x3s2): %s", hipGetErrorString(e));
-      return LSPS_E_HIP;
-    }
-    attr_set = true;
-  }
+  if (int rc = lds_optin(reinterpret_cast<const void *>(igemm_w3x3s2_kernel<false>), (int)WS2_LDS_BYTES, "igemm_w3x3s2")) return rc;
   WS2Params p;
   memset(&p, 0, sizeof(p));
   p.Small = small;

@@ -83,10 +83,12 @@ __global__ __launch_bounds__(256) void inorm_fwd_kernel(const float *__restrict_
 // Backward from the OUTPUT.  act variant (slope>=0): g = dout*lrelu'(out), xhat = out>0 ? out : out/slope.
 // residual variant (res != null, slope<0): g = dout, xhat = out - res.  plain (no res, slope<0): xhat = out.
 // dy = rstd * (g - mean(g) - xhat*mean(g*xhat))
+// `dy` MAY alias `dout` (lsps_conv2d_dgrad_inbwd's fallback path runs in place): neither is __restrict__; every thread
+// reads exactly the elements it later writes, and in the VPT == 0 form all reads of the second loop precede its write.
 template <int VPT>
-__global__ __launch_bounds__(256) void inorm_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ out,
+__global__ __launch_bounds__(256) void inorm_bwd_kernel(const float *dout, const float *__restrict__ out,
                                                         const float *__restrict__ res, const float *__restrict__ rstd_in,
-                                                        float *__restrict__ dy, int hw, float slope) {
+                                                        float *dy, int hw, float slope) {
   __shared__ float red[4];
   const long base = (long)blockIdx.x * hw;
   const float inv = 1.f / (float)hw;

@@ -14,33 +14,15 @@ int wino4_launch_pack(const Wino4Pack &p, hipStream_t st) {
 }
 
 int wino4_launch(const Wino4Params &p, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {                        // 144 KB of LDS: dynamic + opt-in
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_f3x3_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(wino4_f3x3): %s", hipGetErrorString(e));
-      return LSPS_E_HIP;
-    }
-    attr_set = true;
-  }
+  if (int rc = lds_optin(reinterpret_cast<const void *>(wino4_f3x3_kernel), (int)W4_LDS_BYTES, "wino4_f3x3")) return rc;
   hipLaunchKernelGGL(wino4_f3x3_kernel, dim3(p.N * (p.M / 32)), dim3(512), W4_LDS_BYTES, st, p);
   LSPS_CHECK_LAUNCH("wino4_f3x3");
   return 0;
 }
 
 int wino4_launch_wgrad(const Wino4WParams &p, int splits, float *dW, int waves, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {                        // 127 KB of LDS: dynamic + opt-in
-    for (const void *f : {reinterpret_cast<const void *>(wino4_w3x3_kernel<2>), reinterpret_cast<const void *>(wino4_w3x3_kernel<1>)}) {
-      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4W_LDS_BYTES);
-      if (e != hipSuccess) {
-        set_error("hipFuncSetAttribute(wino4_w3x3): %s", hipGetErrorString(e));
-        return LSPS_E_HIP;
-      }
-    }
-    attr_set = true;
-  }
+  for (const void *f : {reinterpret_cast<const void *>(wino4_w3x3_kernel<2>), reinterpret_cast<const void *>(wino4_w3x3_kernel<1>)})
+    if (int rc = lds_optin(f, (int)W4W_LDS_BYTES, "wino4_w3x3")) return rc;
   const dim3 grid(p.C / 32, p.M / 64, splits);
   if (waves == 8)
     hipLaunchKernelGGL(wino4_w3x3_kernel<1>, grid, dim3(512), W4W_LDS_BYTES, st, p);

@@ -7,7 +7,7 @@ so rank-local mean-loss gradients averaged over ranks ARE the global-batch gradi
 optimizer step; 1/world is folded into the Adam kernel (`FlatAdam.grad_scale`).
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU), so the arena is cut into a FEW LARGE
-contiguous buckets (default 32 MiB) — per-link-bound ring steps want big messages — ordered so
+contiguous buckets (default 16 MiB) — per-link-bound ring steps want big messages — ordered so
 that the bucket whose gradients are produced FIRST by backward (the last layers) is launched
 first, on RCCL's own stream, while backward keeps producing the rest (overlap).  Buckets are
 slices of the flat gradient buffer: no flatten / unflatten copies.
@@ -17,6 +17,12 @@ covered by CPU tests (tests/test_dist_cpu.py, world_size 2).
 """
 import torch
 import torch.distributed as dist
+
+
+# 16 MiB: few, large messages (an 8-rank ring moves 2 MiB pieces per step: per-link-bound, not latency-bound), yet small
+# enough that what is still un-sent when backward ends — the last bucket, i.e. the FIRST layers — stays a few MB: on the
+# discriminator that is 6.5 MB (a 32 MiB cut leaves model_S.2's 19 MB weight in it: 25 MB exposed per estimate step)
+DEFAULT_BUCKET_BYTES = 16 << 20
 
 
 def world():
@@ -32,8 +38,39 @@ def active():
     return dist.get_world_size() > 1 or os.environ.get('LSPS_FORCE_DP') == '1'
 
 
+def capturable():
+    """Can this process group's collectives be recorded into a hipGraph?  RCCL kernels can (they are stream work); gloo
+    moves data through the host.  LSPS_DP_GRAPHS=0 keeps data-parallel steps eager."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()) or os.environ.get('LSPS_DP_GRAPHS') == '0':
+        return False
+    return dist.get_backend() == 'nccl'
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def cut_buckets(nbytes, bucket_bytes, segments=None):
+    """Contiguous parameter index ranges [i0, i1) of the gradient arena, in READINESS order: backward produces the
+    gradients of the last layers first, so the walk goes from the last parameter to the first and closes a bucket once
+    it holds >= `bucket_bytes`; bucket 0 is therefore the tail of the arena and is complete first.  A tensor that alone
+    reaches the bucket size travels alone (the discriminator's `model_S.3` weight, 75 MB, is ready a few launches into
+    backward and must not wait for the small layers around it); no bucket crosses a segment start."""
+    n = len(nbytes)
+    starts = set(segments or ())
+    out = []
+    i1, acc = n, 0
+    for i in range(n - 1, -1, -1):
+        big = nbytes[i] >= bucket_bytes
+        if big and i + 1 < i1:             # close what has been collected behind the big tensor
+            out.append((i + 1, i1))
+            i1, acc = i + 1, 0
+        acc += nbytes[i]
+        if big or acc >= bucket_bytes or i == 0 or i in starts:
+            out.append((i, i1))
+            i1, acc = i, 0
+    return out
 
 
 class GradReducer(object):
@@ -48,22 +85,17 @@ class GradReducer(object):
     learn the same sets; a gradient that arrives for a bucket that has already gone out means the signature did not
     determine the graph and raises instead of reducing a half-filled bucket."""
 
-    def __init__(self, arena, bucket_bytes=None, group=None):
+    def __init__(self, arena, bucket_bytes=None, group=None, segments=None):
+        """`segments`: start indices of the parameter groups that must never share a bucket (the generator arena holds
+        `gen` then `map`: a step with train_map=False would otherwise all-reduce the idle Mapping's zeros)."""
         import os
-        if bucket_bytes is None:           # 32 MiB: few, large messages (per-link-bound xGMI ring steps)
-            bucket_bytes = int(os.environ.get('LSPS_BUCKET_BYTES', 32 << 20))
+        if bucket_bytes is None:
+            bucket_bytes = int(os.environ.get("LSPS_BUCKET_BYTES", DEFAULT_BUCKET_BYTES))
         self.arena = arena
         self.group = group
         self.world = world()
         n = len(arena.params)
-        # buckets = contiguous parameter index ranges [i0, i1), cut at >= bucket_bytes
-        self.buckets = []
-        i0, acc = 0, 0
-        for i, p in enumerate(arena.params):
-            acc += p.numel() * 4
-            if acc >= bucket_bytes or i == n - 1:
-                self.buckets.append((i0, i + 1))
-                i0, acc = i + 1, 0
+        self.buckets = cut_buckets([p.numel() * 4 for p in arena.params], bucket_bytes, segments)
         self.bucket_of = [0] * n
         for b, (a0, a1) in enumerate(self.buckets):
             for i in range(a0, a1):
@@ -75,6 +107,7 @@ class GradReducer(object):
         self._learned = {}
         self._scalars = None
         self.stats = dict(steps=0, buckets=0, early=0, exposed_ms=0.0, bytes=0)
+        self.collect_stats = False         # bench.py: HIP events around the waits of finish() (never in a training run)
         self._exposed_events = []
         self.active = active()
         if self.active:
@@ -138,7 +171,7 @@ class GradReducer(object):
             # ranks agree on which buckets carry gradients because they run the same step
             if not self._launched[b] and any(touched[i0:i1]):
                 self._launch(b)
-        timed = self.arena.flat_g.is_cuda
+        timed = self.collect_stats and self.arena.flat_g.is_cuda
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -180,6 +213,15 @@ def broadcast_from_rank0(tensors, group=None):
         return
     for t in tensors:
         dist.broadcast(t, 0, group=group)
+
+
+def agree_from_rank0(value):
+    """Rank 0's python value on every rank (e.g. the iteration count a resume() found); identity in a single process."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    box = [value]
+    dist.broadcast_object_list(box, 0)
+    return box[0]
 
 
 def barrier():

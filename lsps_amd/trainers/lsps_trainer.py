@@ -55,7 +55,7 @@ def _weights_constant(fn):
 
     @functools.wraps(fn)
     def wrapped(self, images_a, *a, **k):
-        if not self._graphs_on or lsps_dist.active():
+        if not self._graphs_on or (lsps_dist.active() and not lsps_dist.capturable()):
             return eager(self, images_a, *a, **k)
         return self._graphed(fn.__name__, eager, (images_a,) + a, k)
     return wrapped
@@ -70,6 +70,10 @@ def _flatten_tensors(obj, out):
         return (type(obj).__name__,) + tuple(_flatten_tensors(o, out) for o in obj)
     if isinstance(obj, dict):
         return ('dict',) + tuple((k, _flatten_tensors(obj[k], out)) for k in sorted(obj))
+    if isinstance(obj, np.ndarray) and obj.size > 1:
+        # repr() of a large array elides its middle: two different arrays would share one signature and the captured
+        # copy would go stale
+        raise TypeError("hipGraph replay: pass arrays as tensors (got a numpy array of %d elements)" % obj.size)
     return ('V', repr(obj))
 
 
@@ -96,8 +100,13 @@ class _GraphedUpdate(object):
         self.graph = torch.cuda.CUDAGraph()
         trainer._capturing = self
         self.pending = None
+        # Under data parallelism the reducer's hooks fire during the capture like in any eager step, so the bucket
+        # all-reduces (RCCL kernels on the process group's stream, forked from / joined to the launch stream by events)
+        # become nodes of the graph at the points of backward where they are launched.  RCCL's watchdog thread polls
+        # events meanwhile: legal only if the capture does not police other threads ('thread_local').
+        mode = dict(capture_error_mode='thread_local') if lsps_dist.active() else {}
         try:
-            with torch.cuda.graph(self.graph, pool=pool):
+            with torch.cuda.graph(self.graph, pool=pool, **mode):
                 self.result = eager(trainer, *a, **k)
         finally:
             trainer._capturing = None
@@ -114,7 +123,8 @@ class _GraphedUpdate(object):
         self.graph.replay()
         key, opt, names, scal = self.pending
         opt.arena.touched[:] = self.touched
-        trainer._finish_step(opt, names, scal, None)
+        # data parallel: the captured all-reduce summed `scal` over the ranks in place
+        trainer._finish_step(opt, names, scal, scal / float(lsps_dist.world()) if lsps_dist.active() else None)
         return self.result
 
 
@@ -162,9 +172,19 @@ class LSPSTrainer(nn.Module):
             for n_ in nets:
                 n_._arena = arena
             opt.grad_scale = 1.0 / lsps_dist.world()
-            self._reducers[key] = lsps_dist.GradReducer(arena)
+            seg, starts = 0, []
+            for n_ in nets:                 # no bucket may hold gradients of two nets (gen | map share one arena)
+                starts.append(seg)
+                seg += len(list(n_.parameters()))
+            self._reducers[key] = lsps_dist.GradReducer(arena, segments=starts)
+        self._drop_graphs()                 # captured launches point into the previous arenas
         self.sync_replicas()
         return self
+
+    def _drop_graphs(self):
+        self._graphs.clear()
+        self._graph_seen.clear()
+        self._graph_pool = None
 
     def sync_replicas(self):
         """Under data parallelism every rank builds its nets from its own RNG (gaussian_weights_init, nn.Linear's
@@ -176,8 +196,10 @@ class LSPSTrainer(nn.Module):
             opt.sync_from_rank0()
 
     def _side_stream(self, device):
-        """Second HIP stream for the independent branch of the estimate modes (LSPS_NO_OVERLAP=1 or data parallelism: none)."""
-        if os.environ.get('LSPS_NO_OVERLAP') == '1' or lsps_dist.active():
+        """Second HIP stream for the independent branch of the estimate modes (LSPS_NO_OVERLAP=1: none).  Also under data
+        parallelism: the gradient hooks run in the AccumulateGrad nodes, which the engine executes on the launch stream after
+        it has joined the side stream's producers, so a bucket's all-reduce is ordered behind both branches."""
+        if os.environ.get('LSPS_NO_OVERLAP') == '1':
             return None
         if self._side is None:
             self._side = torch.cuda.Stream(device=device)
@@ -189,23 +211,26 @@ class LSPSTrainer(nn.Module):
         return self._side
 
     def use_graphs(self, on=True):
-        """hipGraph replay of dis_update / gen_update / post_update (single process only; under torch.distributed the
-        methods stay eager).  A call signature = method + tensor shapes + every non-tensor argument (mode, the
+        """hipGraph replay of dis_update / gen_update / post_update (under torch.distributed only on the RCCL backend, whose
+        collectives can be captured; gloo steps stay eager).  A call signature = method + tensor shapes + every non-tensor argument (mode, the
         hyperparameter dict, feat_mat ...) + train/eval state; its first call runs eagerly (warm-up: workspaces, kernel
         attributes), the second is captured, later ones replay.  Results are those of the eager path (same kernels, same
         order); the tensors a graphed method returns are static buffers overwritten by the next replay.  Random draws
         (GaussianNoiseLayer, the VAE code) come from torch's graph-safe generator offsets."""
         self._graphs_on = bool(on)
         if not on:
-            self._graphs.clear()
-            self._graph_seen.clear()
-            self._graph_pool = None         # its graphs are gone: a later use_graphs(True) starts a fresh memory pool
+            self._drop_graphs()             # a later use_graphs(True) starts a fresh memory pool
         return self
 
     def _graphed(self, name, eager, args, kwargs):
         tensors = []
-        sig = (name, _flatten_tensors((args, kwargs), tensors), self.gen.training, self.dis.training,
-               ops.get_winograd(), ops.get_math_mode())
+        # everything that decides WHICH launches a step makes or WHERE they read / write: argument shapes and values, every
+        # sub-net's train / eval flag (poseVAE.encode draws noise, GaussianNoiseLayer is off in eval), the algorithm /
+        # math switches of the library, the layout / overlap environment and the arenas' addresses
+        sig = (name, _flatten_tensors((args, kwargs), tensors), self.gen.training, self.dis.training, self.vae.training,
+               self.map.training, ops.get_winograd(), ops.get_math_mode(),
+               tuple(os.environ.get(k) for k in ('LSPS_CHWN', 'LSPS_CHWN_MIN_N', 'LSPS_NO_OVERLAP', 'LSPS_NO_PACK_CACHE')),
+               tuple(int(o.arena.flat_p.data_ptr()) for o in (self.dis_opt, self.gen_opt, self.vae_opt) if o.arena is not None))
         g = self._graphs.get(sig)
         if g is not None:
             return g.replay(self, args, kwargs)
@@ -386,9 +411,9 @@ class LSPSTrainer(nn.Module):
             first_a, first_b = images_a[0:4], images_b[0:4]                       # :238 — only the first 4 samples
             if lsps_dist.active():
                 # exact global-batch parity: every rank evaluates the SAME (global first-4) feature term
-                first_a, first_b = first_a.clone(), first_b.clone()
-                torch.distributed.broadcast(first_a, 0)
-                torch.distributed.broadcast(first_b, 0)
+                first = torch.cat((first_a, first_b), 0)                          # ONE 8-image broadcast
+                torch.distributed.broadcast(first, 0)
+                first_a, first_b = first[0:4], first[4:8]
             # The feature branch (generator on 8 samples -> dis.feats on 16) and the regression branch (dis on the whole
             # batch) are independent until the loss is summed, and the first one's launches fill a quarter of the chip at
             # best: it runs on a second HIP stream (forward here, its backward follows it there: autograd replays a node on
@@ -433,6 +458,14 @@ class LSPSTrainer(nn.Module):
         return torch.load(path, map_location='cpu')
 
     def resume(self, snapshot_prefix, idx=-1, load_opt=False, est=False):
+        """Under data parallelism the outcome is rank 0's: a rank that does not see the snapshot (no shared filesystem, a
+        half-written file) still enters the same broadcasts as the others and ends up with rank 0's weights and count."""
+        iterations = self._resume_local(snapshot_prefix, idx, load_opt, est)
+        iterations = lsps_dist.agree_from_rank0(iterations)
+        self.sync_replicas()
+        return iterations
+
+    def _resume_local(self, snapshot_prefix, idx, load_opt, est):
         dirname = os.path.dirname(snapshot_prefix)
         last_model_name = get_model_list(dirname, "est_gen" if est else "gen", idx)
         if last_model_name is None:
@@ -453,7 +486,6 @@ class LSPSTrainer(nn.Module):
         except Exception:
             print('-----Failed to load map parameters!')
         print('Resume from iteration %d' % iterations)
-        self.sync_replicas()
         return iterations
 
     @staticmethod
@@ -476,11 +508,10 @@ class LSPSTrainer(nn.Module):
     def load_vae(self, snapshot_prefix, frac):
         dirname = os.path.dirname(snapshot_prefix)
         last_model_name = get_model_list(dirname, 'vae_%.2f' % frac)
-        if last_model_name is None:
-            return 0
-        self.vae.load_state_dict(self._load(last_model_name))
-        print('Loading pretrained VAE parameters from %s' % last_model_name)
-        self.sync_replicas()
+        if last_model_name is not None:
+            self.vae.load_state_dict(self._load(last_model_name))
+            print('Loading pretrained VAE parameters from %s' % last_model_name)
+        self.sync_replicas()                # every rank, whatever it found locally: rank 0's copy wins
         return 0
 
 

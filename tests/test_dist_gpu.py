@@ -204,3 +204,73 @@ def test_two_rank_hip_trainer_matches_reference_golden_and_overlaps(golden):
         e1, n1 = overlap[(step, 1)]
         assert n1 >= 2, (step, n1)
         assert e0 == 0 and e1 >= n1 - 1, (step, overlap)      # learned in iteration 0, overlapped from iteration 1 on
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 3: data-parallel steps replayed from hipGraphs (the bucket all-reduces are captured RCCL launches) and the
+# estimate modes' side stream under data parallelism.  One rank on RCCL (LSPS_FORCE_DP=1): RCCL refuses two ranks on one
+# device, so this pins the capture / replay machinery and its bookkeeping, not a transfer.
+# ---------------------------------------------------------------------------------------------------------------
+def _dp_graph_worker(port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    os.environ['LSPS_FORCE_DP'] = '1'
+    os.environ['LSPS_BUCKET_BYTES'] = str(1 << 16)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', 0), rank=0, world_size=1)
+    try:
+        import lsps_amd.trainers as prod
+        from lsps_amd import dist as ldist
+        assert ldist.active() and ldist.capturable()
+        A = cases.NativeAdapter(prod, 'cuda')
+        hp = cases.hp_for('tiny')
+        sds = cases.make_weights(hp, lsps_ref)
+        lat2, lat1 = cases.latent_shape(hp, 8), cases.latent_shape(hp, 4)
+        zd = hp['vae']['z_dim']
+        res = []
+        for graphed in (False, True):
+            tr = A.make_trainer(hp, sds)
+            tr.use_graphs(graphed)
+            A.set_train(tr, True)
+            trace, early = [], []
+            for rnd in range(4):
+                b = cases.make_inputs(4)
+                b = {k: (v * (1.0 - 0.1 * rnd)).astype(v.dtype) if k in ('xa', 'xb') else v for k, v in b.items()}
+                A.dis_update(tr, b, hp, cases.noise(lat2, 10 + rnd))
+                A.gen_update(tr, b, hp, (cases.noise(lat2, 20 + rnd), cases.noise(lat1, 30 + rnd), cases.noise(lat1, 40 + rnd)))
+                A.post_update(tr, b, 3, hp, cases.noise(lat2, 50 + rnd), cases.noise((4, zd), 60 + rnd, 0.05),
+                              cases.noise((4, zd), 70 + rnd, 0.05))
+                trace.append(A.scalars(tr))
+                early.append((tr._reducers['dis'].last_early, tr._reducers['dis'].last_buckets))
+            res.append(dict(trace=trace, gen=A.params(tr, 'gen'), dis=A.params(tr, 'dis'), n_graphs=len(tr._graphs),
+                            side=tr._side is not None, early=early))
+        torch.cuda.synchronize()
+        out.put(res)
+    except Exception as e:                                   # the parent would otherwise wait for its timeout
+        import traceback
+        out.put(('error', repr(e), traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_steps_replay_from_hip_graphs_bitwise():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    p = ctx.Process(target=_dp_graph_worker, args=(_free_port(), out))
+    p.start()
+    got = out.get(timeout=900)
+    p.join(timeout=120)
+    assert got[0] != 'error', got
+    assert p.exitcode == 0
+    eager, graphed = got
+    assert graphed['n_graphs'] == 3 and eager['n_graphs'] == 0
+    assert eager['side'] and graphed['side'], "the estimate modes' side stream must also run under data parallelism"
+    assert eager['trace'] == graphed['trace'], (eager['trace'], graphed['trace'])
+    for net in ('gen', 'dis'):
+        for k in eager[net]:
+            assert np.array_equal(eager[net][k], graphed[net][k]), k
+    e, n = eager['early'][-1]
+    assert n >= 2 and e >= n - 1, eager['early']            # eager DP steps still overlap (learned signatures)
