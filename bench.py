@@ -364,12 +364,12 @@ def main():
             step32()                    # captures (the eager timing above was the warm-up of these signatures)
             t_ref_bs_graph = timed(step32, 10)
             tr.use_graphs(False)
-        extra = {'estimate3_step_bs%d' % args.batch: {'steps_per_s': 1.0 / t_est, 'ms_per_step': 1e3 * t_est,
+        extra.update({'estimate3_step_bs%d' % args.batch: {'steps_per_s': 1.0 / t_est, 'ms_per_step': 1e3 * t_est,
                                                        'hip_graph': True, 'eager_ms_per_step': 1e3 * t_est_eager,
                                                        'algorithmic_tflop_per_step': 0.579 * args.batch / 128.0,
                                                        'mfma_floor_ms': 0.579 * args.batch / 128.0 / F32_MFMA_PEAK_TFLOPS * 1e3},
                  'gen_forward_bs%d' % args.batch: {'calls_per_s': 1.0 / t_fwd, 'ms_per_call': 1e3 * t_fwd,
-                                                   'tflops': 7.76 * args.batch / 128.0 / t_fwd}}
+                                                   'tflops': 7.76 * args.batch / 128.0 / t_fwd}})
         if t_ref_bs:
             extra['pretrain_step_bs%d_reference_yaml_batch' % ref_bs] = {
                 'ms_per_step': 1e3 * t_ref_bs, 'steps_per_s': 1.0 / t_ref_bs, 'hip_graph_ms_per_step': 1e3 * t_ref_bs_graph,

@@ -238,6 +238,12 @@ class LSPSTrainer(nn.Module):
             self._graph_seen.add(sig)
             return eager(self, *args, **kwargs)
         torch.cuda.synchronize()
+        if lsps_dist.active():
+            # RCCL's watchdog thread polls the end events of the EAGER collectives it still tracks; HIP refuses such a
+            # query (hipErrorCapturedEvent, which the watchdog turns into an abort) once the process group's stream has
+            # joined a capture.  The device is idle here, so the list drains at the watchdog's next poll (100 ms period).
+            import time
+            time.sleep(0.5)
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
         g = self._graphs[sig] = _GraphedUpdate(self, eager, args, kwargs, self._graph_pool)
