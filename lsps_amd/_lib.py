@@ -64,6 +64,18 @@ _SIGNATURES = {
     'lsps_bnorm_bwd': (c_int, [_P] * 8 + [c_int] * 4 + [_P, c_size_t, _P]),
     'lsps_act_fwd': (c_int, [_P, _P, c_long, c_int, c_float, _P]),
     'lsps_mul_add': (c_int, [_P, _P, _P, _P, c_long, _P]),
+    'lsps_c8_conv3x3_ok': (c_int, [c_int] * 5),
+    'lsps_c8_conv3x3_workspace_bytes': (c_size_t, [c_int] * 2),
+    'lsps_c8_from_nchw': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'lsps_c8_to_nchw': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'lsps_c8_add': (c_int, [_P, _P, _P, c_long, _P]),
+    'lsps_c8_conv3x3_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
+    'lsps_c8_conv3x3_in_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [c_float, c_float, _P, c_size_t, _P]),
+    'lsps_c8_conv3x3_dgrad_acc': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
+    'lsps_c8_conv3x3_dgrad_inbwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [c_float, _P, c_size_t, _P]),
+    'lsps_c8_conv3x3_wgrad_workspace_bytes': (c_size_t, [c_int] * 3),
+    'lsps_c8_conv3x3_wgrad': (c_int, [_P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
+    'lsps_c8_inorm_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     'lsps_crop_normalize': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     'lsps_crop_augment': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
 }

@@ -31,6 +31,11 @@ void set_error(const char *fmt, ...);
 // (kernel, device) under a mutex.
 int lds_optin(const void *kernel, int bytes, const char *name);
 
+// Pack-cache scope of the trainer step (igemm.hip: lsps_pack_cache_begin / _end) for packed weight layouts of other
+// translation units: the cached slot for (W, layout tag, geometry) on this stream (*hit = true), a fresh slot of `need`
+// bytes the caller must fill (*hit = false), or nullptr (no scope open / arena full: pack into the call's workspace).
+void *pack_cache_slot(const float *W, int tag, int M, int C, long sm, long sc, size_t need, bool *hit, hipStream_t st);
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -174,6 +174,11 @@ static void *pack_cache_find(const PackKey &k, size_t need, bool *hit, hipStream
   return cls;
 }
 
+void *pack_cache_slot(const float *W, int tag, int M, int C, long sm, long sc, size_t need, bool *hit, hipStream_t st) {
+  PackKey k = {W, M, M, C, C, 9, 0, 0, tag, sm, sc, 2166136261u};
+  return pack_cache_find(k, need, hit, st);
+}
+
 static int launch_pack(const float *W, void *cls, int M, int Mp, int RED, int REDp, const TapList &l, long sm, long sc,
                        int HxWx, int Wx, hipStream_t st, const float **Wp_out, const int2 **gtab_out,
                        const float **zero_out, int cc = 0) {
