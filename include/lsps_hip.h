@@ -134,6 +134,44 @@ int lsps_conv3x3s2_chwn_dgrad(const float *dy, const float *w, float *dx, int N,
 int lsps_conv3x3s2_chwn_wgrad(const float *x, const float *dy, float *dw, int N, int C, int H, int W, int K,
                               void *ws, size_t ws_bytes, void *stream);
 
+/* ---- bf16 residual trunk in the channel-group layout "C8" (BASELINE config 5: exps/nicvl.yaml, bf16 MFMA conv path) -----
+ * The chain of LeakyINSResBlock layers of SharedResGen (reference common_net.py:160-181, instantiated at
+ * lsps_nets.py:176-179,195-229 on 32x32 maps with 4*ch channels) on bf16 activations stored [N][C/8][H][W][8]: the 8
+ * channels of a pixel are one 16-byte unit = one v_mfma_f32_32x32x16_bf16 operand fragment, so operands are staged by
+ * LDS-DMA without conversion and every tap is a unit offset.  `void *` tensors are bf16 in that layout; weights stay f32
+ * (K, C, 3, 3) (the reference's state-dict layout) and are packed to bf16 per call (cached in the pack-cache scope);
+ * statistics and accumulation are f32.  Geometry: H = W = 32; conv entries C % 16 == 0 and K % 64 == 0 (outputs), the
+ * weight gradient C % 64 == 0 and K % 128 == 0.
+ *   lsps_c8_from_nchw / _to_nchw   layout + precision conversion at the ends of the chain (x [N,C,HW] f32)
+ *   lsps_c8_add                    GaussianNoiseLayer on a C8 tensor (common_net.py:39-40), n = element count
+ *   lsps_c8_conv3x3_fwd            y = conv3x3(x, w) (+ addend)                                   (common_net.py:162)
+ *   lsps_c8_conv3x3_in_fwd         residual == NULL: y = LeakyReLU_slope(InstanceNorm(conv(x, w))) (:162-169, slope < 0: none)
+ *                                  residual != NULL: y = InstanceNorm(conv(x, w)) + residual       (:163-181); rstd [N*K] out
+ *   lsps_c8_conv3x3_dgrad_acc      dx = conv3x3_dgrad(dy, w) + addend (addend nullable)            (autograd of :162 + skip)
+ *   lsps_c8_conv3x3_dgrad_inbwd    dx = backward of [InstanceNorm + LeakyReLU(slope)] applied to conv3x3_dgrad(dy, w), the
+ *                                  norm recovered from its saved output `out_saved` [N,C,..] and `rstd` [N*C]
+ *   lsps_c8_conv3x3_wgrad          dw [K,C,3,3] f32 = weight gradient from x [N,C,..] and dy [N,K,..] (OVERWRITTEN)
+ *   lsps_c8_inorm_bwd              backward of InstanceNorm (+ residual | + LeakyReLU(slope)) from the output (lsps_inorm_bwd
+ *                                  on C8 tensors; planes of <= 1024 pixels) */
+int lsps_c8_conv3x3_ok(int N, int C, int H, int W, int K);            /* 1 if the conv entries take this geometry */
+size_t lsps_c8_conv3x3_workspace_bytes(int C, int K);
+size_t lsps_c8_conv3x3_wgrad_workspace_bytes(int N, int C, int K);
+int lsps_c8_from_nchw(const float *x, void *y, int N, int C, int HW, void *stream);
+int lsps_c8_to_nchw(const void *x, float *y, int N, int C, int HW, void *stream);
+int lsps_c8_add(const void *a, const void *b, void *out, long n, void *stream);
+int lsps_c8_conv3x3_fwd(const void *x, const float *w, const void *addend /*nullable*/, void *y, int N, int C, int H, int W, int K,
+                        void *ws, size_t ws_bytes, void *stream);
+int lsps_c8_conv3x3_in_fwd(const void *x, const float *w, const void *residual /*nullable*/, void *y, float *rstd,
+                           int N, int C, int H, int W, int K, float slope, float eps, void *ws, size_t ws_bytes, void *stream);
+int lsps_c8_conv3x3_dgrad_acc(const void *dy, const float *w, const void *addend /*nullable*/, void *dx,
+                              int N, int C, int H, int W, int K, void *ws, size_t ws_bytes, void *stream);
+int lsps_c8_conv3x3_dgrad_inbwd(const void *dy, const float *w, const void *out_saved, const float *rstd, void *dx,
+                                int N, int C, int H, int W, int K, float slope, void *ws, size_t ws_bytes, void *stream);
+int lsps_c8_conv3x3_wgrad(const void *x, const void *dy, float *dw, int N, int C, int H, int W, int K,
+                          void *ws, size_t ws_bytes, void *stream);
+int lsps_c8_inorm_bwd(const void *dout, const void *out, const void *residual /*nullable*/, const float *rstd, void *dy,
+                      int N, int C, int HW, float slope, void *stream);
+
 /* ---- ConvTranspose2d: replaces nn.ConvTranspose2d forward/backward -------------------------
  * call sites: common_net.py:262 (LeakyReLUConvTranspose2d), lsps_nets.py:226-227 (1x1 output),
  *             lsps_nets.py:17-23 (Mapping).

@@ -39,9 +39,11 @@ namespace lsps {
 
 typedef __attribute__((address_space(3))) void *c8_lds_ptr;
 
-// x < 0 (sign bit set) ? a : b, without a compare mask
-__device__ __forceinline__ float c8_sel_neg_f(float x, float a, float b) {
-  const int m = __builtin_bit_cast(int, x) >> 31;
+// x > 0 ? b : a  (x <= 0, either zero included: LeakyReLU'(0) = slope like torch's `out > 0` test) without a compare mask:
+// 64 such masks held live in SGPR pairs spill.  ((bits - 1) | bits) is negative exactly for +0, -0 and negative x.
+__device__ __forceinline__ float c8_sel_nonpos(float x, float a, float b) {
+  const int xb = __builtin_bit_cast(int, x);
+  const int m = ((xb - 1) | xb) >> 31;
   return __builtin_bit_cast(float, (__builtin_bit_cast(int, a) & m) | (__builtin_bit_cast(int, b) & ~m));
 }
 
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void c8_inorm_bwd_kernel(const unsigned short 
         g[i][e] = d;
         xh[i][e] = o - (float)rv[e];
       } else {
-        g[i][e] = c8_sel_neg_f(o, d * slope, d);
+        g[i][e] = c8_sel_nonpos(o, d * slope, d);
         xh[i][e] = fmaxf(o, 0.f) + fminf(o, 0.f) * inv_slope;
       }
       s[e] += g[i][e];
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
           for (int e = 0; e < 4; ++e) {
             // branch-free forms (64 compare masks held in SGPR pairs spill): sign mask + bitfield select, max / min
             const float d = acc[i][j][rq * 4 + e];
-            const float g = c8_sel_neg_f(o[e], d * p.slope, d);
+            const float g = c8_sel_nonpos(o[e], d * p.slope, d);
             const float xh = fmaxf(o[e], 0.f) + fminf(o[e], 0.f) * inv_slope;
             acc[i][j][rq * 4 + e] = g;
             a1[e] += g;

@@ -575,6 +575,174 @@ class _ResBlockFn(torch.autograd.Function):
         return dx, dw1, dw2
 
 
+# ------------------------------------------------------------------------------------------
+# bf16 residual trunk in the channel-group layout "C8": [N][C/8][H][W][8] bf16 tensors (csrc/c8conv.h, c8wgrad.h)
+# ------------------------------------------------------------------------------------------
+BF16 = torch.bfloat16
+
+
+def is_c8(t):
+    return torch.is_tensor(t) and t.dtype == BF16 and t.dim() == 5 and t.shape[-1] == 8
+
+
+def c8_block_ok(x, channels, dropout=0.0):
+    """Can a LeakyINSResBlock(channels -> channels) on `x` (f32 NCHW or already C8) run on the C8 kernels?  bf16 math mode,
+    32x32 maps, channels % 128 == 0 (k tiles of the weight-gradient kernel), no dropout; LSPS_C8=0 switches the path off."""
+    import os
+    if get_math_mode() != 'bf16' or dropout > 0 or os.environ.get('LSPS_C8', '1') == '0':
+        return False
+    if is_c8(x):
+        N, G, H, W, _ = x.shape
+        C = G * 8
+    else:
+        if x.dim() != 4:
+            return False
+        N, C, H, W = x.shape
+    return N > 0 and C == channels and channels % 128 == 0 and H == 32 and W == 32
+
+
+class _ToC8Fn(torch.autograd.Function):
+    """f32 [N][C][H][W] -> bf16 [N][C/8][H][W][8]; backward = the inverse conversion of the gradient."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, C, H, W = x.shape
+        y = torch.empty((N, C // 8, H, W, 8), dtype=BF16, device=x.device)
+        _lib.check(_lib.lib().lsps_c8_from_nchw(_lib.ptr(x), _lib.ptr(y, BF16), N, C, H * W, _lib.stream()), 'c8_from_nchw')
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        N, G, H, W, _ = g.shape
+        dx = torch.empty((N, G * 8, H, W), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().lsps_c8_to_nchw(_lib.ptr(g, BF16), _lib.ptr(dx), N, G * 8, H * W, _lib.stream()), 'c8_to_nchw')
+        return dx
+
+
+class _FromC8Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y):
+        y = _c(y)
+        N, G, H, W, _ = y.shape
+        x = torch.empty((N, G * 8, H, W), dtype=torch.float32, device=y.device)
+        _lib.check(_lib.lib().lsps_c8_to_nchw(_lib.ptr(y, BF16), _lib.ptr(x), N, G * 8, H * W, _lib.stream()), 'c8_to_nchw')
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        N, C, H, W = g.shape
+        dy = torch.empty((N, C // 8, H, W, 8), dtype=BF16, device=g.device)
+        _lib.check(_lib.lib().lsps_c8_from_nchw(_lib.ptr(g), _lib.ptr(dy, BF16), N, C, H * W, _lib.stream()), 'c8_from_nchw')
+        return dy
+
+
+def to_c8(x):
+    return x if is_c8(x) else _ToC8Fn.apply(x)
+
+
+def from_c8(x):
+    return _FromC8Fn.apply(x) if is_c8(x) else x
+
+
+class _AddC8Fn(torch.autograd.Function):
+    """a + b on C8 tensors (GaussianNoiseLayer, common_net.py:39-40); b is a constant."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        assert a.shape == b.shape
+        out = torch.empty_like(a)
+        _lib.check(_lib.lib().lsps_c8_add(_lib.ptr(a, BF16), _lib.ptr(b, BF16), _lib.ptr(out, BF16), a.numel(), _lib.stream()), 'c8_add')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def add_c8(a, b):
+    return _AddC8Fn.apply(a, b)
+
+
+class _ResBlockC8Fn(torch.autograd.Function):
+    """LeakyINSResBlock on C8 tensors as ONE autograd node (common_net.py:160-181): both convs run c8_conv3x3_kernel with
+    the InstanceNorm (+ LeakyReLU | + skip) in the epilogue; backward = norm-2 backward, two transposing-read weight
+    gradients, conv-2 dgrad through norm-1 + LeakyReLU backward in its epilogue, conv-1 dgrad + skip gradient.  Saved for
+    backward: x, a1, y (bf16) and the two rstd vectors."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2):
+        L = _lib.lib()
+        x, w1, w2 = _c(x), _c(w1), _c(w2)
+        N, G, H, W, _ = x.shape
+        C = G * 8
+        K = w1.shape[0]
+        assert w1.shape == (K, C, 3, 3) and w2.shape == (K, K, 3, 3) and K == C, "residual block: C -> C, 3x3"
+        st = _lib.stream()
+        ws, wsb = _lib.workspace(L.lsps_c8_conv3x3_workspace_bytes(C, K), x.device)
+        flops = 2.0 * N * K * H * W * C * 9
+        a1 = torch.empty_like(x)
+        y = torch.empty_like(x)
+        r1 = torch.empty(N * K, dtype=torch.float32, device=x.device)
+        r2 = torch.empty_like(r1)
+        with profiler.span(flops, 'c8_conv3x3_kernel'):
+            _lib.check(L.lsps_c8_conv3x3_in_fwd(_lib.ptr(x, BF16), _lib.ptr(w1), None, _lib.ptr(a1, BF16), _lib.ptr(r1), N, C, H, W, K,
+                                                LRELU_SLOPE, IN_EPS, ws, wsb, st), 'c8_conv3x3_in_fwd')
+        with profiler.span(flops, 'c8_conv3x3_kernel'):
+            _lib.check(L.lsps_c8_conv3x3_in_fwd(_lib.ptr(a1, BF16), _lib.ptr(w2), _lib.ptr(x, BF16), _lib.ptr(y, BF16), _lib.ptr(r2), N, K,
+                                                H, W, K, -1.0, IN_EPS, ws, wsb, st), 'c8_conv3x3_in_fwd')
+        ctx.save_for_backward(x, w1, w2, a1, y, r1, r2)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        x, w1, w2, a1, y, r1, r2 = ctx.saved_tensors
+        g = _c(g)
+        N, G, H, W, _ = x.shape
+        C = K = G * 8
+        st = _lib.stream()
+        flops = 2.0 * N * K * H * W * C * 9
+        ws, wsb = _lib.workspace(L.lsps_c8_conv3x3_workspace_bytes(C, K), x.device)
+        dh2 = torch.empty_like(y)
+        _lib.check(L.lsps_c8_inorm_bwd(_lib.ptr(g, BF16), _lib.ptr(y, BF16), _lib.ptr(x, BF16), _lib.ptr(r2), _lib.ptr(dh2, BF16), N, K,
+                                       H * W, -1.0, st), 'c8_inorm_bwd')
+        dw1 = dw2 = dx = None
+
+        def wgrad(inp, dy):
+            dw = torch.empty((K, C, 3, 3), dtype=torch.float32, device=x.device)
+            wsw, wswb = _lib.workspace(L.lsps_c8_conv3x3_wgrad_workspace_bytes(N, C, K), x.device)
+            with profiler.span(flops, 'c8_wgrad_kernel'):
+                _lib.check(L.lsps_c8_conv3x3_wgrad(_lib.ptr(inp, BF16), _lib.ptr(dy, BF16), _lib.ptr(dw), N, C, H, W, K, wsw, wswb, st),
+                           'c8_conv3x3_wgrad')
+            return dw
+        if ctx.needs_input_grad[2]:
+            dw2 = wgrad(a1, dh2)
+        dh1 = torch.empty_like(a1)
+        # the weight-gradient partial sums and the packed weights share the per-stream workspace: the pack happens inside the
+        # dgrad call below, after the weight-gradient launches that read the partials were enqueued on the same stream
+        ws, wsb = _lib.workspace(L.lsps_c8_conv3x3_workspace_bytes(C, K), x.device)
+        with profiler.span(flops, 'c8_conv3x3_kernel'):
+            _lib.check(L.lsps_c8_conv3x3_dgrad_inbwd(_lib.ptr(dh2, BF16), _lib.ptr(w2), _lib.ptr(a1, BF16), _lib.ptr(r1), _lib.ptr(dh1, BF16),
+                                                     N, K, H, W, K, LRELU_SLOPE, ws, wsb, st), 'c8_conv3x3_dgrad_inbwd')
+        if ctx.needs_input_grad[1]:
+            dw1 = wgrad(x, dh1)
+        if ctx.needs_input_grad[0]:
+            dx = dh2                                     # dh2 is dead: its storage receives dx
+            ws, wsb = _lib.workspace(L.lsps_c8_conv3x3_workspace_bytes(C, K), x.device)
+            with profiler.span(flops, 'c8_conv3x3_kernel'):
+                _lib.check(L.lsps_c8_conv3x3_dgrad_acc(_lib.ptr(dh1, BF16), _lib.ptr(w1), _lib.ptr(g, BF16), _lib.ptr(dx, BF16), N, C, H, W,
+                                                       K, ws, wsb, st), 'c8_conv3x3_dgrad_acc')
+        return dx, dw1, dw2
+
+
+def res_block_c8(x, w1, w2):
+    return _ResBlockC8Fn.apply(x, w1, w2)
+
+
 def res_block(x, w1, w2):
     """x + IN(conv3x3(LReLU(IN(conv3x3(x, w1))), w2)) — LeakyINSResBlock (common_net.py:160-181), one autograd node."""
     if x.shape[0] == 0:

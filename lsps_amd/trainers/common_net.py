@@ -97,9 +97,35 @@ class GaussianNoiseLayer(nn.Module):
     def forward(self, x, noise=None):
         if not self.training:
             return x
+        if ops.is_c8(x):                                  # bf16 trunk: the draw has x's (N, C, H, W)
+            N, G, H, W, _ = x.shape
+            if noise is None:
+                noise = torch.randn((N, G * 8, H, W), device=x.device, dtype=torch.float32)
+            return ops.add_c8(x, ops.to_c8(noise.detach()))
         if noise is None:
             noise = torch.randn(x.size(), device=x.device, dtype=x.dtype)
         return ops.axpy(x, noise, 1.0)
+
+
+def run_layers(layers, x, noise=None):
+    """Applies a sequence of layers.  In the bf16 math mode the LeakyINSResBlock chains (32x32 maps, channels % 128 == 0) run
+    on bf16 tensors in the channel-group layout of csrc/c8conv.h: `x` is converted once in front of the first such block,
+    stays in that layout through consecutive blocks and a GaussianNoiseLayer, and is converted back in front of any other
+    layer (the caller converts what it hands out: ops.from_c8)."""
+    for l in layers:
+        if isinstance(l, LeakyINSResBlock):
+            ch = l.model[0].weight.shape[0]
+            drop = l.dropout if (l.training and l.dropout > 0) else 0.0
+            if l.model[0].stride == 1 and l.model[0].weight.shape[1] == ch and ops.c8_block_ok(x, ch, drop):
+                x = ops.to_c8(x)
+            else:
+                x = ops.from_c8(x)
+            x = l(x)
+        elif isinstance(l, GaussianNoiseLayer):
+            x = l(x, noise)
+        else:
+            x = l(ops.from_c8(x))
+    return x
 
 
 class LeakyINSResBlock(nn.Module):
@@ -123,6 +149,10 @@ class LeakyINSResBlock(nn.Module):
         """`drop_mask` (tests): the keep mask ALREADY divided by 1-p; default: drawn here in training mode."""
         c1, c2 = self.model[0], self.model[3]
         dropping = self.dropout > 0 and (self.training or drop_mask is not None)
+        if ops.is_c8(x):
+            # bf16 trunk (math mode 'bf16'): activations stay in the channel-group layout between the blocks (run_layers)
+            assert not dropping and c1.stride == 1, "the C8 residual path has no dropout / stride"
+            return ops.res_block_c8(x, c1.weight, c2.weight)
         if not dropping and c1.stride == 1 and c1.weight.shape[0] == c1.weight.shape[1]:
             # one autograd node (fused conv + InstanceNorm entries, skip gradient added in the dgrad epilogue); also under
             # no_grad (dis_update's generator pass, evaluation): nothing is saved then, the fused forward is the same

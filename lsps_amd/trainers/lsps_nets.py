@@ -10,7 +10,7 @@ import torch.nn as nn
 from .common_net import *  # noqa: F401,F403
 from .common_net import (ACT_LRELU, ACT_NONE, ACT_TANH, Conv2d, ConvTranspose2d, GaussianNoiseLayer,
                          LeakyINSResBlock, LeakyINSResNeXtBlock, LeakyReLUConv2d, LeakyReLUConvTranspose2d,
-                         LeakyReLULinear, Linear, _Fused)
+                         LeakyReLULinear, Linear, _Fused, run_layers)
 from .. import ops
 from ..ops import ACT_SOFTPLUS
 
@@ -223,34 +223,38 @@ class SharedResGen(_Net):
         self.decode_A = decoder(tch, params['input_dim_a'])
         self.decode_B = decoder(tch, params['input_dim_b'])
 
+    # In the bf16 math mode the residual trunk (encoder blocks -> shared blocks + noise -> decoder blocks) runs on bf16
+    # tensors in the channel-group layout of csrc/c8conv.h (common_net.run_layers); what the methods return is f32 NCHW.
     def _enc_shared(self, h, noise):
-        for blk in list(self.enc_shared)[:-1]:
-            h = blk(h)
-        return self.enc_shared[-1](h, noise)
+        return run_layers(self.enc_shared, h, noise)
 
     def decode(self, z):
-        out = self.dec_shared(z)
-        return self.decode_A(out), self.decode_B(out)
+        out = run_layers(self.dec_shared, z)
+        return ops.from_c8(run_layers(self.decode_A, out)), ops.from_c8(run_layers(self.decode_B, out))
 
     def encode(self, x_A, x_B, noise_a=None, noise_b=None):
-        return self._enc_shared(self.encode_A(x_A), noise_a), self._enc_shared(self.encode_B(x_B), noise_b)
+        return (ops.from_c8(self._enc_shared(run_layers(self.encode_A, x_A), noise_a)),
+                ops.from_c8(self._enc_shared(run_layers(self.encode_B, x_B), noise_b)))
 
     def forward(self, x_A, x_B, noise=None):
-        out = torch.cat((self.encode_A(x_A), self.encode_B(x_B)), 0)
+        ha, hb = run_layers(self.encode_A, x_A), run_layers(self.encode_B, x_B)
+        if ops.is_c8(ha) != ops.is_c8(hb):
+            ha, hb = ops.from_c8(ha), ops.from_c8(hb)
+        out = torch.cat((ha, hb), 0)
         shared = self._enc_shared(out, noise)
-        out = self.dec_shared(shared)
-        out_A, out_B = self.decode_A(out), self.decode_B(out)
+        out = run_layers(self.dec_shared, shared)
+        out_A, out_B = ops.from_c8(run_layers(self.decode_A, out)), ops.from_c8(run_layers(self.decode_B, out))
         x_Aa, x_Ba = torch.split(out_A, x_A.size(0), dim=0)
         x_Ab, x_Bb = torch.split(out_B, x_A.size(0), dim=0)
-        return x_Aa, x_Ba, x_Ab, x_Bb, shared
+        return x_Aa, x_Ba, x_Ab, x_Bb, ops.from_c8(shared)
 
     def forward_a2b(self, x_A, noise=None):
-        shared = self._enc_shared(self.encode_A(x_A), noise)
-        return self.decode_B(self.dec_shared(shared)), shared
+        shared = self._enc_shared(run_layers(self.encode_A, x_A), noise)
+        return ops.from_c8(run_layers(self.decode_B, run_layers(self.dec_shared, shared))), ops.from_c8(shared)
 
     def forward_b2a(self, x_B, noise=None):
-        shared = self._enc_shared(self.encode_B(x_B), noise)
-        return self.decode_A(self.dec_shared(shared)), shared
+        shared = self._enc_shared(run_layers(self.encode_B, x_B), noise)
+        return ops.from_c8(run_layers(self.decode_A, run_layers(self.dec_shared, shared))), ops.from_c8(shared)
 
 
 class SharedResXGen(SharedResGen):
