@@ -172,6 +172,41 @@ int lsps_c8_conv3x3_wgrad(const void *x, const void *dy, float *dw, int N, int C
 int lsps_c8_inorm_bwd(const void *dout, const void *out, const void *residual /*nullable*/, const float *rstd, void *dy,
                       int N, int C, int HW, float slope, void *stream);
 
+/* ---- bf16 stride-2 3x3 convs on C8 tensors (BASELINE config 5) -------------------------------------------------------
+ * The 3x3 / stride 2 / pad 1 LeakyReLUConv2d layers (reference common_net.py:246-256; generator down-sampling
+ * lsps_nets.py:186-192, discriminator front + shared trunk lsps_nets.py:117-124 on 64x64 ... 2x2 output maps) and the
+ * 3x3 / stride 2 / pad 1 / output_padding 1 LeakyReLUConvTranspose2d layers (common_net.py:258-268, lsps_nets.py:222-225)
+ * on bf16 activations in the C8 layout above; weights f32 in the reference's layouts ((K,C,3,3) resp. (Ci,Co,3,3)), packed
+ * to bf16 per call (cached in the pack-cache scope); bias f32; f32 accumulation.  H, W (the LARGER map of the layer) are
+ * powers of two; channels: conv C % 64 == 0, K % 128 == 0; transposed conv Ci % 128 == 0, Co % 64 == 0 (see the _ok entries).
+ * slope < 0: no activation.  One workspace size covers the three directions of a layer.
+ *   lsps_c8_conv3x3s2_fwd       y [N,K,H/2,W/2] = LeakyReLU_slope(conv(x [N,C,H,W], w) + bias)       (common_net.py:250-252)
+ *   lsps_c8_conv3x3s2_dgrad     dx [N,C,H,W] from dy [N,K,H/2,W/2] (the gradient w.r.t. the conv's OUTPUT, activation undone)
+ *   lsps_c8_conv3x3s2_wgrad     dw [K,C,3,3] f32 (OVERWRITTEN)
+ *   lsps_c8_convT3x3s2_fwd      y [N,Co,2H,2W] = LeakyReLU_slope(convT(x [N,Ci,H,W], w) + bias)      (common_net.py:262-264)
+ *   lsps_c8_convT3x3s2_dgrad    dx [N,Ci,H,W] from dy [N,Co,2H,2W]
+ *   lsps_c8_convT3x3s2_wgrad    dw [Ci,Co,3,3] f32 (OVERWRITTEN)
+ *   lsps_c8_act_bwd_bias        g = dy * LeakyReLU'(y) from the layer's OUTPUT y (slope > 0 keeps the sign), db [C] = sum of g
+ *                               over n and pixels (db nullable); the C8 form of lsps_act_bwd_bias */
+int lsps_c8_conv3x3s2_ok(int N, int C, int H, int W, int K);
+int lsps_c8_convT3x3s2_ok(int N, int Ci, int H, int W, int Co);
+size_t lsps_c8_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K);     /* convT: (N, Co, 2H, 2W, Ci) */
+int lsps_c8_conv3x3s2_fwd(const void *x, const float *w, const float *bias /*nullable*/, void *y, int N, int C, int H, int W, int K,
+                          float slope, void *ws, size_t ws_bytes, void *stream);
+int lsps_c8_conv3x3s2_dgrad(const void *dy, const float *w, void *dx, int N, int C, int H, int W, int K,
+                            void *ws, size_t ws_bytes, void *stream);
+int lsps_c8_conv3x3s2_wgrad(const void *x, const void *dy, float *dw, int N, int C, int H, int W, int K,
+                            void *ws, size_t ws_bytes, void *stream);
+int lsps_c8_convT3x3s2_fwd(const void *x, const float *w, const float *bias /*nullable*/, void *y, int N, int Ci, int H, int W, int Co,
+                           float slope, void *ws, size_t ws_bytes, void *stream);
+int lsps_c8_convT3x3s2_dgrad(const void *dy, const float *w, void *dx, int N, int Ci, int H, int W, int Co,
+                             void *ws, size_t ws_bytes, void *stream);
+int lsps_c8_convT3x3s2_wgrad(const void *x, const void *dy, float *dw, int N, int Ci, int H, int W, int Co,
+                             void *ws, size_t ws_bytes, void *stream);
+size_t lsps_c8_act_bwd_bias_workspace_bytes(int N, int C);
+int lsps_c8_act_bwd_bias(const void *dy, const void *y, void *g, float *db /*nullable*/, int N, int C, int HW, float slope,
+                         void *ws, size_t ws_bytes, void *stream);
+
 /* ---- ConvTranspose2d: replaces nn.ConvTranspose2d forward/backward -------------------------
  * call sites: common_net.py:262 (LeakyReLUConvTranspose2d), lsps_nets.py:226-227 (1x1 output),
  *             lsps_nets.py:17-23 (Mapping).

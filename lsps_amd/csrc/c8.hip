@@ -1,7 +1,9 @@
 // C-ABI of the bf16 residual trunk in the channel-group layout "C8" (c8conv.h, c8wgrad.h): BASELINE config 5.
+#include <algorithm>
 #include "common.h"
 #include "c8conv.h"
 #include "c8wgrad.h"
+#include "c8s2.h"
 
 namespace lsps {
 
@@ -75,6 +77,185 @@ static int c8_run(const void *x, const float *w, const void *r, void *y, float *
     default: hipLaunchKernelGGL(c8_conv3x3_kernel<3>, grid, dim3(512), C8_LDS_BYTES, st, p); break;
   }
   LSPS_CHECK_LAUNCH("c8_conv3x3");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// stride-2 3x3 family (c8s2.h)
+// ------------------------------------------------------------------------------------------------------------------
+static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// pixel tiles of the SMALL map: `px` consecutive (n, p, q)
+static bool c8s2_tile(int N, int P, int Q, int px, int *TI, int *TR, int *tpi, int *ntiles) {
+  const int PQ = P * Q;
+  if (PQ >= px) {
+    if (Q > px) return false;
+    *TI = 1;
+    *TR = px / Q;
+    *tpi = P / *TR;
+    *ntiles = N * *tpi;
+  } else {
+    *TI = px / PQ;
+    *TR = P;
+    *tpi = 1;
+    *ntiles = (N + *TI - 1) / *TI;
+  }
+  return true;
+}
+
+// forward-direction geometry: NJ = 2 (256-pixel tiles) when the de-interleaved image of a tile fits the stage, else NJ = 1
+static int c8s2_fwd_nj(int N, int Cx, int H, int W, int M, C8S2Params *p) {
+  if (N <= 0 || H < 2 || W < 2 || !pow2(H) || !pow2(W) || (Cx & 15) || (M & 127)) return 0;
+  const int P = H / 2, Q = W / 2;
+  for (int nj = 2; nj >= 1; --nj) {
+    int TI, TR, tpi, nt;
+    if (!c8s2_tile(N, P, Q, 128 * nj, &TI, &TR, &tpi, &nt)) continue;
+    const long bunits = 2l * TI * (2 * TR + 1) * (2 * Q + 1);
+    const long bytes = (long)TI * (Cx >> 3) * H * W * 16;
+    if (bunits > C8S2F_BPIECES * 64 || bytes >= (1l << 31)) continue;
+    if (p) {
+      p->H = H; p->W = W; p->P = P; p->Q = Q;
+      p->TI = TI; p->TR = TR; p->tiles_per_img = tpi; p->ntiles = nt;
+    }
+    return nj;
+  }
+  return 0;
+}
+
+static bool c8s2_tr_geom(int N, int Cx, int H, int W, int M, C8S2Params *p) {      // H x W = the BIG (output) map
+  if (N <= 0 || H < 2 || W < 2 || !pow2(H) || !pow2(W) || (Cx & 31) || (M & 63)) return false;
+  const int P = H / 2, Q = W / 2;
+  int TI, TR, tpi, nt;
+  if (!c8s2_tile(N, P, Q, 256, &TI, &TR, &tpi, &nt)) return false;
+  const long bunits = 2l * TI * (TR + 1) * (Q + 1);
+  const long bytes = (long)TI * (Cx >> 3) * P * Q * 16;
+  if (bunits > 1152 || bytes >= (1l << 31) || (long)(M >> 3) * H * W * 16 >= (1l << 40)) return false;
+  if (p) {
+    p->H = H; p->W = W; p->P = P; p->Q = Q;
+    p->TI = TI; p->TR = TR; p->tiles_per_img = tpi; p->ntiles = nt;
+  }
+  return true;
+}
+
+static bool c8s2_wgrad_geom(int N, int K, int C, int H, int W, C8S2WParams *p) {   // small [N][K][H/2][W/2], big [N][C][H][W]
+  if (N <= 0 || H < 2 || W < 2 || !pow2(H) || !pow2(W) || (K & 127) || (C & 63)) return false;
+  const int P = H / 2, Q = W / 2;
+  int TI, TR, cpi, nc;
+  if (!c8s2_tile(N, P, Q, 64, &TI, &TR, &cpi, &nc)) return false;
+  const int blk = (2 * TR + 1) * (2 * Q + 1);
+  int bplane = TI * blk;
+  while ((bplane & 7) != 4) ++bplane;                            // plane stride = 64 (mod 128) bytes: bank quarter rotation
+  if (8 * bplane > C8S2W_BPIECES * 64) return false;
+  if ((long)TI * (C >> 3) * H * W * 16 >= (1l << 31) || (long)TI * (K >> 3) * P * Q * 16 >= (1l << 31)) return false;
+  const int tiles = (K >> 7) * (C >> 6);
+  int s = (2 * 256 + tiles - 1) / tiles;
+  s = (s + 7) / 8 * 8;                                           // a split lives on ONE XCD (workgroup -> tile mapping): use all 8
+  if (s > nc) s = nc;
+  const int cps = (nc + s - 1) / s;
+  s = (nc + cps - 1) / cps;
+  if (p) {
+    p->N = N; p->K = K; p->C = C; p->H = H; p->W = W; p->P = P; p->Q = Q;
+    p->TIW = TI; p->TRW = TR; p->chunks_per_img = cpi; p->nchunks = nc;
+    p->splits = s; p->chunks_per_split = cps; p->bplane = bplane;
+  }
+  return true;
+}
+
+static int c8s2_pack(const float *w, int M, int C, long sm, long sc, int BM, void *ws, size_t ws_bytes, hipStream_t st,
+                     const unsigned short **out) {
+  const size_t need = (size_t)M * C * 9 * sizeof(unsigned short);
+  bool hit = false;
+  void *slot = pack_cache_slot(w, /*tag: C8 stride-2 layout*/ (1 << 23) + BM, M, C, sm, sc, need, &hit, st);
+  if (!slot) {
+    if (ws_bytes < need || !ws) {
+      set_error("c8 stride-2 conv: workspace too small (%zu < %zu)", ws_bytes, need);
+      return LSPS_E_ARG;
+    }
+    slot = ws;
+  }
+  *out = (const unsigned short *)slot;
+  if (hit) return 0;
+  C8S2Pack pp;
+  pp.W = w;
+  pp.Wq = (unsigned short *)slot;
+  pp.M = M; pp.C = C; pp.BM = BM; pp.sm = sm; pp.sc = sc;
+  hipLaunchKernelGGL(c8s2_pack_kernel, dim3(ceil_div((long)M * C * 9, 256)), dim3(256), 0, st, pp);
+  LSPS_CHECK_LAUNCH("c8s2_pack");
+  return 0;
+}
+
+// small[n][m] = act(bias + sum Wt[m][kk][r][s] big[n][kk][2p+r-1][2q+s-1]);  W element (m, kk, t) at m*sm + kk*sc + t
+static int c8s2_run_fwd(const void *big, const float *w, long sm, long sc, const float *bias, void *small, int N, int Cx, int H, int W,
+                        int M, float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+  C8S2Params p;
+  const int nj = c8s2_fwd_nj(N, Cx, H, W, M, &p);
+  if (!nj) {
+    set_error("c8 stride-2 conv (forward direction): unsupported geometry N=%d C=%d %dx%d M=%d", N, Cx, H, W, M);
+    return LSPS_E_ARG;
+  }
+  const unsigned short *wq = nullptr;
+  if (int rc = c8s2_pack(w, M, Cx, sm, sc, 128, ws, ws_bytes, st, &wq)) return rc;
+  p.X = (const unsigned short *)big;
+  p.Wq = wq;
+  p.bias = bias;
+  p.Y = (unsigned short *)small;
+  p.N = N; p.Cx = Cx; p.M = M;
+  p.lrelu = slope >= 0.f ? slope : 1.f;
+  const dim3 grid((p.ntiles + 7) / 8 * 8 * (M >> 7));
+  if (nj == 2) {
+    if (int rc = lds_optin(reinterpret_cast<const void *>(c8s2_fwd_kernel<2>), C8S2F_LDS_BYTES, "c8s2_fwd")) return rc;
+    hipLaunchKernelGGL(c8s2_fwd_kernel<2>, grid, dim3(512), C8S2F_LDS_BYTES, st, p);
+  } else {
+    if (int rc = lds_optin(reinterpret_cast<const void *>(c8s2_fwd_kernel<1>), C8S2F_LDS_BYTES, "c8s2_fwd")) return rc;
+    hipLaunchKernelGGL(c8s2_fwd_kernel<1>, grid, dim3(512), C8S2F_LDS_BYTES, st, p);
+  }
+  LSPS_CHECK_LAUNCH("c8s2_fwd");
+  return 0;
+}
+
+// big[n][m][2p+r-1][2q+s-1] += Wt[m][kk][r][s] small[n][kk][p][q] (+ bias, activation); H x W = the big map
+static int c8s2_run_tr(const void *small, const float *w, long sm, long sc, const float *bias, void *big, int N, int Cx, int H, int W,
+                       int M, float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+  C8S2Params p;
+  if (!c8s2_tr_geom(N, Cx, H, W, M, &p)) {
+    set_error("c8 stride-2 conv (transposed direction): unsupported geometry N=%d C=%d -> %dx%d M=%d", N, Cx, H, W, M);
+    return LSPS_E_ARG;
+  }
+  const unsigned short *wq = nullptr;
+  if (int rc = c8s2_pack(w, M, Cx, sm, sc, 64, ws, ws_bytes, st, &wq)) return rc;
+  p.X = (const unsigned short *)small;
+  p.Wq = wq;
+  p.bias = bias;
+  p.Y = (unsigned short *)big;
+  p.N = N; p.Cx = Cx; p.M = M;
+  p.lrelu = slope >= 0.f ? slope : 1.f;
+  if (int rc = lds_optin(reinterpret_cast<const void *>(c8s2_tr_kernel), C8S2T_LDS_BYTES, "c8s2_tr")) return rc;
+  hipLaunchKernelGGL(c8s2_tr_kernel, dim3((p.ntiles + 7) / 8 * 8 * (M >> 6)), dim3(512), C8S2T_LDS_BYTES, st, p);
+  LSPS_CHECK_LAUNCH("c8s2_tr");
+  return 0;
+}
+
+static int c8s2_run_wgrad(const void *small, const void *big, float *dw, int N, int K, int C, int H, int W, void *ws, size_t ws_bytes,
+                          hipStream_t st) {
+  C8S2WParams p;
+  if (!c8s2_wgrad_geom(N, K, C, H, W, &p)) {
+    set_error("c8 stride-2 weight gradient: unsupported geometry N=%d K=%d C=%d %dx%d", N, K, C, H, W);
+    return LSPS_E_ARG;
+  }
+  const size_t need = (size_t)p.splits * 9 * K * C * sizeof(float);
+  if (!ws || ws_bytes < need) {
+    set_error("c8 stride-2 weight gradient: workspace too small (%zu < %zu)", ws_bytes, need);
+    return LSPS_E_ARG;
+  }
+  p.S = (const unsigned short *)small;
+  p.B = (const unsigned short *)big;
+  p.part = (float *)ws;
+  if (int rc = lds_optin(reinterpret_cast<const void *>(c8s2_wgrad_kernel), C8S2W_LDS_BYTES, "c8s2_wgrad")) return rc;
+  const int tiles = (K >> 7) * (C >> 6);
+  hipLaunchKernelGGL(c8s2_wgrad_kernel, dim3((p.splits + 7) / 8 * 8 * tiles), dim3(512), C8S2W_LDS_BYTES, st, p);
+  LSPS_CHECK_LAUNCH("c8s2_wgrad");
+  hipLaunchKernelGGL(c8_wgrad_reduce_kernel, dim3(ceil_div((long)K * C, 256)), dim3(256), 0, st, (const float *)p.part, dw, K * C, p.splits);
+  LSPS_CHECK_LAUNCH("c8s2_wgrad_reduce");
   return 0;
 }
 
@@ -197,6 +378,92 @@ int lsps_c8_inorm_bwd(const void *dout, const void *out, const void *residual, c
   hipLaunchKernelGGL(c8_inorm_bwd_kernel, dim3(N * (C >> 3)), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)dout,
                      (const unsigned short *)out, (const unsigned short *)residual, rstd, (unsigned short *)dy, HW, slope);
   LSPS_CHECK_LAUNCH("c8_inorm_bwd");
+  return 0;
+}
+
+// ---- stride-2 3x3 family ------------------------------------------------------------------------------------------
+int lsps_c8_conv3x3s2_ok(int N, int C, int H, int W, int K) {
+  return c8s2_fwd_nj(N, C, H, W, K, nullptr) && c8s2_tr_geom(N, K, H, W, C, nullptr) && c8s2_wgrad_geom(N, K, C, H, W, nullptr) ? 1 : 0;
+}
+
+int lsps_c8_convT3x3s2_ok(int N, int Ci, int H, int W, int Co) {      // x [N, Ci, H, W] -> y [N, Co, 2H, 2W]
+  return c8s2_tr_geom(N, Ci, 2 * H, 2 * W, Co, nullptr) && c8s2_fwd_nj(N, Co, 2 * H, 2 * W, Ci, nullptr) &&
+                 c8s2_wgrad_geom(N, Ci, Co, 2 * H, 2 * W, nullptr)
+             ? 1
+             : 0;
+}
+
+// packed weights (forward / transposed direction) or the weight gradient's partial sums, whichever is larger; H x W = big map
+size_t lsps_c8_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K) {
+  size_t need = (size_t)C * K * 9 * sizeof(unsigned short);
+  C8S2WParams p;
+  if (c8s2_wgrad_geom(N, K, C, H, W, &p)) need = std::max(need, (size_t)p.splits * 9 * K * C * sizeof(float));
+  return align_up(need, 256);
+}
+
+int lsps_c8_conv3x3s2_fwd(const void *x, const float *w, const float *bias, void *y, int N, int C, int H, int W, int K, float slope,
+                          void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(x && w && y, "c8_conv3x3s2_fwd: null pointer");
+  return c8s2_run_fwd(x, w, (long)C * 9, 9, bias, y, N, C, H, W, K, slope, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_c8_conv3x3s2_dgrad(const void *dy, const float *w, void *dx, int N, int C, int H, int W, int K, void *ws, size_t ws_bytes,
+                            void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(dy && w && dx, "c8_conv3x3s2_dgrad: null pointer");
+  return c8s2_run_tr(dy, w, 9, (long)C * 9, nullptr, dx, N, K, H, W, C, -1.f, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_c8_conv3x3s2_wgrad(const void *x, const void *dy, float *dw, int N, int C, int H, int W, int K, void *ws, size_t ws_bytes,
+                            void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(x && dy && dw, "c8_conv3x3s2_wgrad: null pointer");
+  return c8s2_run_wgrad(dy, x, dw, N, K, C, H, W, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_c8_convT3x3s2_fwd(const void *x, const float *w, const float *bias, void *y, int N, int Ci, int H, int W, int Co, float slope,
+                           void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(x && w && y, "c8_convT3x3s2_fwd: null pointer");
+  return c8s2_run_tr(x, w, 9, (long)Co * 9, bias, y, N, Ci, 2 * H, 2 * W, Co, slope, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_c8_convT3x3s2_dgrad(const void *dy, const float *w, void *dx, int N, int Ci, int H, int W, int Co, void *ws, size_t ws_bytes,
+                             void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(dy && w && dx, "c8_convT3x3s2_dgrad: null pointer");
+  return c8s2_run_fwd(dy, w, (long)Co * 9, 9, nullptr, dx, N, Co, 2 * H, 2 * W, Ci, -1.f, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_c8_convT3x3s2_wgrad(const void *x, const void *dy, float *dw, int N, int Ci, int H, int W, int Co, void *ws, size_t ws_bytes,
+                             void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(x && dy && dw, "c8_convT3x3s2_wgrad: null pointer");
+  return c8s2_run_wgrad(x, dy, dw, N, Ci, Co, 2 * H, 2 * W, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t lsps_c8_act_bwd_bias_workspace_bytes(int N, int C) { return align_up((size_t)std::min(N, 64) * C * sizeof(float), 256); }
+
+int lsps_c8_act_bwd_bias(const void *dy, const void *y, void *g, float *db, int N, int C, int HW, float slope, void *ws, size_t ws_bytes,
+                         void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(dy && y && g && N > 0 && C > 0 && (C & 7) == 0 && HW > 0, "c8_act_bwd_bias: bad arguments (C %% 8 == 0)");
+  LSPS_CHECK_ARG(slope >= 0.f, "c8_act_bwd_bias: LeakyReLU slope >= 0");
+  // enough workgroups to fill the chip: (C / 8) x splits >= ~1024
+  int splits = std::min(N, std::max(1, 1024 / (C >> 3)));
+  splits = std::min(splits, 64);
+  const int ips = (N + splits - 1) / splits;
+  splits = (N + ips - 1) / ips;
+  LSPS_CHECK_ARG(ws && ws_bytes >= (size_t)splits * C * sizeof(float), "c8_act_bwd_bias: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(c8_act_bwd_bias_kernel, dim3(C >> 3, splits), dim3(256), 0, st, (const unsigned short *)dy, (const unsigned short *)y,
+                     (unsigned short *)g, (float *)ws, N, C, HW, ips, slope);
+  LSPS_CHECK_LAUNCH("c8_act_bwd_bias");
+  if (db) {
+    hipLaunchKernelGGL(c8_colsum_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)ws, db, C, splits);
+    LSPS_CHECK_LAUNCH("c8_colsum");
+  }
   return 0;
 }
 

@@ -667,6 +667,151 @@ def add_c8(a, b):
     return _AddC8Fn.apply(a, b)
 
 
+def _c8_enabled():
+    import os
+    return get_math_mode() == 'bf16' and os.environ.get('LSPS_C8', '1') != '0'
+
+
+def c8_conv_s2_ok(x, w, stride, pad):
+    """Can LeakyReLUConv2d(C, K, 3, stride 2, pad 1) on `x` (f32 NCHW or C8) run on the C8 stride-2 kernels (csrc/c8s2.h)?
+    bf16 math mode only; LSPS_C8=0 / LSPS_C8S2=0 switch it off."""
+    import os
+    if not _c8_enabled() or os.environ.get('LSPS_C8S2', '1') == '0' or stride != 2 or pad != 1 or tuple(w.shape[2:]) != (3, 3):
+        return False
+    if is_c8(x):
+        N, G, H, W, _ = x.shape
+        C = G * 8
+    elif x.dim() == 4:
+        N, C, H, W = x.shape
+    else:
+        return False
+    return N > 0 and C == w.shape[1] and _lib.lib().lsps_c8_conv3x3s2_ok(N, C, H, W, w.shape[0]) == 1
+
+
+def c8_convT_s2_ok(x, w, stride, pad, outpad):
+    import os
+    if not _c8_enabled() or os.environ.get('LSPS_C8S2', '1') == '0' or stride != 2 or pad != 1 or outpad != 1 or \
+            tuple(w.shape[2:]) != (3, 3):
+        return False
+    if is_c8(x):
+        N, G, H, W, _ = x.shape
+        C = G * 8
+    elif x.dim() == 4:
+        N, C, H, W = x.shape
+    else:
+        return False
+    return N > 0 and C == w.shape[0] and _lib.lib().lsps_c8_convT3x3s2_ok(N, C, H, W, w.shape[1]) == 1
+
+
+def _c8_act_backward(L, dy, y, slope, want_db, channels, st):
+    """g = dy * LeakyReLU'(y) from the layer's OUTPUT (+ the bias gradient in the same pass) on C8 tensors."""
+    if slope < 0:
+        assert not want_db, "bias gradient of an activation-free C8 conv: not needed by any layer"
+        return dy, None
+    N, G, H, W, _ = dy.shape
+    g = torch.empty_like(dy)
+    db = torch.empty(channels, dtype=torch.float32, device=dy.device) if want_db else None
+    ws, wsb = _lib.workspace(L.lsps_c8_act_bwd_bias_workspace_bytes(N, channels), dy.device)
+    _lib.check(L.lsps_c8_act_bwd_bias(_lib.ptr(dy, BF16), _lib.ptr(y, BF16), _lib.ptr(g, BF16), _lib.ptr(db), N, channels, H * W,
+                                      slope, ws, wsb, st), 'c8_act_bwd_bias')
+    return g, db
+
+
+class _ConvS2C8Fn(torch.autograd.Function):
+    """LeakyReLUConv2d(C, K, 3, 2, 1) (common_net.py:246-256) on a C8 tensor: x [N][C/8][H][W][8] -> [N][K/8][H/2][W/2][8]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope):
+        L = _lib.lib()
+        x, w = _c(x), _c(w)
+        N, G, H, W, _ = x.shape
+        C, K = G * 8, w.shape[0]
+        y = torch.empty((N, K // 8, H // 2, W // 2, 8), dtype=BF16, device=x.device)
+        ws, wsb = _lib.workspace(L.lsps_c8_conv3x3s2_workspace_bytes(N, C, H, W, K), x.device)
+        with profiler.span(2.0 * N * K * (H // 2) * (W // 2) * C * 9, 'c8s2_fwd_kernel'):
+            _lib.check(L.lsps_c8_conv3x3s2_fwd(_lib.ptr(x, BF16), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y, BF16), N, C, H, W, K, slope,
+                                               ws, wsb, _lib.stream()), 'c8_conv3x3s2_fwd')
+        ctx.geom = (N, C, H, W, K, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if slope >= 0 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w, y = ctx.saved_tensors
+        N, C, H, W, K, slope = ctx.geom
+        dy = _c(dy)
+        st = _lib.stream()
+        flops = 2.0 * N * K * (H // 2) * (W // 2) * C * 9
+        dx = dw = db = None
+        g, db = _c8_act_backward(L, dy, y, slope, ctx.has_bias and ctx.needs_input_grad[2], K, st)
+        ws, wsb = _lib.workspace(L.lsps_c8_conv3x3s2_workspace_bytes(N, C, H, W, K), x.device)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            with profiler.span(flops, 'c8s2_wgrad_kernel'):
+                _lib.check(L.lsps_c8_conv3x3s2_wgrad(_lib.ptr(x, BF16), _lib.ptr(g, BF16), _lib.ptr(dw), N, C, H, W, K, ws, wsb, st),
+                           'c8_conv3x3s2_wgrad')
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            with profiler.span(flops, 'c8s2_tr_kernel'):
+                _lib.check(L.lsps_c8_conv3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(dx, BF16), N, C, H, W, K, ws, wsb, st),
+                           'c8_conv3x3s2_dgrad')
+        return dx, dw, db, None
+
+
+def conv3x3s2_c8(x, w, b=None, slope=LRELU_SLOPE):
+    return _ConvS2C8Fn.apply(x, w, b, float(slope))
+
+
+class _ConvTS2C8Fn(torch.autograd.Function):
+    """LeakyReLUConvTranspose2d(Ci, Co, 3, 2, 1, 1) (common_net.py:258-268) on a C8 tensor:
+    x [N][Ci/8][H][W][8] -> [N][Co/8][2H][2W][8]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope):
+        L = _lib.lib()
+        x, w = _c(x), _c(w)
+        N, G, H, W, _ = x.shape
+        Ci, Co = G * 8, w.shape[1]
+        y = torch.empty((N, Co // 8, 2 * H, 2 * W, 8), dtype=BF16, device=x.device)
+        ws, wsb = _lib.workspace(L.lsps_c8_conv3x3s2_workspace_bytes(N, Co, 2 * H, 2 * W, Ci), x.device)
+        with profiler.span(2.0 * N * Ci * H * W * Co * 9, 'c8s2_tr_kernel'):
+            _lib.check(L.lsps_c8_convT3x3s2_fwd(_lib.ptr(x, BF16), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y, BF16), N, Ci, H, W, Co, slope,
+                                                ws, wsb, _lib.stream()), 'c8_convT3x3s2_fwd')
+        ctx.geom = (N, Ci, H, W, Co, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if slope >= 0 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w, y = ctx.saved_tensors
+        N, Ci, H, W, Co, slope = ctx.geom
+        dy = _c(dy)
+        st = _lib.stream()
+        flops = 2.0 * N * Ci * H * W * Co * 9
+        dx = dw = db = None
+        g, db = _c8_act_backward(L, dy, y, slope, ctx.has_bias and ctx.needs_input_grad[2], Co, st)
+        ws, wsb = _lib.workspace(L.lsps_c8_conv3x3s2_workspace_bytes(N, Co, 2 * H, 2 * W, Ci), x.device)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            with profiler.span(flops, 'c8s2_wgrad_kernel'):
+                _lib.check(L.lsps_c8_convT3x3s2_wgrad(_lib.ptr(x, BF16), _lib.ptr(g, BF16), _lib.ptr(dw), N, Ci, H, W, Co, ws, wsb, st),
+                           'c8_convT3x3s2_wgrad')
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            with profiler.span(flops, 'c8s2_fwd_kernel'):
+                _lib.check(L.lsps_c8_convT3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(dx, BF16), N, Ci, H, W, Co, ws, wsb, st),
+                           'c8_convT3x3s2_dgrad')
+        return dx, dw, db, None
+
+
+def convT3x3s2_c8(x, w, b=None, slope=LRELU_SLOPE):
+    return _ConvTS2C8Fn.apply(x, w, b, float(slope))
+
+
 class _ResBlockC8Fn(torch.autograd.Function):
     """LeakyINSResBlock on C8 tensors as ONE autograd node (common_net.py:160-181): both convs run c8_conv3x3_kernel with
     the InstanceNorm (+ LeakyReLU | + skip) in the epilogue; backward = norm-2 backward, two transposing-read weight

@@ -108,10 +108,11 @@ class GaussianNoiseLayer(nn.Module):
 
 
 def run_layers(layers, x, noise=None):
-    """Applies a sequence of layers.  In the bf16 math mode the LeakyINSResBlock chains (32x32 maps, channels % 128 == 0) run
-    on bf16 tensors in the channel-group layout of csrc/c8conv.h: `x` is converted once in front of the first such block,
-    stays in that layout through consecutive blocks and a GaussianNoiseLayer, and is converted back in front of any other
-    layer (the caller converts what it hands out: ops.from_c8)."""
+    """Applies a sequence of layers.  In the bf16 math mode the layers that have kernels for bf16 tensors in the
+    channel-group layout of csrc/c8conv.h / c8s2.h — LeakyINSResBlock chains on 32x32 maps, the 3x3 / stride-2
+    LeakyReLUConv2d and LeakyReLUConvTranspose2d layers, GaussianNoiseLayer — run on such tensors: `x` is converted in front
+    of the first of them, stays in that layout through consecutive ones and is converted back in front of any other layer
+    (the caller converts what it hands out: ops.from_c8)."""
     for l in layers:
         if isinstance(l, LeakyINSResBlock):
             ch = l.model[0].weight.shape[0]
@@ -121,6 +122,12 @@ def run_layers(layers, x, noise=None):
             else:
                 x = ops.from_c8(x)
             x = l(x)
+        elif isinstance(l, LeakyReLUConv2d):
+            c = l.model[0]
+            x = l(ops.to_c8(x) if ops.c8_conv_s2_ok(x, c.weight, c.stride, c.padding) else ops.from_c8(x))
+        elif isinstance(l, LeakyReLUConvTranspose2d):
+            c = l.model[0]
+            x = l(ops.to_c8(x) if ops.c8_convT_s2_ok(x, c.weight, c.stride, c.padding, c.output_padding) else ops.from_c8(x))
         elif isinstance(l, GaussianNoiseLayer):
             x = l(x, noise)
         else:
@@ -178,7 +185,10 @@ class LeakyReLUConv2d(nn.Module):
         self.model.apply(gaussian_weights_init)
 
     def forward(self, x):
-        return self.model[0](x)
+        c = self.model[0]
+        if ops.is_c8(x):                                  # bf16 math mode, 3x3 / stride 2 (run_layers decides): csrc/c8s2.h
+            return ops.conv3x3s2_c8(x, c.weight, c.bias, LRELU_SLOPE)
+        return c(x)
 
 
 class LeakyReLUConvTranspose2d(nn.Module):
@@ -192,7 +202,10 @@ class LeakyReLUConvTranspose2d(nn.Module):
         self.model.apply(gaussian_weights_init)
 
     def forward(self, x):
-        return self.model[0](x)
+        c = self.model[0]
+        if ops.is_c8(x):
+            return ops.convT3x3s2_c8(x, c.weight, c.bias, LRELU_SLOPE)
+        return c(x)
 
 
 class LeakyReLULinear(nn.Module):

@@ -136,11 +136,15 @@ class SharedDis(_Net):
         return nn.Sequential(*layers), discrim, post
 
     def _trunk(self, f):
-        """model_S on `f` [N][C][H][W].  The trunk is a chain of 3x3 / stride-2 LeakyReLUConv2d on 16x16 ... 2x2 maps: where
-        the geometry allows (N % 4 == 0, channels % 128 == 0, even maps, f32 math) it runs in batch-innermost layout on
-        the plain-GEMM kernels of csrc/chwn.hip (one transpose in, one out); otherwise layer by layer in NCHW."""
+        """model_S on `f` ([N][C][H][W] f32, or a C8 tensor from the fronts in the bf16 math mode) -> f32 [N][C'][h][w].
+        The trunk is a chain of 3x3 / stride-2 LeakyReLUConv2d on 16x16 ... 2x2 maps.  bf16 math mode: on bf16 tensors in the
+        channel-group layout (csrc/c8s2.h, common_net.run_layers).  f32: where the geometry allows (N % 4 == 0, channels
+        % 128 == 0, even maps) in batch-innermost layout on the plain-GEMM kernels of csrc/chwn.hip (one transpose in, one
+        out); otherwise layer by layer in NCHW."""
         import os
         layers = list(self.model_S)
+        if ops.is_c8(f) or ops.get_math_mode() == 'bf16':
+            return ops.from_c8(run_layers(layers, f))
         N, C, H, W = f.shape
         # below ~96 samples the 128-wide batch tile of the GEMM is mostly padding (dis.feats on 16 samples: slower than NCHW)
         ok = len(layers) > 0 and N >= int(os.environ.get('LSPS_CHWN_MIN_N', '96')) and os.environ.get('LSPS_CHWN', '1') != '0'
@@ -160,8 +164,14 @@ class SharedDis(_Net):
             t = ops.conv3x3s2_chwn(t, conv.weight, conv.bias, ops.ACT_LRELU, ops.LRELU_SLOPE)
         return ops.chwn_to_nchw(t)
 
+    @staticmethod
+    def _cat0(a, b):
+        if ops.is_c8(a) != ops.is_c8(b):
+            a, b = ops.from_c8(a), ops.from_c8(b)
+        return torch.cat((a, b), 0)
+
     def _regress(self, front, x):
-        post = self.Post(self._trunk(front(x))).squeeze()
+        post = self.Post(self._trunk(run_layers(front, x))).squeeze()
         return post, post, post
 
     def regress_a(self, x_A):
@@ -171,12 +181,12 @@ class SharedDis(_Net):
         return self._regress(self.model_B, x_B)
 
     def feats(self, x_aa, x_ba, x_ab, x_bb):
-        f = torch.cat((self.model_A(torch.cat((x_aa, x_ba), 0)), self.model_B(torch.cat((x_ab, x_bb), 0))), 0)
+        f = self._cat0(run_layers(self.model_A, torch.cat((x_aa, x_ba), 0)), run_layers(self.model_B, torch.cat((x_ab, x_bb), 0)))
         f = self._trunk(f)
         return torch.split(f, f.size(0) // 4, dim=0)
 
     def forward(self, x_A, x_B, second_feats=False):
-        f = self._trunk(torch.cat((self.model_A(x_A), self.model_B(x_B)), 0))
+        f = self._trunk(self._cat0(run_layers(self.model_A, x_A), run_layers(self.model_B, x_B)))
         out_D = self.D(f)
         feats_A, feats_B = torch.split(f, f.size(0) // 2, dim=0)
         out_D_A, out_D_B = torch.split(out_D, out_D.size(0) // 2, dim=0)

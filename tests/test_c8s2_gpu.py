@@ -1,0 +1,129 @@
+"""bf16 stride-2 3x3 convs / transposed convs on C8 tensors (csrc/c8s2.h; BASELINE config 5), through the C-ABI.
+
+Every entry against an f64 reference computed from the SAME bf16-rounded operands (as tests/test_c8_gpu.py): the bound
+isolates the kernel (f32 accumulation order + one bf16 rounding of the result).  Geometries: every stride-2 layer of the
+shipped nets (generator down / up-sampling, discriminator front conv and trunk: 64x64 ... 2x2 output maps) with batch
+sizes that leave ragged last tiles (tiles of 4 / 16 / 32 / 64 whole images on the small maps)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_c8_gpu import BF, C8_TOL, _env, _from_c8, _need_gpu, _rand, _rb, _rel, _to_c8
+
+pytestmark = pytest.mark.gpu
+
+# (N, C, H = W of the conv INPUT, K)
+CONV_GEOMS = [(3, 64, 128, 128),        # generator down 1            (lsps_nets.py:186-188)
+              (3, 128, 64, 256),        # generator down 2
+              (5, 64, 64, 128),         # discriminator front conv 2   (lsps_nets.py:121-123)
+              (5, 128, 32, 256),        # trunk layer 1 .. 4           (lsps_nets.py:131-133)
+              (6, 256, 16, 512),
+              (21, 512, 8, 1024),
+              (70, 1024, 4, 2048),
+              (1, 64, 16, 128)]
+# (N, Ci, H = W of the transposed conv INPUT, Co)
+CONVT_GEOMS = [(3, 256, 32, 128), (3, 128, 64, 64), (5, 128, 4, 64), (19, 128, 2, 64)]
+
+
+def _ws(L, _lib, dev, N, C, H, K):
+    return _lib.workspace(L.lsps_c8_conv3x3s2_workspace_bytes(N, C, H, H, K), dev)
+
+
+@pytest.mark.parametrize("N,C,H,K", CONV_GEOMS)
+def test_c8_conv3x3s2_forward_dgrad_wgrad(N, C, H, K):
+    _need_gpu()
+    _lib, L, dev, st = _env()
+    assert L.lsps_c8_conv3x3s2_ok(N, C, H, H, K) == 1
+    g = torch.Generator().manual_seed(N * 7 + C + H + K)
+    x = _rand(g, N, C, H, H)
+    w = _rand(g, K, C, 3, 3, scale=1.0 / (3.0 * C ** 0.5))
+    b = _rand(g, K, scale=0.5)
+    P = H // 2
+    dy = _rand(g, N, K, P, P)
+    xd, wd, bd, dyd = _rb(x).double().cpu(), _rb(w).double().cpu(), b.double().cpu(), _rb(dy).double().cpu()
+    xc, dyc = _to_c8(x), _to_c8(dy)
+    ws, wsb = _ws(L, _lib, dev, N, C, H, K)
+
+    y = torch.empty((N, K // 8, P, P, 8), dtype=BF, device=dev)
+    for slope in (0.01, -1.0):
+        y.fill_(7.0)
+        _lib.check(L.lsps_c8_conv3x3s2_fwd(xc.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, C, H, H, K, slope, ws, wsb, st), 'fwd')
+        ref = F.conv2d(xd, wd, bd, stride=2, padding=1)
+        if slope >= 0:
+            ref = F.leaky_relu(ref, slope)
+        assert _rel(_from_c8(y), ref) <= C8_TOL, ('fwd', slope)
+    _lib.check(L.lsps_c8_conv3x3s2_fwd(xc.data_ptr(), w.data_ptr(), None, y.data_ptr(), N, C, H, H, K, -1.0, ws, wsb, st), 'fwd nobias')
+    assert _rel(_from_c8(y), F.conv2d(xd, wd, None, stride=2, padding=1)) <= C8_TOL
+
+    dx = torch.full((N, C // 8, H, H, 8), 7.0, dtype=BF, device=dev)
+    _lib.check(L.lsps_c8_conv3x3s2_dgrad(dyc.data_ptr(), w.data_ptr(), dx.data_ptr(), N, C, H, H, K, ws, wsb, st), 'dgrad')
+    ref = F.conv_transpose2d(dyd, wd, stride=2, padding=1, output_padding=1)
+    assert _rel(_from_c8(dx), ref) <= C8_TOL, 'dgrad'
+
+    dw = torch.full((K, C, 3, 3), 7.0, device=dev)
+    _lib.check(L.lsps_c8_conv3x3s2_wgrad(xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), N, C, H, H, K, ws, wsb, st), 'wgrad')
+    ref = torch.nn.grad.conv2d_weight(xd, (K, C, 3, 3), dyd, stride=2, padding=1)
+    assert _rel(dw, ref) <= 2e-5 * max(1.0, (N * P * P) ** 0.5 / 16), 'wgrad'     # f32 accumulation of exact bf16 products
+
+
+@pytest.mark.parametrize("N,Ci,H,Co", CONVT_GEOMS)
+def test_c8_convT3x3s2_forward_dgrad_wgrad(N, Ci, H, Co):
+    _need_gpu()
+    _lib, L, dev, st = _env()
+    assert L.lsps_c8_convT3x3s2_ok(N, Ci, H, H, Co) == 1
+    g = torch.Generator().manual_seed(N * 11 + Ci + H + Co)
+    x = _rand(g, N, Ci, H, H)
+    w = _rand(g, Ci, Co, 3, 3, scale=1.0 / (1.5 * Ci ** 0.5))
+    b = _rand(g, Co, scale=0.5)
+    Ho = 2 * H
+    dy = _rand(g, N, Co, Ho, Ho)
+    xd, wd, bd, dyd = _rb(x).double().cpu(), _rb(w).double().cpu(), b.double().cpu(), _rb(dy).double().cpu()
+    xc, dyc = _to_c8(x), _to_c8(dy)
+    ws, wsb = _lib.workspace(L.lsps_c8_conv3x3s2_workspace_bytes(N, Co, Ho, Ho, Ci), dev)
+
+    y = torch.full((N, Co // 8, Ho, Ho, 8), 7.0, dtype=BF, device=dev)
+    _lib.check(L.lsps_c8_convT3x3s2_fwd(xc.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Ci, H, H, Co, 0.01, ws, wsb, st), 'fwd')
+    ref = F.leaky_relu(F.conv_transpose2d(xd, wd, bd, stride=2, padding=1, output_padding=1), 0.01)
+    assert _rel(_from_c8(y), ref) <= C8_TOL, 'convT fwd'
+
+    dx = torch.full((N, Ci // 8, H, H, 8), 7.0, dtype=BF, device=dev)
+    _lib.check(L.lsps_c8_convT3x3s2_dgrad(dyc.data_ptr(), w.data_ptr(), dx.data_ptr(), N, Ci, H, H, Co, ws, wsb, st), 'dgrad')
+    assert _rel(_from_c8(dx), F.conv2d(dyd, wd, None, stride=2, padding=1)) <= C8_TOL, 'convT dgrad'
+
+    dw = torch.full((Ci, Co, 3, 3), 7.0, device=dev)
+    _lib.check(L.lsps_c8_convT3x3s2_wgrad(xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), N, Ci, H, H, Co, ws, wsb, st), 'wgrad')
+    ref = torch.nn.grad.conv2d_weight(dyd, (Ci, Co, 3, 3), xd, stride=2, padding=1)      # the transposed conv's adjoint roles
+    assert _rel(dw, ref) <= 2e-5 * max(1.0, (N * H * H) ** 0.5 / 16), 'convT wgrad'
+
+
+@pytest.mark.parametrize("N,C,HW", [(3, 64, 4096), (70, 2048, 4), (5, 128, 1024), (1, 8, 5)])
+def test_c8_act_bwd_bias(N, C, HW):
+    _need_gpu()
+    _lib, L, dev, st = _env()
+    g = torch.Generator().manual_seed(N + C + HW)
+    y = F.leaky_relu(torch.randn(N, C, HW, 1, generator=g), 0.01).cuda()
+    y[0, 0, 0, 0] = 0.0                                       # LeakyReLU'(0) = slope, as torch's `out > 0` test
+    dy = _rand(g, N, C, HW, 1)
+    yc, dyc = _to_c8(y), _to_c8(dy)
+    gc = torch.empty_like(dyc)
+    db = torch.full((C,), 7.0, device=dev)
+    ws, wsb = _lib.workspace(L.lsps_c8_act_bwd_bias_workspace_bytes(N, C), dev)
+    _lib.check(L.lsps_c8_act_bwd_bias(dyc.data_ptr(), yc.data_ptr(), gc.data_ptr(), db.data_ptr(), N, C, HW, 0.01, ws, wsb, st), 'abb')
+    yd, dyd = _rb(y).double().cpu(), _rb(dy).double().cpu()
+    ref = torch.where(yd > 0, dyd, dyd * 0.01)
+    got = _from_c8(gc)
+    assert _rel(got, ref) <= C8_TOL
+    assert _rel(db, got.double().cpu().sum((0, 2, 3))) <= 1e-5 * max(1.0, (N * HW) ** 0.5 / 8)
+
+
+def test_c8s2_entries_reject_what_they_cannot_do():
+    _need_gpu()
+    _lib, L, dev, st = _env()
+    assert L.lsps_c8_conv3x3s2_ok(4, 64, 48, 48, 128) == 0        # not a power of two
+    assert L.lsps_c8_conv3x3s2_ok(4, 24, 32, 32, 128) == 0        # C % 64
+    assert L.lsps_c8_conv3x3s2_ok(4, 64, 32, 32, 64) == 0         # K % 128
+    assert L.lsps_c8_convT3x3s2_ok(4, 64, 32, 32, 64) == 0        # Ci % 128
+    x = torch.zeros(8, dtype=BF, device=dev)
+    w = torch.zeros(8, device=dev)
+    rc = L.lsps_c8_conv3x3s2_fwd(x.data_ptr(), w.data_ptr(), None, x.data_ptr(), 4, 24, 32, 32, 128, 0.01, None, 0, st)
+    assert rc != 0 and b'unsupported geometry' in L.lsps_last_error()
