@@ -1,11 +1,21 @@
 // C-ABI of the bf16 residual trunk in the channel-group layout "C8" (c8conv.h, c8wgrad.h): BASELINE config 5.
 #include <algorithm>
+#include <stdlib.h>
 #include "common.h"
 #include "c8conv.h"
 #include "c8wgrad.h"
 #include "c8s2.h"
 
 namespace lsps {
+
+static int c8_wgrad_queue() {                     // workgroups per CU the weight-gradient kernels' grids aim at (experiments)
+  static int q = 0;
+  if (!q) {
+    const char *e = getenv("LSPS_C8W_QUEUE");
+    q = e && atoi(e) > 0 ? atoi(e) : 1;             // one round of workgroups: half the partial sums of 2, measured faster (profiles/r3d)
+  }
+  return q;
+}
 
 static bool c8_geom_ok(int N, int C, int H, int W, int K) {
   return N > 0 && H == 32 && W == 32 && C >= 16 && (C & 15) == 0 && K >= 64 && (K & 63) == 0 && (long)(C >> 3) * 1024 * 16 < (1l << 31);
@@ -148,7 +158,7 @@ static bool c8s2_wgrad_geom(int N, int K, int C, int H, int W, C8S2WParams *p) {
   if (8 * bplane > C8S2W_BPIECES * 64) return false;
   if ((long)TI * (C >> 3) * H * W * 16 >= (1l << 31) || (long)TI * (K >> 3) * P * Q * 16 >= (1l << 31)) return false;
   const int tiles = (K >> 7) * (C >> 6);
-  int s = (2 * 256 + tiles - 1) / tiles;
+  int s = (c8_wgrad_queue() * 256 + tiles - 1) / tiles;
   s = (s + 7) / 8 * 8;                                           // a split lives on ONE XCD (workgroup -> tile mapping): use all 8
   if (s > nc) s = nc;
   const int cps = (nc + s - 1) / s;
@@ -332,7 +342,7 @@ int lsps_c8_conv3x3_dgrad_inbwd(const void *dy, const float *w, const void *out_
 // splits of the weight gradient's image loop: enough workgroups to fill the chip (one workgroup per CU: 118 KB of LDS)
 static int c8_wgrad_splits(int N, int C, int K) {
   const int tiles = (K >> 7) * (C >> 6);
-  int s = (2 * 256 + tiles - 1) / tiles;           // ~2 workgroups per CU in the queue
+  int s = (c8_wgrad_queue() * 256 + tiles - 1) / tiles;
   s = (s + 7) / 8 * 8;
   if (s > N) s = N;
   return s < 1 ? 1 : s;

@@ -34,7 +34,9 @@ namespace lsps {
 #define C8_APIECES 18                                // 9 taps x 2 k-halves x 64 k = 1152 units
 #define C8_AUNITS (C8_APIECES * 64)
 #define C8_STAGE ((C8_BUNITS + C8_AUNITS) * 16)      // 56320 bytes
-#define C8_LDS_BYTES (2 * C8_STAGE)                  // 112640 bytes: one workgroup per CU
+#define C8_RBYTES (128 * 1024)                       // epilogue operand tile R (64 channels x 1024 pixels bf16) staged over the dead stages
+#define C8_SCRATCH (C8_RBYTES)                       // epilogue reduction scratch behind it (5 KB)
+#define C8_LDS_BYTES (C8_RBYTES + 5120)              // 136192 bytes (stages: 112640): one workgroup per CU
 #define C8_ACHUNK (C8_AUNITS * 8)                    // bf16 elements of packed weights per (k tile, chunk)
 
 typedef __attribute__((address_space(3))) void *c8_lds_ptr;
@@ -259,12 +261,31 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
   const unsigned b_base = (unsigned)((half * C8_PLANE + 4 * wave * C8_LDW + l31) * 16);
   const unsigned a_base = (unsigned)(C8_BUNITS * 16 + (half * 64 + l31) * 16);
 
+  // The epilogue's second operand (addend / residual / saved output: this workgroup's 64 channels of image n, 128 KB) is
+  // fetched by LDS-DMA over the main loop's stages: the pieces that do not overlap the LAST chunk's stage while that chunk
+  // computes, the rest after the loop — the epilogue reads it from LDS (a per-element global load -> store chain, which
+  // the compiler must serialise because Y may alias R, cost 25 - 40 % of the kernel: profiles/r3d_pmc_c8.txt).
+  const bool useR = (MODE == 2 || MODE == 3 || (MODE == 0 && p.R != nullptr));
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned short *>(p.R ? p.R : p.X) + ((long)n * (p.M >> 3) + kt * 8) * 8192, 0, C8_RBYTES, 0x00020000);
+  const int last_lo = ((nch - 1) & 1) * (C8_STAGE / 1024), last_hi = last_lo + C8_STAGE / 1024;     // pieces under the last stage
+  auto issueR = [&](bool late) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int piece = wave + 8 * i;
+      const bool under = piece >= last_lo && piece < last_hi;
+      if (under == late)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (c8_lds_ptr)(c8_lds + piece * 1024), 16, (unsigned)(lane * 16), piece * 1024, 0, 0);
+    }
+  };
+
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (int ch = 0; ch < nch; ++ch) {
     const int stage = ch & 1;
     if (ch + 1 < nch) issue(ch + 1, stage ^ 1);
+    else if (useR) issueR(false);
     const unsigned char *Bs = c8_lds + stage * C8_STAGE + b_base;
     const unsigned char *As = c8_lds + stage * C8_STAGE + a_base;
 #pragma unroll
@@ -283,6 +304,12 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
     __builtin_amdgcn_s_barrier();
   }
 
+  if (useR) {
+    issueR(true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
   // ---------------------------------------------------------------------------------------------------------------
   // epilogue.  acc[i][j][r]: channel kt*64 + i*32 + (r&3) + 8*(r>>2) + 4*half, pixel (row 4*wave + j, column l31).
   // A register quad (r>>2 fixed) = 4 consecutive channels = 8 bytes of the unit of channel group kt*8 + i*4 + (r>>2).
@@ -293,8 +320,9 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
     return ((y_img + (long)(kt * 8 + i * 4 + rq) * plane_units + (4 * wave + j) * 32 + l31) << 1) + half;
   };
   typedef unsigned long long u64;
-  auto load4 = [&](const unsigned short *base, long piece, float (&o)[4]) {
-    const bf16x4 v = __builtin_bit_cast(bf16x4, reinterpret_cast<const u64 *>(base)[piece]);
+  auto loadR = [&](int i, int rq, int j, float (&o)[4]) {        // R's 4 channels of this lane's accumulator quad, from LDS
+    const bf16x4 v = __builtin_bit_cast(
+        bf16x4, *reinterpret_cast<const u64 *>(c8_lds + (((i * 4 + rq) * 1024 + (4 * wave + j) * 32 + l31) << 4) + 8 * half));
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (float)v[e];
   };
@@ -316,9 +344,9 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = acc[i][j][rq * 4 + e];
           const long piece = unit_of(i, rq, j);
-          if (p.R) {
+          if (useR) {
             float a[4];
-            load4(p.R, piece, a);
+            loadR(i, rq, j, a);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += a[e];
           }
@@ -342,7 +370,7 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
       for (int j = 0; j < 4; ++j) {
         if (MODE == 3) {
           float o[4];
-          load4(p.R, unit_of(i, rq, j), o);
+          loadR(i, rq, j, o);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             // branch-free forms (64 compare masks held in SGPR pairs spill): sign mask + bitfield select, max / min
@@ -371,7 +399,7 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
   c8_reduce_scatter32<16>(s1, l31);
   c8_reduce_scatter32<16>(s2, l31);
   // lane (half, l31) now holds the wave's sums of accumulator slot qs = l31: channel kt*64 + (qs>>4)*32 + (qs&3) + 8*((qs>>2)&3) + 4*half
-  float *red = reinterpret_cast<float *>(c8_lds);               // [wave 8][half 2][32][2]   (main-loop stages are dead)
+  float *red = reinterpret_cast<float *>(c8_lds + C8_SCRATCH);  // [wave 8][half 2][32][2]   (behind the R tile)
   float *stat = red + 8 * 2 * 32 * 2;                            // [half 2][32][4]
   red[((wave * 2 + half) * 32 + l31) * 2 + 0] = s1[0];
   red[((wave * 2 + half) * 32 + l31) * 2 + 1] = s2[0];
@@ -413,7 +441,7 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
         float o[4];
         if (MODE == 3) {
           float sv[4];
-          load4(p.R, piece, sv);
+          loadR(i, rq, j, sv);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float xh = fmaxf(sv[e], 0.f) + fminf(sv[e], 0.f) * inv_slope;
@@ -428,7 +456,7 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
           }
           if (MODE == 2) {
             float a[4];
-            load4(p.R, piece, a);
+            loadR(i, rq, j, a);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += a[e];
           }
