@@ -207,6 +207,28 @@ size_t lsps_c8_act_bwd_bias_workspace_bytes(int N, int C);
 int lsps_c8_act_bwd_bias(const void *dy, const void *y, void *g, float *db /*nullable*/, int N, int C, int HW, float slope,
                          void *ws, size_t ws_bytes, void *stream);
 
+/* ---- the two ends of the generator / discriminator in the bf16 math mode ------------------------------------------------
+ *   lsps_c8_stem_fwd     LeakyReLUConv2d(1, 64, 7, stride, 3) stems (lsps_nets.py:117,184): f32 image x [N,1,H,W] in, C8 bf16
+ *                        activation y out (slope < 0: no activation)
+ *   lsps_c8_stem_wgrad   dw [K,1,R,S] and db [K] (nullable) from the image, the C8 gradient dy w.r.t. the layer's OUTPUT and the
+ *                        layer's saved C8 output y: the LeakyReLU backward happens while dy is staged, the bias gradient is
+ *                        one more column of the same product (replaces lsps_act_bwd_bias + lsps_conv2d_wgrad)
+ *   lsps_c8_pw1_*        ConvTranspose2d(C, 1, kernel 1) + Tanh output head (lsps_nets.py:226-229) on a C8 input x:
+ *                        y [N,HW] f32 = act(b + sum_c w[c] x[c]); dx (C8) = w[c] * dpre; dw [C], db [1] from x and dpre, where
+ *                        dpre [N,HW] f32 is the gradient w.r.t. the pre-activation (lsps_act_bwd of dy) */
+int lsps_c8_stem_ok(int N, int H, int W, int K, int R, int S, int stride, int pad);
+size_t lsps_c8_stem_workspace_bytes(int K, int R, int S);
+int lsps_c8_stem_fwd(const float *x, const float *w, const float *bias /*nullable*/, void *y, int N, int H, int W, int K, int R, int S,
+                     int stride, int pad, float slope, void *stream);
+int lsps_c8_stem_wgrad(const float *x, const void *dy, const void *y, float *dw, float *db /*nullable*/, int N, int H, int W, int K,
+                       int R, int S, int stride, int pad, float slope, void *ws, size_t ws_bytes, void *stream);
+size_t lsps_c8_pw1_workspace_bytes(int N, int C);
+int lsps_c8_pw1_fwd(const void *x, const float *w, const float *bias /*nullable*/, float *y, int N, int C, int HW, int act, float slope,
+                    void *stream);
+int lsps_c8_pw1_dgrad(const float *dpre, const float *w, void *dx, int N, int C, int HW, void *stream);
+int lsps_c8_pw1_wgrad(const void *x, const float *dpre, float *dw, float *db /*nullable*/, int N, int C, int HW,
+                      void *ws, size_t ws_bytes, void *stream);
+
 /* ---- ConvTranspose2d: replaces nn.ConvTranspose2d forward/backward -------------------------
  * call sites: common_net.py:262 (LeakyReLUConvTranspose2d), lsps_nets.py:226-227 (1x1 output),
  *             lsps_nets.py:17-23 (Mapping).

@@ -87,6 +87,14 @@ _SIGNATURES = {
     'lsps_c8_convT3x3s2_wgrad': (c_int, [_P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
     'lsps_c8_act_bwd_bias_workspace_bytes': (c_size_t, [c_int] * 2),
     'lsps_c8_act_bwd_bias': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
+    'lsps_c8_stem_ok': (c_int, [c_int] * 8),
+    'lsps_c8_stem_workspace_bytes': (c_size_t, [c_int] * 3),
+    'lsps_c8_stem_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [c_float, _P]),
+    'lsps_c8_stem_wgrad': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 8 + [c_float, _P, c_size_t, _P]),
+    'lsps_c8_pw1_workspace_bytes': (c_size_t, [c_int] * 2),
+    'lsps_c8_pw1_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    'lsps_c8_pw1_dgrad': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    'lsps_c8_pw1_wgrad': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     'lsps_crop_normalize': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     'lsps_crop_augment': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
 }

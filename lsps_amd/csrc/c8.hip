@@ -5,6 +5,7 @@
 #include "c8conv.h"
 #include "c8wgrad.h"
 #include "c8s2.h"
+#include "c8ends.h"
 
 namespace lsps {
 
@@ -474,6 +475,47 @@ int lsps_c8_act_bwd_bias(const void *dy, const void *y, void *g, float *db, int 
     hipLaunchKernelGGL(c8_colsum_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)ws, db, C, splits);
     LSPS_CHECK_LAUNCH("c8_colsum");
   }
+  return 0;
+}
+
+// ---- the generator's 1x1 output head on a C8 tensor (c8ends.h) ------------------------------------------------------
+static int c8_pw1_splits(int N, int C) {
+  int s = std::min(N, std::max(1, 2048 / (C >> 3)));
+  const int ips = (N + s - 1) / s;
+  return (N + ips - 1) / ips;
+}
+
+size_t lsps_c8_pw1_workspace_bytes(int N, int C) { return align_up((size_t)c8_pw1_splits(N, C) * (C + 1) * sizeof(float), 256); }
+
+int lsps_c8_pw1_fwd(const void *x, const float *w, const float *bias, float *y, int N, int C, int HW, int act, float slope, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(x && w && y && N > 0 && C > 0 && (C & 7) == 0 && HW > 0, "c8_pw1_fwd: bad arguments (C %% 8 == 0)");
+  hipLaunchKernelGGL(c8_pw1_fwd_kernel, dim3(ceil_div(HW, 256), N), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x, w, bias, y,
+                     C, HW, act, slope);
+  LSPS_CHECK_LAUNCH("c8_pw1_fwd");
+  return 0;
+}
+
+int lsps_c8_pw1_dgrad(const float *dpre, const float *w, void *dx, int N, int C, int HW, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(dpre && w && dx && N > 0 && C > 0 && (C & 7) == 0 && HW > 0, "c8_pw1_dgrad: bad arguments (C %% 8 == 0)");
+  hipLaunchKernelGGL(c8_pw1_dgrad_kernel, dim3(ceil_div(HW, 256), N), dim3(256), 0, (hipStream_t)stream, dpre, w, (unsigned short *)dx, C,
+                     HW);
+  LSPS_CHECK_LAUNCH("c8_pw1_dgrad");
+  return 0;
+}
+
+int lsps_c8_pw1_wgrad(const void *x, const float *dpre, float *dw, float *db, int N, int C, int HW, void *ws, size_t ws_bytes,
+                      void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(x && dpre && dw && N > 0 && C > 0 && (C & 7) == 0 && HW > 0, "c8_pw1_wgrad: bad arguments (C %% 8 == 0)");
+  const int splits = c8_pw1_splits(N, C), ips = (N + splits - 1) / splits;
+  LSPS_CHECK_ARG(ws && ws_bytes >= (size_t)splits * (C + 1) * sizeof(float), "c8_pw1_wgrad: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(c8_pw1_wgrad_kernel, dim3(C >> 3, splits), dim3(256), 0, st, (const unsigned short *)x, dpre, (float *)ws, N, C, HW, ips);
+  LSPS_CHECK_LAUNCH("c8_pw1_wgrad");
+  hipLaunchKernelGGL(c8_pw1_wgrad_reduce_kernel, dim3(ceil_div(C + 1, 256)), dim3(256), 0, st, (const float *)ws, dw, db, C, splits);
+  LSPS_CHECK_LAUNCH("c8_pw1_wgrad_reduce");
   return 0;
 }
 

@@ -22,6 +22,7 @@ struct C1Params {
   int TP, rows, LW;              // output rows per workgroup, staged input rows, LDS row stride (Wd + 2 pad)
   int act;
   float slope;
+  int out_c8;                    // 1: Y is bf16 in the channel-group layout [N][K/8][P][Q][8] (c8conv.h; bf16 math mode)
 };
 
 __device__ __forceinline__ void c1_stage_rows(float *xs, const float *xn, int row0, int rows, int LW, int H, int Wd, int pad,
@@ -108,6 +109,25 @@ __global__ __launch_bounds__(256, 2) void c1_fwd_kernel(C1Params p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][i], b, acc[i], 0, 0, 0);
     }
+    if (fast && p.out_c8) {                                  // wave-uniform.  A register quad = 4 consecutive channels = 8 bytes
+      const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<unsigned short *>(p.Y) + ((long)n * p.K + m0) * PQ, 0, 0x7fffffff, 0x00020000);
+      const unsigned vo = (unsigned)(((p0 + pr) * p.Q + q0 + l31) * 16 + half * 8);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          bf16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = acc[i][rq * 4 + e];
+            v[e] = (__bf16)(lrelu ? fmaxf(a, a * p.slope) : a);
+          }
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), crs, vo, (i * 4 + rq) * (int)PQ * 16, 0);
+        }
+      continue;
+    }
     if (fast) {                                              // wave-uniform
       const unsigned vo = (unsigned)(((p0 + pr) * p.Q + q0 + l31) * 4 + half * 4 * pq4);
 #pragma unroll
@@ -143,6 +163,12 @@ __global__ __launch_bounds__(256, 2) void c1_fwd_kernel(C1Params p) {
 #define C1W_XMAX 1536             // floats of staged input rows: 6 per thread
 struct C1WParams {
   const float *X, *DY;
+  // bf16 math mode: dy and the layer's saved OUTPUT y as C8 tensors [N][K/8][P][Q][8] (DY unused).  The LeakyReLU backward
+  // g = dy * (y > 0 ? 1 : slope) happens while the tile is staged, and the bias gradient sum(g) comes out as tap column
+  // T of the same product (its B operand is a row of ones): no separate activation-backward pass over the largest
+  // activation of the net.  part is [blocks][K * (T + 1)] then.
+  const unsigned short *DYc, *Yc;
+  float slope;
   float *part;                   // [blocks][K * T]
   int N, H, Wd, K, P, Q, R, S, stride, pad;
   int LW, RB, xrows;             // LDS row stride (Wd + 2 pad), output rows per iteration, staged input rows
@@ -150,8 +176,10 @@ struct C1WParams {
 };
 
 __global__ __launch_bounds__(256, 2) void c1_wgrad_kernel(C1WParams p) {
-  __shared__ __attribute__((aligned(16))) float lds[64 * C1W_LDA + C1W_XMAX];
+  __shared__ __attribute__((aligned(16))) float lds[64 * C1W_LDA + 2 * C1W_XMAX];
   float *dys = lds, *xs = lds + 64 * C1W_LDA;
+  const bool c8 = p.DYc != nullptr;                       // wave-uniform
+  for (int u = threadIdx.x; u < C1W_XMAX; u += 256) xs[C1W_XMAX + u] = 1.f;      // the bias-gradient "tap" reads ones
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -164,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void c1_wgrad_kernel(C1WParams p) {
   for (int j = 0; j < 2; ++j) {
     const int t = j * 32 + l31;
     const int r = t < T ? t / p.S : 0, c = t < T ? t - r * p.S : 0;
-    toff[j] = r * p.LW + c;
+    toff[j] = (c8 && t == T) ? C1W_XMAX : r * p.LW + c;
   }
   f32x16 acc[2][2];
 #pragma unroll
@@ -194,13 +222,35 @@ __global__ __launch_bounds__(256, 2) void c1_wgrad_kernel(C1WParams p) {
     x_c[i] = u - x_r[i] * p.LW - p.pad;
   }
 
+  // C8 staging assignment: unit u = tid + 256 i (i < 4) -> (channel group u / 128, pixel u % 128 of the iteration's 128)
+  int c_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = tid + 256 * i, g8 = u >> 7, px = u & 127;
+    const int rb = px / p.Q, cq = px - rb * p.Q;
+    c_off[i] = (g8 * 8 < p.K ? g8 : 0) * (int)PQ + rb * p.Q + cq;          // in 16-byte units
+  }
   f32x4 dreg[8];
   float xreg[6];
   auto fetch = [&](int it) {
     const int n = it / (p.P / p.RB), pr = (it - n * (p.P / p.RB)) * p.RB;
-    const float *dyn = p.DY + (long)n * p.K * PQ + (long)pr * p.Q;
+    if (c8) {                                              // dreg[2 i], dreg[2 i + 1] = the 8 channels of unit i, activation undone
+      const u32x4 *dq = reinterpret_cast<const u32x4 *>(p.DYc) + (long)n * (p.K >> 3) * PQ + (long)pr * p.Q;
+      const u32x4 *yq = reinterpret_cast<const u32x4 *>(p.Yc) + (long)n * (p.K >> 3) * PQ + (long)pr * p.Q;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dreg[i] = *reinterpret_cast<const f32x4 *>(dyn + d_off[i]);
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8 dv = __builtin_bit_cast(bf16x8, dq[c_off[i]]), yv = __builtin_bit_cast(bf16x8, yq[c_off[i]]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (float)dv[e];
+          dreg[2 * i + (e >> 2)][e & 3] = (float)yv[e] > 0.f ? d : d * p.slope;
+        }
+      }
+    } else {
+      const float *dyn = p.DY + (long)n * p.K * PQ + (long)pr * p.Q;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dreg[i] = *reinterpret_cast<const f32x4 *>(dyn + d_off[i]);
+    }
     const float *xn = p.X + (long)n * HWx;
     const int row0 = pr * p.stride - p.pad;
 #pragma unroll
@@ -222,14 +272,24 @@ __global__ __launch_bounds__(256, 2) void c1_wgrad_kernel(C1WParams p) {
   const float *Bp = xs + srow * p.stride * p.LW + (sq0 + half) * p.stride;
   for (int it = it_begin; it < it_end; ++it) {
     __syncthreads();
+    if (c8) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const bool live = (tid + 256 * i) >> 5 < p.K;        // channels >= K are zero rows
-      float *d = dys + d_lds[i];
-      d[0] = live ? dreg[i][0] : 0.f;
-      d[1] = live ? dreg[i][1] : 0.f;
-      d[2] = live ? dreg[i][2] : 0.f;
-      d[3] = live ? dreg[i][3] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const int u = tid + 256 * i, g8 = u >> 7, px = u & 127;
+        const bool live = g8 * 8 < p.K;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dys[(g8 * 8 + e) * C1W_LDA + px] = live ? dreg[2 * i + (e >> 2)][e & 3] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool live = (tid + 256 * i) >> 5 < p.K;      // channels >= K are zero rows
+        float *d = dys + d_lds[i];
+        d[0] = live ? dreg[i][0] : 0.f;
+        d[1] = live ? dreg[i][1] : 0.f;
+        d[2] = live ? dreg[i][2] : 0.f;
+        d[3] = live ? dreg[i][3] : 0.f;
+      }
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -268,11 +328,26 @@ __global__ __launch_bounds__(256, 2) void c1_wgrad_kernel(C1WParams p) {
     }
   }
   __syncthreads();
-  float *out = p.part + (long)blockIdx.x * p.K * T;
-  for (int u = tid; u < p.K * T; u += 256) {
-    const int k = u / T, t = u - k * T;
+  const int To = c8 ? T + 1 : T;                           // C8: column T = the bias gradient
+  float *out = p.part + (long)blockIdx.x * p.K * To;
+  for (int u = tid; u < p.K * To; u += 256) {
+    const int k = u / To, t = u - k * To;
     out[u] = red[k * 64 + t];
   }
+}
+
+// dW[k][t] = sum_b part[b][k][t] (t < T), db[k] = sum_b part[b][k][T]
+__global__ __launch_bounds__(256) void c1_wgrad_c8_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db,
+                                                                 int K, int T, int blocks) {
+  const int u = blockIdx.x * 256 + threadIdx.x, To = T + 1;
+  if (u >= K * To) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += part[(long)b * K * To + u];
+  const int k = u / To, t = u - k * To;
+  if (t < T)
+    dW[k * T + t] = s;
+  else if (db)
+    db[k] = s;
 }
 
 }  // namespace lsps

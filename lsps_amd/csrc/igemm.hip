@@ -717,9 +717,10 @@ static bool c1_fwd_ok(int Cb, int Hb, int Wb, int Hs, int Ws, int R, int S, int 
 }
 
 static int run_c1_fwd(const float *in, const float *W, const float *bias, float *out, int N, int Hb, int Wb, int M, int Hs,
-                      int Ws, int R, int S, int st_, int pad, int act, float slope, hipStream_t st) {
+                      int Ws, int R, int S, int st_, int pad, int act, float slope, hipStream_t st, int out_c8 = 0) {
   C1Params p;
   memset(&p, 0, sizeof(p));
+  p.out_c8 = out_c8;
   p.X = in;
   p.W = W;
   p.bias = bias;
@@ -1273,11 +1274,15 @@ static bool c1_wgrad_ok(int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, i
 static size_t c1_wgrad_ws_bytes(int Cs, int R, int S) { return (size_t)C1W_BLOCKS * Cs * R * S * sizeof(float) + 256; }
 
 static int run_c1_wgrad(const float *small, const float *big, float *dW, int N, int Hb, int Wb, int Cs, int Hs, int Ws,
-                        int R, int S, int st_, int pad, void *ws, size_t ws_bytes, hipStream_t st) {
+                        int R, int S, int st_, int pad, void *ws, size_t ws_bytes, hipStream_t st, const void *dy_c8 = nullptr,
+                        const void *y_c8 = nullptr, float slope = 0.f, float *db = nullptr) {
   C1WParams p;
   memset(&p, 0, sizeof(p));
   p.X = big;
   p.DY = small;
+  p.DYc = (const unsigned short *)dy_c8;
+  p.Yc = (const unsigned short *)y_c8;
+  p.slope = slope;
   p.N = N;
   p.H = Hb;
   p.Wd = Wb;
@@ -1295,14 +1300,21 @@ static int run_c1_wgrad(const float *small, const float *big, float *dW, int N, 
   int blocks = p.iters_total < C1W_BLOCKS ? p.iters_total : C1W_BLOCKS;
   p.iters_per_block = ceil_div(p.iters_total, blocks);
   blocks = ceil_div(p.iters_total, p.iters_per_block);
-  if (c1_wgrad_ws_bytes(Cs, R, S) > ws_bytes) {
-    set_error("wgrad workspace too small: need %zu, have %zu", c1_wgrad_ws_bytes(Cs, R, S), ws_bytes);
+  const size_t need = dy_c8 ? (size_t)C1W_BLOCKS * Cs * (R * S + 1) * sizeof(float) : c1_wgrad_ws_bytes(Cs, R, S);
+  if (need > ws_bytes) {
+    set_error("wgrad workspace too small: need %zu, have %zu", need, ws_bytes);
     return LSPS_E_WS;
   }
   p.part = (float *)ws;
   hipLaunchKernelGGL(c1_wgrad_kernel, dim3(blocks), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("c1_wgrad");
   note_kernel("c1_wgrad_kernel");
+  if (dy_c8) {
+    hipLaunchKernelGGL(c1_wgrad_c8_reduce_kernel, dim3(ceil_div((long)Cs * (R * S + 1), 256)), dim3(256), 0, st, (const float *)p.part, dW,
+                       db, Cs, R * S, blocks);
+    LSPS_CHECK_LAUNCH("c1_wgrad_c8_reduce");
+    return 0;
+  }
   const long nW = (long)Cs * R * S;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(nW, 256)), dim3(256), 0, st, (const float *)p.part, dW, nW, blocks);
   LSPS_CHECK_LAUNCH("reduce_partials");
@@ -1802,6 +1814,43 @@ int lsps_convT2d_wgrad(const float *x, const float *dy, float *dw, float *db, in
   if (rc) return rc;
   if (db) return run_bias_grad(dy, db, N, Co, Ho * Wo, ws, ws_bytes, (hipStream_t)stream);
   return 0;
+}
+
+// ---- the single-input-channel stems in the bf16 math mode: f32 image in, C8 bf16 activation out (conv_c1.h) ----------
+static bool c8_stem_geom(int N, int H, int W, int K, int R, int S, int stride, int pad, int *P, int *Q) {
+  if (N <= 0 || H <= 0 || W <= 0 || K <= 0 || (K & 63) || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return false;
+  *P = (H + 2 * pad - R) / stride + 1;
+  *Q = (W + 2 * pad - S) / stride + 1;
+  return *P > 0 && *Q > 0 && c1_fwd_ok(1, H, W, *P, *Q, R, S, stride, pad, (long)R * S) && R * S < 64 &&
+         c1_wgrad_ok(1, H, W, K, *P, *Q, R, S, stride, pad) && K <= 64 && (long)K * *P * *Q * 2 < (1L << 31);
+}
+
+int lsps_c8_stem_ok(int N, int H, int W, int K, int R, int S, int stride, int pad) {
+  int P, Q;
+  return c8_stem_geom(N, H, W, K, R, S, stride, pad, &P, &Q) ? 1 : 0;
+}
+
+size_t lsps_c8_stem_workspace_bytes(int K, int R, int S) { return (size_t)C1W_BLOCKS * K * (R * S + 1) * sizeof(float) + 256; }
+
+int lsps_c8_stem_fwd(const float *x, const float *w, const float *bias, void *y, int N, int H, int W, int K, int R, int S, int stride,
+                     int pad, float slope, void *stream) {
+  (void)hipGetLastError();
+  int P, Q;
+  LSPS_CHECK_ARG(x && w && y, "c8_stem_fwd: null pointer");
+  LSPS_CHECK_ARG(c8_stem_geom(N, H, W, K, R, S, stride, pad, &P, &Q), "c8_stem_fwd: unsupported geometry (one input channel, K == 64)");
+  LSPS_CHECK_ARG(slope <= 1.f, "c8_stem_fwd: LeakyReLU slope in [0, 1] (or < 0: no activation)");
+  return run_c1_fwd(x, w, bias, (float *)y, N, H, W, K, P, Q, R, S, stride, pad, slope >= 0.f ? LSPS_ACT_LRELU : LSPS_ACT_NONE, slope,
+                    (hipStream_t)stream, 1);
+}
+
+int lsps_c8_stem_wgrad(const float *x, const void *dy, const void *y, float *dw, float *db, int N, int H, int W, int K, int R, int S,
+                       int stride, int pad, float slope, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  int P, Q;
+  LSPS_CHECK_ARG(x && dy && y && dw && ws, "c8_stem_wgrad: null pointer");
+  LSPS_CHECK_ARG(c8_stem_geom(N, H, W, K, R, S, stride, pad, &P, &Q), "c8_stem_wgrad: unsupported geometry (one input channel, K == 64)");
+  LSPS_CHECK_ARG(slope >= 0.f, "c8_stem_wgrad: LeakyReLU slope >= 0 (1: no activation)");
+  return run_c1_wgrad(nullptr, x, dw, N, H, W, K, P, Q, R, S, stride, pad, ws, ws_bytes, (hipStream_t)stream, dy, y, slope, db);
 }
 
 }  // extern "C"

@@ -812,6 +812,122 @@ def convT3x3s2_c8(x, w, b=None, slope=LRELU_SLOPE):
     return _ConvTS2C8Fn.apply(x, w, b, float(slope))
 
 
+def c8_stem_ok(x, w, stride, pad):
+    """Single-input-channel stem (7x7) writing its activation straight in the C8 layout (bf16 math mode)."""
+    if not _c8_enabled() or is_c8(x) or x.dim() != 4 or x.shape[1] != 1 or w.shape[1] != 1:
+        return False
+    N, _, H, W = x.shape
+    return N > 0 and _lib.lib().lsps_c8_stem_ok(N, H, W, w.shape[0], w.shape[2], w.shape[3], stride, pad) == 1
+
+
+class _StemC8Fn(torch.autograd.Function):
+    """LeakyReLUConv2d(1, K, 7, stride, 3) (lsps_nets.py:117,184): f32 image in, C8 bf16 activation out.  Backward: weight and
+    bias gradient in ONE kernel from (x, dy, saved y) — the LeakyReLU backward is applied while dy is staged."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, slope):
+        L = _lib.lib()
+        x, w = _c(x), _c(w)
+        N, _, H, W = x.shape
+        K, _, R, S = w.shape
+        P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
+        y = torch.empty((N, K // 8, P, Q, 8), dtype=BF16, device=x.device)
+        with profiler.span(2.0 * N * K * P * Q * R * S, 'c1_fwd_kernel'):
+            _lib.check(L.lsps_c8_stem_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y, BF16), N, H, W, K, R, S, stride, pad, slope,
+                                          _lib.stream()), 'c8_stem_fwd')
+        ctx.geom = (N, H, W, K, R, S, stride, pad, slope, P, Q)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w, y = ctx.saved_tensors
+        N, H, W, K, R, S, stride, pad, slope, P, Q = ctx.geom
+        dy = _c(dy)
+        st = _lib.stream()
+        flops = 2.0 * N * K * P * Q * R * S
+        dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_db:
+            dw = torch.empty_like(w)
+            db = torch.empty(K, dtype=torch.float32, device=x.device) if want_db else None
+            ws, wsb = _lib.workspace(L.lsps_c8_stem_workspace_bytes(K, R, S), x.device)
+            with profiler.span(flops, 'c1_wgrad_kernel'):
+                _lib.check(L.lsps_c8_stem_wgrad(_lib.ptr(x), _lib.ptr(dy, BF16), _lib.ptr(y, BF16), _lib.ptr(dw), _lib.ptr(db), N, H, W, K,
+                                                R, S, stride, pad, slope if slope >= 0 else 1.0, ws, wsb, st), 'c8_stem_wgrad')
+        if ctx.needs_input_grad[0]:
+            # gradient w.r.t. the image (the discriminator's stems inside gen_update): the f32 path of the layer
+            g, _ = _c8_act_backward(L, dy, y, slope, False, K, st)
+            g32 = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
+            _lib.check(L.lsps_c8_to_nchw(_lib.ptr(g, BF16), _lib.ptr(g32), N, K, P * Q, st), 'c8_to_nchw')
+            dx = torch.empty_like(x)
+            ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, 1, H, W, K, R, S, stride, pad), x.device)
+            with profiler.span(flops):
+                _lib.check(L.lsps_conv2d_dgrad(_lib.ptr(g32), _lib.ptr(w), _lib.ptr(dx), N, 1, H, W, K, R, S, stride, pad, ws, wsb, st),
+                           'conv2d_dgrad')
+        return dx, dw, db, None, None, None
+
+
+def stem_c8(x, w, b, stride, pad, slope=LRELU_SLOPE):
+    return _StemC8Fn.apply(x, w, b, int(stride), int(pad), float(slope))
+
+
+def c8_pw1_ok(x, w, stride, pad, outpad):
+    return _c8_enabled() and is_c8(x) and tuple(w.shape) == (x.shape[1] * 8, 1, 1, 1) and stride == 1 and pad == 0 and outpad == 0
+
+
+class _Pw1C8Fn(torch.autograd.Function):
+    """ConvTranspose2d(C, 1, kernel 1) [+ Tanh] on a C8 tensor (lsps_nets.py:226-229): x [N][C/8][H][W][8] -> y f32 [N,1,H,W]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope):
+        L = _lib.lib()
+        x, w = _c(x), _c(w)
+        N, G, H, W, _ = x.shape
+        y = torch.empty((N, 1, H, W), dtype=torch.float32, device=x.device)
+        with profiler.span(2.0 * N * G * 8 * H * W, 'pw1_fwd_kernel'):
+            _lib.check(L.lsps_c8_pw1_fwd(_lib.ptr(x, BF16), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, G * 8, H * W, act, slope,
+                                         _lib.stream()), 'c8_pw1_fwd')
+        ctx.geom = (N, G * 8, H, W, act, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w, y = ctx.saved_tensors
+        N, C, H, W, act, slope = ctx.geom
+        dy = _c(dy)
+        st = _lib.stream()
+        flops = 2.0 * N * C * H * W
+        dx = dw = db = None
+        if act != ACT_NONE:
+            dpre = torch.empty_like(dy)
+            _lib.check(L.lsps_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dpre), dy.numel(), act, slope, st), 'act_bwd')
+        else:
+            dpre = dy
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            with profiler.span(flops, 'pw1_dgrad_kernel'):
+                _lib.check(L.lsps_c8_pw1_dgrad(_lib.ptr(dpre), _lib.ptr(w), _lib.ptr(dx, BF16), N, C, H * W, st), 'c8_pw1_dgrad')
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_db:
+            dw = torch.empty_like(w)
+            db = torch.empty(1, dtype=torch.float32, device=x.device) if want_db else None
+            ws, wsb = _lib.workspace(L.lsps_c8_pw1_workspace_bytes(N, C), x.device)
+            with profiler.span(flops, 'pw1_wgrad_kernel'):
+                _lib.check(L.lsps_c8_pw1_wgrad(_lib.ptr(x, BF16), _lib.ptr(dpre), _lib.ptr(dw), _lib.ptr(db), N, C, H * W, ws, wsb, st),
+                           'c8_pw1_wgrad')
+        return dx, dw, db, None, None
+
+
+def pw1_c8(x, w, b=None, act=ACT_NONE, slope=LRELU_SLOPE):
+    return _Pw1C8Fn.apply(x, w, b, int(act), float(slope))
+
+
 class _ResBlockC8Fn(torch.autograd.Function):
     """LeakyINSResBlock on C8 tensors as ONE autograd node (common_net.py:160-181): both convs run c8_conv3x3_kernel with
     the InstanceNorm (+ LeakyReLU | + skip) in the epilogue; backward = norm-2 backward, two transposing-read weight

@@ -124,12 +124,17 @@ def run_layers(layers, x, noise=None):
             x = l(x)
         elif isinstance(l, LeakyReLUConv2d):
             c = l.model[0]
-            x = l(ops.to_c8(x) if ops.c8_conv_s2_ok(x, c.weight, c.stride, c.padding) else ops.from_c8(x))
+            if ops.c8_stem_ok(x, c.weight, c.stride, c.padding):     # 7x7 stem: f32 image in, C8 activation out
+                x = ops.stem_c8(x, c.weight, c.bias, c.stride, c.padding, LRELU_SLOPE)
+            else:
+                x = l(ops.to_c8(x) if ops.c8_conv_s2_ok(x, c.weight, c.stride, c.padding) else ops.from_c8(x))
         elif isinstance(l, LeakyReLUConvTranspose2d):
             c = l.model[0]
             x = l(ops.to_c8(x) if ops.c8_convT_s2_ok(x, c.weight, c.stride, c.padding, c.output_padding) else ops.from_c8(x))
         elif isinstance(l, GaussianNoiseLayer):
             x = l(x, noise)
+        elif isinstance(l, ConvTranspose2d) and ops.c8_pw1_ok(x, l.weight, l.stride, l.padding, l.output_padding):
+            x = ops.pw1_c8(x, l.weight, l.bias, l.act, LRELU_SLOPE)      # 1x1 output head (+ Tanh) straight from the C8 tensor
         else:
             x = l(ops.from_c8(x))
     return x

@@ -127,3 +127,61 @@ def test_c8s2_entries_reject_what_they_cannot_do():
     w = torch.zeros(8, device=dev)
     rc = L.lsps_c8_conv3x3s2_fwd(x.data_ptr(), w.data_ptr(), None, x.data_ptr(), 4, 24, 32, 32, 128, 0.01, None, 0, st)
     assert rc != 0 and b'unsupported geometry' in L.lsps_last_error()
+
+
+@pytest.mark.parametrize("N,H,stride", [(3, 128, 1), (5, 128, 2), (2, 64, 2)])
+def test_c8_stem_forward_and_weight_gradient(N, H, stride):
+    """7x7 single-input-channel stems (lsps_nets.py:117,184): C8 output; weight + bias gradient with the LeakyReLU backward
+    applied while dy is staged, against f64 from the same bf16-rounded dy / y."""
+    _need_gpu()
+    _lib, L, dev, st = _env()
+    K, R, pad = 64, 7, 3
+    assert L.lsps_c8_stem_ok(N, H, H, K, R, R, stride, pad) == 1
+    g = torch.Generator().manual_seed(N + H + stride)
+    x = _rand(g, N, 1, H, H)
+    w = _rand(g, K, 1, R, R, scale=0.1)
+    b = _rand(g, K, scale=0.3)
+    P = (H + 2 * pad - R) // stride + 1
+    y = torch.full((N, K // 8, P, P, 8), 7.0, dtype=BF, device=dev)
+    _lib.check(L.lsps_c8_stem_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, H, H, K, R, R, stride, pad, 0.01, st), 'stem fwd')
+    ref = F.leaky_relu(F.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), stride=stride, padding=pad), 0.01)
+    assert _rel(_from_c8(y), ref) <= C8_TOL
+    dy = _rand(g, N, K, P, P)
+    dyc = _to_c8(dy)
+    dw = torch.full((K, 1, R, R), 7.0, device=dev)
+    db = torch.full((K,), 7.0, device=dev)
+    ws, wsb = _lib.workspace(L.lsps_c8_stem_workspace_bytes(K, R, R), dev)
+    _lib.check(L.lsps_c8_stem_wgrad(x.data_ptr(), dyc.data_ptr(), y.data_ptr(), dw.data_ptr(), db.data_ptr(), N, H, H, K, R, R, stride, pad,
+                                    0.01, ws, wsb, st), 'stem wgrad')
+    yd, dyd = _from_c8(y).double().cpu(), _rb(dy).double().cpu()
+    gd = torch.where(yd > 0, dyd, dyd * 0.01)
+    wref = torch.nn.grad.conv2d_weight(x.double().cpu(), (K, 1, R, R), gd, stride=stride, padding=pad)
+    assert _rel(dw, wref) <= 1e-4
+    assert _rel(db, gd.sum((0, 2, 3))) <= 1e-4
+
+
+@pytest.mark.parametrize("N,C,H", [(3, 64, 128), (5, 16, 8)])
+def test_c8_pw1_head(N, C, H):
+    """ConvTranspose2d(C, 1, 1) + Tanh on a C8 input (lsps_nets.py:226-229)."""
+    _need_gpu()
+    _lib, L, dev, st = _env()
+    g = torch.Generator().manual_seed(N + C + H)
+    x = _rand(g, N, C, H, H)
+    w = _rand(g, C, 1, 1, 1, scale=0.2)
+    b = _rand(g, 1, scale=0.3)
+    xc = _to_c8(x)
+    y = torch.full((N, 1, H, H), 7.0, device=dev)
+    _lib.check(L.lsps_c8_pw1_fwd(xc.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, C, H * H, 2, 0.0, st), 'pw1 fwd')      # 2 = tanh
+    xd, wd = _rb(x).double().cpu(), w.double().cpu()
+    ref = torch.tanh(F.conv_transpose2d(xd, wd, b.double().cpu()))
+    assert _rel(y, ref) <= 1e-5
+    dpre = _rand(g, N, 1, H, H)
+    dx = torch.full((N, C // 8, H, H, 8), 7.0, dtype=BF, device=dev)
+    _lib.check(L.lsps_c8_pw1_dgrad(dpre.data_ptr(), w.data_ptr(), dx.data_ptr(), N, C, H * H, st), 'pw1 dgrad')
+    assert _rel(_from_c8(dx), F.conv2d(dpre.double().cpu(), wd)) <= C8_TOL
+    dw = torch.full((C, 1, 1, 1), 7.0, device=dev)
+    db = torch.full((1,), 7.0, device=dev)
+    ws, wsb = _lib.workspace(L.lsps_c8_pw1_workspace_bytes(N, C), dev)
+    _lib.check(L.lsps_c8_pw1_wgrad(xc.data_ptr(), dpre.data_ptr(), dw.data_ptr(), db.data_ptr(), N, C, H * H, ws, wsb, st), 'pw1 wgrad')
+    assert _rel(dw.view(C), (xd * dpre.double().cpu()).sum((0, 2, 3))) <= 1e-4
+    assert _rel(db, dpre.double().cpu().sum().view(1)) <= 1e-4

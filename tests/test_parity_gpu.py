@@ -121,6 +121,43 @@ def test_joint_readout_matches_oracle():
     assert abs(np.nanmean(np.nanmean(err, axis=1)) - ref['mean_err']) <= 1e-3 * ref['mean_err']
 
 
+def test_joint_readout_bf16_math_mode():
+    """A12 in the bf16 math mode (BASELINE config 5; the tolerance that matters there): regress_b on the C8 bf16
+    stride-2 kernels -> vae.decode -> mm joints against the f32 CPU oracle: joint coordinates within 1e-2 of their abs-max,
+    the worst joint per frame and the <= 40 mm decisions identical."""
+    from lsps_amd import ops
+    A = _adapter()
+    hp = cases.hp_for('full')
+    sds = cases.make_weights(hp, lsps_ref)
+    n = 16
+    b = cases.make_inputs(n)
+    cube = np.array([300.0, 300.0, 300.0], np.float32)
+    ref_tr = cases.NativeAdapter(lsps_ref, 'cpu').make_trainer(hp, sds)
+    ref = lsps_ref.joint_readout(ref_tr.dis, ref_tr.vae, torch.as_tensor(b['xb']), torch.as_tensor(b['lb']), b['cb'], cube)
+    tr = A.make_trainer(hp, sds)
+    tr.dis.eval()
+    ops.set_math_mode('bf16')
+    try:
+        ops.kernel_log_begin()
+        with torch.no_grad():
+            _, post, _ = tr.dis.regress_b(A.T(b['xb']))
+            pose = tr.vae.decode(post).cpu().numpy()
+        ops.kernel_log_end()
+    finally:
+        ops.set_math_mode('f32')
+    gt = b['lb'].reshape(n, -1, 3)[:, lsps_ref.NYU_EVAL_JOINTS]
+    pr = pose.reshape(n, -1, 3)[:, lsps_ref.NYU_EVAL_JOINTS]
+    com = b['cb'].reshape(n, 1, 3)
+    pr3d, gt3d = pr * (cube[0] / 2.) + com, gt * (cube[0] / 2.) + com
+    err = np.sqrt(np.square(gt3d - pr3d).sum(axis=2))
+    rel = np.abs(pose - ref['pose']).max() / np.abs(ref['pose']).max()
+    print("bf16 joint read-out: rel err of the joints", rel)
+    assert 1e-6 < rel <= 1e-2
+    assert (np.argmax(err, axis=1) == ref['worst_joint']).all()
+    assert int((np.nanmax(err, axis=1) <= 40).sum()) == ref['frames_within_40']
+    assert abs(np.nanmean(np.nanmean(err, axis=1)) - ref['mean_err']) <= 1e-2 * ref['mean_err']
+
+
 def test_full_batch_properties():
     """Size-independent checks at BASELINE's full size (bs=128 per domain, ch=64), where the oracle is
     too slow to run: per-sample independence (a sample's output does not depend on its batch-mates),
