@@ -284,8 +284,10 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
   __builtin_amdgcn_s_barrier();
   for (int ch = 0; ch < nch; ++ch) {
     const int stage = ch & 1;
+#ifndef C8_ABL_NODMA                     // ablation builds: tools/build_abl_c8.sh (profiles/r3g_c8_ablations.txt)
     if (ch + 1 < nch) issue(ch + 1, stage ^ 1);
     else if (useR) issueR(false);
+#endif
     const unsigned char *Bs = c8_lds + stage * C8_STAGE + b_base;
     const unsigned char *As = c8_lds + stage * C8_STAGE + a_base;
 #pragma unroll
@@ -304,6 +306,19 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
     __builtin_amdgcn_s_barrier();
   }
 
+#ifdef C8_ABL_NOEPI
+  {                                     // ablation: no epilogue (the accumulators stay live through an impossible store)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 1.2345e30f) p.Y[0] = 1;
+    return;
+  }
+#endif
   if (useR) {
     issueR(true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
