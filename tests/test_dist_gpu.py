@@ -111,17 +111,20 @@ def test_two_rank_step_equals_global_batch_step():
 # round 2: the 2-rank HIP trainer against the REFERENCE's golden global-batch vectors, replicas that start from
 # different RNG streams, and overlap of the all-reduce with backward in all three update methods
 # ---------------------------------------------------------------------------------------------------------------
-def _golden_worker(rank, world, port, out):
+def _golden_worker(rank, world, port, out, config='tiny'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
-    os.environ['LSPS_BUCKET_BYTES'] = str(1 << 16)          # tiny nets: several buckets per arena
+    if config == 'tiny':
+        os.environ['LSPS_BUCKET_BYTES'] = str(1 << 16)      # tiny nets: several buckets per arena
+    else:
+        os.environ.pop('LSPS_BUCKET_BYTES', None)           # full width: the DEFAULT bucket layout
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         import lsps_amd.trainers as prod
         from collections import OrderedDict
-        hp = cases.hp_for('tiny')
+        hp = cases.hp_for(config)
         # (1) no pre-seeded weights: each rank initialises from its own RNG stream; cuda() must make them identical
         torch.manual_seed(4321 + rank)
         tr0 = prod.LSPSTrainer(hp)
@@ -174,10 +177,44 @@ def _golden_worker(rank, world, port, out):
             R['estimate3.it%d.dis.params' % it] = A.params(tr, 'dis')
         torch.cuda.synchronize()
         if rank == 0:
-            out.put((R, overlap, replicas_equal))
+            layout = {k: [(a0, a1, sum(p.numel() * 4 for p in r.arena.params[a0:a1])) for a0, a1 in r.buckets]
+                      for k, r in tr._reducers.items()}
+            out.put((R, overlap, replicas_equal, layout))
     finally:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def test_two_rank_full_width_default_buckets_match_reference_golden(golden):
+    """the 2-rank step once at FULL width with the DEFAULT bucket size — the bucket layout a real
+    data-parallel run instantiates (model_S.3.weight alone in the first bucket) — against the reference's global-batch golden
+    vectors (pretrain N = 2 global, estimate3 N = 8 global)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from lsps_amd import dist as ldist
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_golden_worker, args=(r, 2, port, out, 'full')) for r in range(2)]
+    for p in procs:
+        p.start()
+    R, overlap, replicas_equal, layout = out.get(timeout=1500)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert replicas_equal
+    g = {k: v for k, v in golden('full').items() if k.split('/')[0] in R}
+    assert len(g) > 100
+    bad, worst = cases.compare(R, g, 1e-3, grad_rtol=2e-2)
+    print("worst rel err", worst)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
+    # readiness order: the heads' few small tensors first, then model_S.3.weight (75.5 MB) ALONE — it leaves a few launches
+    # into backward instead of waiting for the front layers
+    big = [b for b in layout['dis'][:2] if b[1] - b[0] == 1 and b[2] >= ldist.DEFAULT_BUCKET_BYTES]
+    assert big and layout['dis'][0][2] < ldist.DEFAULT_BUCKET_BYTES + big[0][2], layout['dis'][:3]
+    for step in ('dis_update', 'gen_update', 'post_update'):
+        e1, n1 = overlap[(step, 1)]
+        assert n1 >= 2 and e1 >= n1 - 1, (step, overlap)
 
 
 def test_two_rank_hip_trainer_matches_reference_golden_and_overlaps(golden):
@@ -189,7 +226,7 @@ def test_two_rank_hip_trainer_matches_reference_golden_and_overlaps(golden):
     procs = [ctx.Process(target=_golden_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    R, overlap, replicas_equal = out.get(timeout=900)
+    R, overlap, replicas_equal, _ = out.get(timeout=900)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

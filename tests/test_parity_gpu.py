@@ -258,6 +258,61 @@ def test_full_size_step_gradients_equal_the_mean_of_chunk_gradients():
     assert worst['dis'] > 0.0 and worst['gen'] > 0.0          # different kernels really ran (not the same bits twice)
 
 
+def test_full_size_post_update_mode3_is_chunk_regression_mean_plus_first4_feature_term():
+    """The literal `estimate3` step at BASELINE's full size (post_update(mode=3), bs=128 per domain, full width), backward
+    included.  Its loss is reg_w * mean_n ||regress_a(x_n) - code_n||^2 (a batch mean) + feature_w_reg * the feature term of
+    the FIRST FOUR samples per domain (batch-independent; lsps_trainer.py:238).  So with sixteen 8-sample chunks:
+        grad(full, mode 3) = mean_j grad(chunk j, mode 0) + [grad(chunk 0, mode 3) - grad(chunk 0, mode 0)]
+    (mode 0 = the same regression term alone, :227-230).  The full step runs the bench's dispatch (batch-innermost trunk at
+    N=128, side stream), the chunks the small-batch paths the golden vectors pin at N=8."""
+    A = _adapter()
+    hp = cases.hp_for('full')
+    sds = cases.make_weights(hp, lsps_ref)
+    n, ch = 128, 8
+    b = cases.make_inputs(n)
+    zd = hp['vae']['z_dim']
+    nz_gen = cases.noise(cases.latent_shape(hp, 8), 51)
+    nz_va, nz_vb = cases.noise((n, zd), 52, 0.05), cases.noise((n, zd), 53, 0.05)
+
+    def reload(tr):
+        for net in ('gen', 'dis', 'vae', 'map'):
+            getattr(tr, net).load_state_dict({k: torch.as_tensor(v) for k, v in sds[net].items()})
+
+    def grads64(tr):
+        return {k: np.asarray(v, np.float64) for k, v in A.grads(tr, 'dis').items() if v is not None}
+
+    tr = A.make_trainer(hp, sds)
+    A.set_train(tr, True)
+    A.post_update(tr, b, 3, hp, nz_gen, nz_va, nz_vb)
+    full, full_s = grads64(tr), A.scalars(tr)
+    acc, reg_acc = None, 0.0
+    for j in range(n // ch):
+        bj = {k: v[j * ch:(j + 1) * ch] for k, v in b.items()}
+        reload(tr)
+        A.post_update(tr, bj, 0, hp, nz_gen, nz_va[j * ch:(j + 1) * ch], nz_vb[j * ch:(j + 1) * ch])
+        g = grads64(tr)
+        reg_acc += float(A.scalars(tr)['dis_reg_loss'])
+        if j == 0:
+            g0 = g
+        acc = g if acc is None else {k: acc[k] + g[k] for k in acc}
+    reload(tr)
+    b0 = {k: v[0:ch] for k, v in b.items()}
+    A.post_update(tr, b0, 3, hp, nz_gen, nz_va[0:ch], nz_vb[0:ch])
+    g3 = grads64(tr)
+    errs = []
+    for name, g in full.items():
+        if name not in acc:
+            continue
+        expect = acc[name] / float(n // ch) + (g3[name] - g0[name])
+        scale = max(float(np.abs(expect).max()), 1e-12)
+        errs.append((float(np.abs(g - expect).max()) / scale, name))
+    errs.sort(reverse=True)
+    assert errs and errs[0][0] <= 5e-3, errs[:5]
+    assert errs[len(errs) // 10][0] <= 5e-4, errs[len(errs) // 10]
+    assert abs(float(full_s['dis_reg_loss']) - reg_acc / (n // ch)) <= 1e-3 * abs(reg_acc / (n // ch))
+    assert errs[0][0] > 0.0
+
+
 def test_update_steps_are_bitwise_deterministic():
     """No atomics anywhere on the path (split reductions are two-stage): the same step from the same state
     gives bit-identical losses and weights."""
