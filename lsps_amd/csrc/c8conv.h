@@ -331,9 +331,6 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
   // ---------------------------------------------------------------------------------------------------------------
   const long plane_units = 1024;
   const long y_img = (long)n * (p.M >> 3) * plane_units;
-  auto unit_of = [&](int i, int rq, int j) -> long {             // in 8-byte pieces: (unit * 2 + half)
-    return ((y_img + (long)(kt * 8 + i * 4 + rq) * plane_units + (4 * wave + j) * 32 + l31) << 1) + half;
-  };
   typedef unsigned long long u64;
   auto loadR = [&](int i, int rq, int j, float (&o)[4]) {        // R's 4 channels of this lane's accumulator quad, from LDS
     const bf16x4 v = __builtin_bit_cast(
@@ -341,11 +338,26 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (float)v[e];
   };
-  auto store4 = [&](long piece, const float (&o)[4]) {
+  // Stores: a lane holds 4 channels (8 bytes) of a pixel's unit, lane + 32 the other 4.  Two image rows (j, j + 1) are
+  // exchanged across the half-waves (v_permlane32_swap: cdna_hip_programming.md T21) so that lanes 0-31 store the whole
+  // 16-byte units of row j and lanes 32-63 those of row j + 1: 16 store instructions of 16 B per lane instead of 32 of 8 B
+  // (the store tail of a one-workgroup-per-CU kernel is issue-bound).
+  typedef unsigned c8_u32x2 __attribute__((ext_vector_type(2)));
+  auto pack4 = [&](const float (&o)[4]) -> c8_u32x2 {
     bf16x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (__bf16)o[e];
-    reinterpret_cast<u64 *>(p.Y)[piece] = __builtin_bit_cast(u64, v);
+    return __builtin_bit_cast(c8_u32x2, v);
+  };
+  auto store_pair = [&](int i, int rq, int j0, c8_u32x2 A, c8_u32x2 B) {       // A: row 4 wave + j0, B: the row below
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(A[d], B[d], false, false);
+      A[d] = sw[0];
+      B[d] = sw[1];
+    }
+    const long unit = y_img + (long)(kt * 8 + i * 4 + rq) * plane_units + (4 * wave + j0 + half) * 32 + l31;
+    reinterpret_cast<u32x4 *>(p.Y)[unit] = u32x4{A[0], A[1], B[0], B[1]};
   };
 
   if (MODE == 0) {
@@ -353,20 +365,24 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq)
+      {
+        c8_u32x2 pk[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = acc[i][j][rq * 4 + e];
-          const long piece = unit_of(i, rq, j);
           if (useR) {
             float a[4];
             loadR(i, rq, j, a);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += a[e];
           }
-          store4(piece, o);
+          pk[j] = pack4(o);
         }
+        store_pair(i, rq, 0, pk[0], pk[1]);
+        store_pair(i, rq, 2, pk[2], pk[3]);
+      }
     return;
   }
 
@@ -450,9 +466,9 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
       f32x4 st[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) st[e] = *reinterpret_cast<const f32x4 *>(stat + (half * 32 + i * 16 + rq * 4 + e) * 4);
+      c8_u32x2 pk[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const long piece = unit_of(i, rq, j);
         float o[4];
         if (MODE == 3) {
           float sv[4];
@@ -476,8 +492,10 @@ __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {
             for (int e = 0; e < 4; ++e) o[e] += a[e];
           }
         }
-        store4(piece, o);
+        pk[j] = pack4(o);
       }
+      store_pair(i, rq, 0, pk[0], pk[1]);
+      store_pair(i, rq, 2, pk[2], pk[3]);
     }
 }
 

@@ -105,6 +105,9 @@ def run(opts, trainer_factory=None, loader_a=None, loader_b=None, test_batches=N
                 trainer.dis_sch.step()
                 trainer.gen_sch.step()
         trainer.cuda(gpu)
+        if getattr(opts, 'dtype', 'f32') != 'f32':
+            from . import ops as _ops
+            _ops.set_math_mode(opts.dtype)  # process-wide: bf16 MFMA conv path on bf16 activations
         if getattr(opts, 'graphs', False):
             trainer.use_graphs(True)        # hipGraph replay of the update steps (single process)
         try:                                                                             # :116-124
@@ -182,6 +185,8 @@ def build_parser():
     p.add_argument('--batch_size', type=int, default=0, help="override (reference: 1 in pretrain, YAML in estimate)")
     p.add_argument('--iterations', type=int, default=0, help="stop after this many iterations (default: YAML max_iterations)")
     p.add_argument('--data', type=str, default='synthetic', choices=['synthetic'])
+    p.add_argument('--dtype', type=str, default='f32', choices=['f32', 'bf16'],
+                   help="'bf16': bf16 MFMA conv path on bf16 activations (BASELINE config 5, e.g. with exps/nicvl.yaml); default exact f32")
     p.add_argument('--graphs', action='store_true', help="replay dis_update / gen_update / post_update from hipGraphs")
     p.add_argument('--augment', action='store_true', help="augment every batch as the datasets do (geometry on the host, pixels on the GPU)")
     return p
