@@ -229,6 +229,18 @@ int lsps_c8_pw1_dgrad(const float *dpre, const float *w, void *dx, int N, int C,
 int lsps_c8_pw1_wgrad(const void *x, const float *dpre, float *dw, float *db /*nullable*/, int N, int C, int HW,
                       void *ws, size_t ws_bytes, void *stream);
 
+/* dgrad entries with the PREVIOUS layer's LeakyReLU backward fused into the epilogue (bf16 math mode): the layer in front of
+ * this one saved its output act_y (the shape of dx); the gradient handed to it is already multiplied by LeakyReLU'(act_y)
+ * (slope act_slope >= 0) and its bias gradient db_prev [channels of dx] (nullable) comes out of per-workgroup partial sums —
+ * this replaces that layer's lsps_c8_act_bwd_bias pass (autograd of common_net.py:252,264 folded into the consumer's dgrad). */
+int lsps_c8_conv3x3s2_dgrad_act(const void *dy, const float *w, const void *act_y, float act_slope, void *dx, float *db_prev,
+                                int N, int C, int H, int W, int K, void *ws, size_t ws_bytes, void *stream);
+int lsps_c8_convT3x3s2_dgrad_act(const void *dy, const float *w, const void *act_y, float act_slope, void *dx, float *db_prev,
+                                 int N, int Ci, int H, int W, int Co, void *ws, size_t ws_bytes, void *stream);
+size_t lsps_c8_pw1_dgrad_act_workspace_bytes(int N, int C);
+int lsps_c8_pw1_dgrad_act(const float *dpre, const float *w, const void *act_y, float act_slope, void *dx, float *db_prev,
+                          int N, int C, int HW, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- ConvTranspose2d: replaces nn.ConvTranspose2d forward/backward -------------------------
  * call sites: common_net.py:262 (LeakyReLUConvTranspose2d), lsps_nets.py:226-227 (1x1 output),
  *             lsps_nets.py:17-23 (Mapping).

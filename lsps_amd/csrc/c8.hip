@@ -195,9 +195,32 @@ static int c8s2_pack(const float *w, int M, int C, long sm, long sc, int BM, voi
   return 0;
 }
 
+// out[c] = sum over `rows` rows of part[rows][C]; `scratch` >= 64 * C floats when rows > 64
+static int c8_colsum(const float *part, float *out, int C, int rows, float *scratch, hipStream_t st) {
+  if (rows > 64) {
+    const int rpc = (rows + 63) / 64, chunks = (rows + rpc - 1) / rpc;
+    hipLaunchKernelGGL(c8_colsum_stage1_kernel, dim3(ceil_div(C, 64), chunks), dim3(256), 0, st, part, scratch, C, rows, rpc);
+    LSPS_CHECK_LAUNCH("c8_colsum_stage1");
+    part = scratch;
+    rows = chunks;
+  }
+  hipLaunchKernelGGL(c8_colsum_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, out, C, rows);
+  LSPS_CHECK_LAUNCH("c8_colsum");
+  return 0;
+}
+
+// bias-gradient partial sums of a fused-activation dgrad: [ntiles][M] + [64][M] floats at the END of the workspace (the packed
+// weights, if they are not in the pack-cache scope, sit at its start)
+static float *c8s2_dbpart(void *ws, size_t ws_bytes, int ntiles, int M, size_t pack_bytes) {
+  const size_t need = ((size_t)ntiles + 64) * M * sizeof(float);
+  if (!ws || ws_bytes < align_up(pack_bytes, 256) + need) return nullptr;
+  return reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + ((ws_bytes - need) & ~(size_t)255));
+}
+
 // small[n][m] = act(bias + sum Wt[m][kk][r][s] big[n][kk][2p+r-1][2q+s-1]);  W element (m, kk, t) at m*sm + kk*sc + t
 static int c8s2_run_fwd(const void *big, const float *w, long sm, long sc, const float *bias, void *small, int N, int Cx, int H, int W,
-                        int M, float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+                        int M, float slope, void *ws, size_t ws_bytes, hipStream_t st, const void *act_y = nullptr, float act_slope = 0.f,
+                        float *db_prev = nullptr) {
   C8S2Params p;
   const int nj = c8s2_fwd_nj(N, Cx, H, W, M, &p);
   if (!nj) {
@@ -212,6 +235,16 @@ static int c8s2_run_fwd(const void *big, const float *w, long sm, long sc, const
   p.Y = (unsigned short *)small;
   p.N = N; p.Cx = Cx; p.M = M;
   p.lrelu = slope >= 0.f ? slope : 1.f;
+  p.ActY = (const unsigned short *)act_y;
+  p.act_slope = act_slope;
+  p.dbpart = nullptr;
+  if (act_y) {
+    p.dbpart = c8s2_dbpart(ws, ws_bytes, p.ntiles, M, (size_t)M * Cx * 9 * sizeof(unsigned short));
+    if (!p.dbpart) {
+      set_error("c8 stride-2 conv: workspace too small for the bias-gradient partial sums");
+      return LSPS_E_ARG;
+    }
+  }
   const dim3 grid((p.ntiles + 7) / 8 * 8 * (M >> 7));
   if (nj == 2) {
     if (int rc = lds_optin(reinterpret_cast<const void *>(c8s2_fwd_kernel<2>), C8S2F_LDS_BYTES, "c8s2_fwd")) return rc;
@@ -221,12 +254,14 @@ static int c8s2_run_fwd(const void *big, const float *w, long sm, long sc, const
     hipLaunchKernelGGL(c8s2_fwd_kernel<1>, grid, dim3(512), C8S2F_LDS_BYTES, st, p);
   }
   LSPS_CHECK_LAUNCH("c8s2_fwd");
+  if (act_y && db_prev) return c8_colsum(p.dbpart, db_prev, M, p.ntiles, p.dbpart + (size_t)p.ntiles * M, st);
   return 0;
 }
 
 // big[n][m][2p+r-1][2q+s-1] += Wt[m][kk][r][s] small[n][kk][p][q] (+ bias, activation); H x W = the big map
 static int c8s2_run_tr(const void *small, const float *w, long sm, long sc, const float *bias, void *big, int N, int Cx, int H, int W,
-                       int M, float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+                       int M, float slope, void *ws, size_t ws_bytes, hipStream_t st, const void *act_y = nullptr, float act_slope = 0.f,
+                       float *db_prev = nullptr) {
   C8S2Params p;
   if (!c8s2_tr_geom(N, Cx, H, W, M, &p)) {
     set_error("c8 stride-2 conv (transposed direction): unsupported geometry N=%d C=%d -> %dx%d M=%d", N, Cx, H, W, M);
@@ -240,9 +275,20 @@ static int c8s2_run_tr(const void *small, const float *w, long sm, long sc, cons
   p.Y = (unsigned short *)big;
   p.N = N; p.Cx = Cx; p.M = M;
   p.lrelu = slope >= 0.f ? slope : 1.f;
+  p.ActY = (const unsigned short *)act_y;
+  p.act_slope = act_slope;
+  p.dbpart = nullptr;
+  if (act_y) {
+    p.dbpart = c8s2_dbpart(ws, ws_bytes, p.ntiles, M, (size_t)M * Cx * 9 * sizeof(unsigned short));
+    if (!p.dbpart) {
+      set_error("c8 stride-2 conv: workspace too small for the bias-gradient partial sums");
+      return LSPS_E_ARG;
+    }
+  }
   if (int rc = lds_optin(reinterpret_cast<const void *>(c8s2_tr_kernel), C8S2T_LDS_BYTES, "c8s2_tr")) return rc;
   hipLaunchKernelGGL(c8s2_tr_kernel, dim3((p.ntiles + 7) / 8 * 8 * (M >> 6)), dim3(512), C8S2T_LDS_BYTES, st, p);
   LSPS_CHECK_LAUNCH("c8s2_tr");
+  if (act_y && db_prev) return c8_colsum(p.dbpart, db_prev, M, p.ntiles, p.dbpart + (size_t)p.ntiles * M, st);
   return 0;
 }
 
@@ -407,6 +453,13 @@ int lsps_c8_convT3x3s2_ok(int N, int Ci, int H, int W, int Co) {      // x [N, C
 // packed weights (forward / transposed direction) or the weight gradient's partial sums, whichever is larger; H x W = big map
 size_t lsps_c8_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K) {
   size_t need = (size_t)C * K * 9 * sizeof(unsigned short);
+  {                                    // fused-activation dgrad forms: packed weights + [ntiles + 64][channels] partial sums
+    C8S2Params q;
+    size_t part = 0;
+    if (c8s2_tr_geom(N, K, H, W, C, &q)) part = std::max(part, ((size_t)q.ntiles + 64) * C * sizeof(float));          // conv dgrad -> dx [C]
+    if (c8s2_fwd_nj(N, C, H, W, K, &q)) part = std::max(part, ((size_t)q.ntiles + 64) * K * sizeof(float));          // convT dgrad -> dx [K = Ci]
+    need = align_up(need, 256) + part + 256;
+  }
   C8S2WParams p;
   if (c8s2_wgrad_geom(N, K, C, H, W, &p)) need = std::max(need, (size_t)p.splits * 9 * K * C * sizeof(float));
   return align_up(need, 256);
@@ -516,6 +569,38 @@ int lsps_c8_pw1_wgrad(const void *x, const float *dpre, float *dw, float *db, in
   LSPS_CHECK_LAUNCH("c8_pw1_wgrad");
   hipLaunchKernelGGL(c8_pw1_wgrad_reduce_kernel, dim3(ceil_div(C + 1, 256)), dim3(256), 0, st, (const float *)ws, dw, db, C, splits);
   LSPS_CHECK_LAUNCH("c8_pw1_wgrad_reduce");
+  return 0;
+}
+
+// ---- dgrad entries with the PREVIOUS layer's LeakyReLU backward (+ its bias gradient) fused into the epilogue -----------
+int lsps_c8_conv3x3s2_dgrad_act(const void *dy, const float *w, const void *act_y, float act_slope, void *dx, float *db_prev, int N, int C,
+                                int H, int W, int K, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(dy && w && dx && act_y && act_slope >= 0.f, "c8_conv3x3s2_dgrad_act: null pointer / slope < 0");
+  return c8s2_run_tr(dy, w, 9, (long)C * 9, nullptr, dx, N, K, H, W, C, -1.f, ws, ws_bytes, (hipStream_t)stream, act_y, act_slope, db_prev);
+}
+
+int lsps_c8_convT3x3s2_dgrad_act(const void *dy, const float *w, const void *act_y, float act_slope, void *dx, float *db_prev, int N,
+                                 int Ci, int H, int W, int Co, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(dy && w && dx && act_y && act_slope >= 0.f, "c8_convT3x3s2_dgrad_act: null pointer / slope < 0");
+  return c8s2_run_fwd(dy, w, (long)Co * 9, 9, nullptr, dx, N, Co, 2 * H, 2 * W, Ci, -1.f, ws, ws_bytes, (hipStream_t)stream, act_y,
+                      act_slope, db_prev);
+}
+
+size_t lsps_c8_pw1_dgrad_act_workspace_bytes(int N, int C) { return align_up(((size_t)N + 64) * C * sizeof(float), 256); }
+
+int lsps_c8_pw1_dgrad_act(const float *dpre, const float *w, const void *act_y, float act_slope, void *dx, float *db_prev, int N, int C,
+                          int HW, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(dpre && w && act_y && dx && N > 0 && C > 0 && (C & 7) == 0 && C <= 64 && HW > 0 && act_slope >= 0.f,
+                 "c8_pw1_dgrad_act: bad arguments (C %% 8 == 0, C <= 64)");
+  LSPS_CHECK_ARG(ws && ws_bytes >= ((size_t)N + 64) * C * sizeof(float), "c8_pw1_dgrad_act: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(c8_pw1_dgrad_act_kernel, dim3(N), dim3(256), 0, st, dpre, w, (const unsigned short *)act_y, (unsigned short *)dx,
+                     (float *)ws, C, HW, act_slope);
+  LSPS_CHECK_LAUNCH("c8_pw1_dgrad_act");
+  if (db_prev) return c8_colsum((const float *)ws, db_prev, C, N, (float *)ws + (size_t)N * C, st);
   return 0;
 }
 

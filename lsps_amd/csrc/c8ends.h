@@ -40,6 +40,44 @@ __global__ __launch_bounds__(256) void c8_pw1_dgrad_kernel(const float *__restri
   }
 }
 
+// dx[n][c][pix] = w[c] * dpre[n][pix] * (y[n][c][pix] > 0 ? 1 : slope): the head's input gradient with the LeakyReLU backward of
+// the layer in front of it (whose saved output is y) fused, and that layer's bias gradient as per-image partial sums
+// part[n][c] (C <= 64).  One workgroup per image.
+__global__ __launch_bounds__(256) void c8_pw1_dgrad_act_kernel(const float *__restrict__ dpre, const float *__restrict__ w,
+                                                               const unsigned short *__restrict__ y, unsigned short *__restrict__ dx,
+                                                               float *__restrict__ part, int C, int HW, float slope) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = C >> 3;
+  const u32x4 *yp = reinterpret_cast<const u32x4 *>(y) + (long)n * G * HW;
+  u32x4 *xp = reinterpret_cast<u32x4 *>(dx) + (long)n * G * HW;
+  float s[64];
+#pragma unroll
+  for (int e = 0; e < 64; ++e) s[e] = 0.f;
+  for (int px = tid; px < HW; px += 256) {
+    const float d = dpre[(long)n * HW + px];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (g >= G) break;
+      const bf16x8 yv = __builtin_bit_cast(bf16x8, yp[(long)g * HW + px]);
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = w[g * 8 + e] * d;
+        v[e] = (__bf16)c8_sel_nonpos((float)yv[e], x * slope, x);
+        s[g * 8 + e] += (float)v[e];
+      }
+      xp[(long)g * HW + px] = __builtin_bit_cast(u32x4, v);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 64; ++e) {
+    const float t = wave_sum(s[e]);
+    if (lane == 0) red[wave][e] = t;
+  }
+  __syncthreads();
+  if (tid < C) part[(long)n * C + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
 // part[split][c] = sum over the split's images and all pixels of x[n][c][pix] * dpre[n][pix];  part[split][C] = sum of dpre
 // (the bias gradient; written by the blocks of channel group 0).  grid (C / 8, splits).
 __global__ __launch_bounds__(256) void c8_pw1_wgrad_kernel(const unsigned short *__restrict__ x, const float *__restrict__ dpre,

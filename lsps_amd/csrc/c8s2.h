@@ -36,6 +36,12 @@ struct C8S2Params {
   int TI, TR;                    // pixel tile (of the SMALL map): TI images x TR rows x Q columns
   int tiles_per_img, ntiles;
   float lrelu;                   // epilogue: v = max(v, v * lrelu) (1 = no activation; 0 <= slope <= 1)
+  // dgrad entries with the PREVIOUS layer's LeakyReLU backward fused (the layer whose output this gradient belongs to):
+  // y = y * (ActY > 0 ? 1 : act_slope) with ActY that layer's saved output (Y's shape), and dbpart[pixel tile][M] = the
+  // per-channel sums of the masked result over the workgroup's pixels (that layer's bias gradient, summed by c8_colsum_kernel)
+  const unsigned short *ActY;
+  float act_slope;
+  float *dbpart;
 };
 
 struct C8S2Pack {
@@ -190,6 +196,22 @@ __global__ __launch_bounds__(512, 1) void c8s2_fwd_kernel(C8S2Params p) {
 
   // epilogue: acc[i][j][r] = channel mt*128 + wm*64 + i*32 + (r&3) + 8 (r>>2) + 4 half of pixel j; a register quad = 8 bytes
   typedef unsigned long long u64;
+  const bool masked = p.ActY != nullptr;                        // uniform
+  u64 ay[2][4][NJ];                                              // the mask operand's pieces, all fetched before the first store
+  if (masked) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int m4 = mt * 128 + wm * 64 + i * 32 + 8 * rq + 4 * half;
+          ay[i][rq][j] = ypix[j] >= 0 ? reinterpret_cast<const u64 *>(p.ActY)[((ypix[j] + (long)(m4 >> 3) * PQ) << 1) + half] : 0ull;
+        }
+  }
+  float sdb[32];
+#pragma unroll
+  for (int e = 0; e < 32; ++e) sdb[e] = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -203,12 +225,33 @@ __global__ __launch_bounds__(512, 1) void c8s2_fwd_kernel(C8S2Params p) {
         bf16x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float x = acc[i][j][rq * 4 + e] + b4[e];
-          v[e] = (__bf16)fmaxf(x, x * p.lrelu);
+          float x = acc[i][j][rq * 4 + e] + b4[e];
+          x = fmaxf(x, x * p.lrelu);
+          if (masked) {
+            const bf16x4 a = __builtin_bit_cast(bf16x4, ay[i][rq][j]);
+            x = c8_sel_nonpos((float)a[e], x * p.act_slope, x);
+          }
+          v[e] = (__bf16)x;
+          if (masked) sdb[i * 16 + rq * 4 + e] += (float)v[e];
         }
         reinterpret_cast<u64 *>(p.Y)[((ypix[j] + (long)(m4 >> 3) * PQ) << 1) + half] = __builtin_bit_cast(u64, v);
       }
     }
+  if (masked) {
+    // per-channel sums over the workgroup's pixels: butterfly over the 32 pixel lanes of a half, then over the 4 pixel waves
+    c8_reduce_scatter32<16>(sdb, l31);                           // lane (half, l31): slot l31 = i*16 + r of its half
+    float *red = reinterpret_cast<float *>(s2_lds);              // [wave 8][half 2][32]   (the stages are dead: last barrier passed)
+    red[(wave * 2 + half) * 32 + l31] = sdb[0];
+    __syncthreads();
+    if (tid < 128) {                                             // (wm, half, slot)
+      const int w_m = tid >> 6, hf = (tid >> 5) & 1, qs = tid & 31;
+      float t = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) t += red[((w4 * 2 + w_m) * 2 + hf) * 32 + qs];
+      const int m = mt * 128 + w_m * 64 + (qs >> 4) * 32 + (qs & 3) + 8 * ((qs >> 2) & 3) + 4 * hf;
+      p.dbpart[(long)ptile * p.M + m] = t;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -341,6 +384,27 @@ __global__ __launch_bounds__(512, 1) void c8s2_tr_kernel(C8S2Params p) {
   // epilogue.  acc[cls][j][r]: channel mt*64 + wm*32 + (r&3) + 8 (r>>2) + 4 half at output (2p + a, 2q + b).  The two column
   // classes of a row are exchanged across the half-waves (v_permlane32_swap: cdna_hip_programming.md T21) so that lanes 0-31
   // store the whole 16-byte unit of column 2q and lanes 32-63 that of column 2q + 1: 1 KB contiguous per wave instruction.
+  typedef unsigned long long u64;
+  const bool masked = p.ActY != nullptr;                        // uniform
+  u64 ay[4][2][2][2];                                            // [rq][a][j][b]: the mask operand's pieces, fetched before the first store
+  if (masked) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int m8 = mt * 64 + wm * 32 + 8 * rq;
+            ay[rq][a][j][b] = ypix[j] >= 0
+                                  ? reinterpret_cast<const u64 *>(p.ActY)[((ypix[j] + (long)(m8 >> 3) * HWl + (long)a * p.W + b) << 1) + half]
+                                  : 0ull;
+          }
+  }
+  float sdb[32];
+#pragma unroll
+  for (int e = 0; e < 32; ++e) sdb[e] = 0.f;
 #pragma unroll
   for (int rq = 0; rq < 4; ++rq) {
     const int m8 = mt * 64 + wm * 32 + 8 * rq;                  // channel group's first channel
@@ -356,8 +420,14 @@ __global__ __launch_bounds__(512, 1) void c8s2_tr_kernel(C8S2Params p) {
           bf16x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float x = acc[a * 2 + b][j][rq * 4 + e] + b4[e];
-            v[e] = (__bf16)fmaxf(x, x * p.lrelu);
+            float x = acc[a * 2 + b][j][rq * 4 + e] + b4[e];
+            x = fmaxf(x, x * p.lrelu);
+            if (masked) {
+              const bf16x4 m_ = __builtin_bit_cast(bf16x4, ay[rq][a][j][b]);
+              x = c8_sel_nonpos((float)m_[e], x * p.act_slope, x);
+            }
+            v[e] = (__bf16)x;
+            if (masked && ypix[j] >= 0) sdb[rq * 4 + e] += (float)v[e];
           }
           const uint2 u = __builtin_bit_cast(uint2, v);
           w[b][0] = u.x;
@@ -374,6 +444,24 @@ __global__ __launch_bounds__(512, 1) void c8s2_tr_kernel(C8S2Params p) {
         u32x4 o = {w[0][0], w[0][1], w[1][0], w[1][1]};
         reinterpret_cast<u32x4 *>(p.Y)[unit] = o;
       }
+  }
+  if (masked) {
+    // 16 channel slots per lane: add the two 16-lane halves of the 32 pixel lanes, butterfly over the remaining four bits,
+    // then sum the 4 pixel waves through LDS
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sdb[e] += __shfl_xor(sdb[e], 16, 64);
+    c8_reduce_scatter32<8>(sdb, l31);                            // lane: slot (l31 & 15) = r of its half
+    float *red = reinterpret_cast<float *>(s2_lds);              // [wave 8][half 2][16]
+    if ((l31 & 16) == 0) red[(wave * 2 + half) * 16 + l31] = sdb[0];
+    __syncthreads();
+    if (tid < 64) {                                              // (wm, half, slot)
+      const int w_m = tid >> 5, hf = (tid >> 4) & 1, qs = tid & 15;
+      float t = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) t += red[((w4 * 2 + w_m) * 2 + hf) * 16 + qs];
+      const int m = mt * 64 + w_m * 32 + (qs & 3) + 8 * (qs >> 2) + 4 * hf;
+      p.dbpart[(long)ptile * p.M + m] = t;
+    }
   }
 }
 
@@ -570,6 +658,21 @@ __global__ __launch_bounds__(256) void c8_act_bwd_bias_kernel(const unsigned sho
   }
   __syncthreads();
   if (tid < 8) dbpart[(long)split * C + cg * 8 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// part2[chunk][c] = sum of rows [chunk * rows_per_chunk, ...) of part[rows][C]: the first stage of a column sum over many rows
+// (per-workgroup bias-gradient partials: up to thousands of rows); grid (ceil(C / 64), chunks), thread = (row lane 0..3, channel)
+__global__ __launch_bounds__(256) void c8_colsum_stage1_kernel(const float *__restrict__ part, float *__restrict__ part2, int C, int rows,
+                                                               int rows_per_chunk) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, chunk = blockIdx.y;
+  const int r0 = chunk * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float s = 0.f;
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 4) s += part[(long)r * C + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) part2[(long)chunk * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void c8_colsum_kernel(const float *__restrict__ part, float *__restrict__ out, int C, int splits) {

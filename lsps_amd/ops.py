@@ -703,6 +703,22 @@ def c8_convT_s2_ok(x, w, stride, pad, outpad):
     return N > 0 and C == w.shape[0] and _lib.lib().lsps_c8_convT3x3s2_ok(N, C, H, W, w.shape[1]) == 1
 
 
+class ActHolder(object):
+    """Shared by a C8 layer with a fused LeakyReLU epilogue (the producer) and the ONE layer that consumes its output
+    (common_net.run_layers pairs consecutive layers): the consumer's dgrad kernel multiplies the gradient it hands back by
+    LeakyReLU'(producer output) in its epilogue and leaves the producer's bias gradient here, so the producer's own
+    activation-backward pass (lsps_c8_act_bwd_bias: 6 bytes per element over the layer's output) is skipped."""
+    __slots__ = ('slope', 'fused', 'db')
+
+    def __init__(self, slope):
+        self.slope, self.fused, self.db = float(slope), False, None
+
+
+def _fusable(prev):
+    import os
+    return prev is not None and prev.slope >= 0 and os.environ.get('LSPS_C8_FUSE_ACT', '1') != '0'
+
+
 def _c8_act_backward(L, dy, y, slope, want_db, channels, st):
     """g = dy * LeakyReLU'(y) from the layer's OUTPUT (+ the bias gradient in the same pass) on C8 tensors."""
     if slope < 0:
@@ -721,11 +737,12 @@ class _ConvS2C8Fn(torch.autograd.Function):
     """LeakyReLUConv2d(C, K, 3, 2, 1) (common_net.py:246-256) on a C8 tensor: x [N][C/8][H][W][8] -> [N][K/8][H/2][W/2][8]."""
 
     @staticmethod
-    def forward(ctx, x, w, b, slope):
+    def forward(ctx, x, w, b, slope, prev, own):
         L = _lib.lib()
         x, w = _c(x), _c(w)
         N, G, H, W, _ = x.shape
         C, K = G * 8, w.shape[0]
+        ctx.prev, ctx.own = prev, own
         y = torch.empty((N, K // 8, H // 2, W // 2, 8), dtype=BF16, device=x.device)
         ws, wsb = _lib.workspace(L.lsps_c8_conv3x3s2_workspace_bytes(N, C, H, W, K), x.device)
         with profiler.span(2.0 * N * K * (H // 2) * (W // 2) * C * 9, 'c8s2_fwd_kernel'):
@@ -745,7 +762,12 @@ class _ConvS2C8Fn(torch.autograd.Function):
         st = _lib.stream()
         flops = 2.0 * N * K * (H // 2) * (W // 2) * C * 9
         dx = dw = db = None
-        g, db = _c8_act_backward(L, dy, y, slope, ctx.has_bias and ctx.needs_input_grad[2], K, st)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.own is not None and ctx.own.fused:        # the consumer's dgrad epilogue already applied this layer's LeakyReLU'
+            g, db = dy, (ctx.own.db if want_db else None)
+            ctx.own.fused, ctx.own.db = False, None
+        else:
+            g, db = _c8_act_backward(L, dy, y, slope, want_db, K, st)
         ws, wsb = _lib.workspace(L.lsps_c8_conv3x3s2_workspace_bytes(N, C, H, W, K), x.device)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
@@ -755,13 +777,20 @@ class _ConvS2C8Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             with profiler.span(flops, 'c8s2_tr_kernel'):
-                _lib.check(L.lsps_c8_conv3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(dx, BF16), N, C, H, W, K, ws, wsb, st),
-                           'c8_conv3x3s2_dgrad')
-        return dx, dw, db, None
+                if _fusable(ctx.prev):                   # x is the previous layer's output: its LeakyReLU backward rides along
+                    dbp = torch.empty(C, dtype=torch.float32, device=x.device)
+                    _lib.check(L.lsps_c8_conv3x3s2_dgrad_act(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(x, BF16), ctx.prev.slope,
+                                                             _lib.ptr(dx, BF16), _lib.ptr(dbp), N, C, H, W, K, ws, wsb, st),
+                               'c8_conv3x3s2_dgrad_act')
+                    ctx.prev.fused, ctx.prev.db = True, dbp
+                else:
+                    _lib.check(L.lsps_c8_conv3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(dx, BF16), N, C, H, W, K, ws, wsb, st),
+                               'c8_conv3x3s2_dgrad')
+        return dx, dw, db, None, None, None
 
 
-def conv3x3s2_c8(x, w, b=None, slope=LRELU_SLOPE):
-    return _ConvS2C8Fn.apply(x, w, b, float(slope))
+def conv3x3s2_c8(x, w, b=None, slope=LRELU_SLOPE, prev=None, own=None):
+    return _ConvS2C8Fn.apply(x, w, b, float(slope), prev, own)
 
 
 class _ConvTS2C8Fn(torch.autograd.Function):
@@ -769,11 +798,12 @@ class _ConvTS2C8Fn(torch.autograd.Function):
     x [N][Ci/8][H][W][8] -> [N][Co/8][2H][2W][8]."""
 
     @staticmethod
-    def forward(ctx, x, w, b, slope):
+    def forward(ctx, x, w, b, slope, prev, own):
         L = _lib.lib()
         x, w = _c(x), _c(w)
         N, G, H, W, _ = x.shape
         Ci, Co = G * 8, w.shape[1]
+        ctx.prev, ctx.own = prev, own
         y = torch.empty((N, Co // 8, 2 * H, 2 * W, 8), dtype=BF16, device=x.device)
         ws, wsb = _lib.workspace(L.lsps_c8_conv3x3s2_workspace_bytes(N, Co, 2 * H, 2 * W, Ci), x.device)
         with profiler.span(2.0 * N * Ci * H * W * Co * 9, 'c8s2_tr_kernel'):
@@ -793,7 +823,12 @@ class _ConvTS2C8Fn(torch.autograd.Function):
         st = _lib.stream()
         flops = 2.0 * N * Ci * H * W * Co * 9
         dx = dw = db = None
-        g, db = _c8_act_backward(L, dy, y, slope, ctx.has_bias and ctx.needs_input_grad[2], Co, st)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.own is not None and ctx.own.fused:
+            g, db = dy, (ctx.own.db if want_db else None)
+            ctx.own.fused, ctx.own.db = False, None
+        else:
+            g, db = _c8_act_backward(L, dy, y, slope, want_db, Co, st)
         ws, wsb = _lib.workspace(L.lsps_c8_conv3x3s2_workspace_bytes(N, Co, 2 * H, 2 * W, Ci), x.device)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
@@ -803,13 +838,20 @@ class _ConvTS2C8Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             with profiler.span(flops, 'c8s2_fwd_kernel'):
-                _lib.check(L.lsps_c8_convT3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(dx, BF16), N, Ci, H, W, Co, ws, wsb, st),
-                           'c8_convT3x3s2_dgrad')
-        return dx, dw, db, None
+                if _fusable(ctx.prev):
+                    dbp = torch.empty(Ci, dtype=torch.float32, device=x.device)
+                    _lib.check(L.lsps_c8_convT3x3s2_dgrad_act(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(x, BF16), ctx.prev.slope,
+                                                              _lib.ptr(dx, BF16), _lib.ptr(dbp), N, Ci, H, W, Co, ws, wsb, st),
+                               'c8_convT3x3s2_dgrad_act')
+                    ctx.prev.fused, ctx.prev.db = True, dbp
+                else:
+                    _lib.check(L.lsps_c8_convT3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(dx, BF16), N, Ci, H, W, Co, ws, wsb,
+                                                          st), 'c8_convT3x3s2_dgrad')
+        return dx, dw, db, None, None, None
 
 
-def convT3x3s2_c8(x, w, b=None, slope=LRELU_SLOPE):
-    return _ConvTS2C8Fn.apply(x, w, b, float(slope))
+def convT3x3s2_c8(x, w, b=None, slope=LRELU_SLOPE, prev=None, own=None):
+    return _ConvTS2C8Fn.apply(x, w, b, float(slope), prev, own)
 
 
 def c8_stem_ok(x, w, stride, pad):
@@ -882,10 +924,11 @@ class _Pw1C8Fn(torch.autograd.Function):
     """ConvTranspose2d(C, 1, kernel 1) [+ Tanh] on a C8 tensor (lsps_nets.py:226-229): x [N][C/8][H][W][8] -> y f32 [N,1,H,W]."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, slope):
+    def forward(ctx, x, w, b, act, slope, prev):
         L = _lib.lib()
         x, w = _c(x), _c(w)
         N, G, H, W, _ = x.shape
+        ctx.prev = prev
         y = torch.empty((N, 1, H, W), dtype=torch.float32, device=x.device)
         with profiler.span(2.0 * N * G * 8 * H * W, 'pw1_fwd_kernel'):
             _lib.check(L.lsps_c8_pw1_fwd(_lib.ptr(x, BF16), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, G * 8, H * W, act, slope,
@@ -912,7 +955,14 @@ class _Pw1C8Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             with profiler.span(flops, 'pw1_dgrad_kernel'):
-                _lib.check(L.lsps_c8_pw1_dgrad(_lib.ptr(dpre), _lib.ptr(w), _lib.ptr(dx, BF16), N, C, H * W, st), 'c8_pw1_dgrad')
+                if _fusable(ctx.prev) and C <= 64:
+                    dbp = torch.empty(C, dtype=torch.float32, device=x.device)
+                    wsd, wsdb = _lib.workspace(L.lsps_c8_pw1_dgrad_act_workspace_bytes(N, C), x.device)
+                    _lib.check(L.lsps_c8_pw1_dgrad_act(_lib.ptr(dpre), _lib.ptr(w), _lib.ptr(x, BF16), ctx.prev.slope, _lib.ptr(dx, BF16),
+                                                       _lib.ptr(dbp), N, C, H * W, wsd, wsdb, st), 'c8_pw1_dgrad_act')
+                    ctx.prev.fused, ctx.prev.db = True, dbp
+                else:
+                    _lib.check(L.lsps_c8_pw1_dgrad(_lib.ptr(dpre), _lib.ptr(w), _lib.ptr(dx, BF16), N, C, H * W, st), 'c8_pw1_dgrad')
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_db:
             dw = torch.empty_like(w)
@@ -921,11 +971,11 @@ class _Pw1C8Fn(torch.autograd.Function):
             with profiler.span(flops, 'pw1_wgrad_kernel'):
                 _lib.check(L.lsps_c8_pw1_wgrad(_lib.ptr(x, BF16), _lib.ptr(dpre), _lib.ptr(dw), _lib.ptr(db), N, C, H * W, ws, wsb, st),
                            'c8_pw1_wgrad')
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def pw1_c8(x, w, b=None, act=ACT_NONE, slope=LRELU_SLOPE):
-    return _Pw1C8Fn.apply(x, w, b, int(act), float(slope))
+def pw1_c8(x, w, b=None, act=ACT_NONE, slope=LRELU_SLOPE, prev=None):
+    return _Pw1C8Fn.apply(x, w, b, int(act), float(slope), prev)
 
 
 class _ResBlockC8Fn(torch.autograd.Function):

@@ -113,6 +113,7 @@ def run_layers(layers, x, noise=None):
     LeakyReLUConv2d and LeakyReLUConvTranspose2d layers, GaussianNoiseLayer — run on such tensors: `x` is converted in front
     of the first of them, stays in that layout through consecutive ones and is converted back in front of any other layer
     (the caller converts what it hands out: ops.from_c8)."""
+    prev = None            # ops.ActHolder of the C8 layer whose output `x` is (consecutive layers: nobody else consumes it)
     for l in layers:
         if isinstance(l, LeakyINSResBlock):
             ch = l.model[0].weight.shape[0]
@@ -121,22 +122,35 @@ def run_layers(layers, x, noise=None):
                 x = ops.to_c8(x)
             else:
                 x = ops.from_c8(x)
-            x = l(x)
+            x, prev = l(x), None
         elif isinstance(l, LeakyReLUConv2d):
             c = l.model[0]
             if ops.c8_stem_ok(x, c.weight, c.stride, c.padding):     # 7x7 stem: f32 image in, C8 activation out
-                x = ops.stem_c8(x, c.weight, c.bias, c.stride, c.padding, LRELU_SLOPE)
+                x, prev = ops.stem_c8(x, c.weight, c.bias, c.stride, c.padding, LRELU_SLOPE), None
+            elif ops.c8_conv_s2_ok(x, c.weight, c.stride, c.padding):
+                xin = ops.to_c8(x)
+                own = ops.ActHolder(LRELU_SLOPE)
+                x = ops.conv3x3s2_c8(xin, c.weight, c.bias, LRELU_SLOPE, prev if xin is x else None, own)
+                prev = own
             else:
-                x = l(ops.to_c8(x) if ops.c8_conv_s2_ok(x, c.weight, c.stride, c.padding) else ops.from_c8(x))
+                x, prev = l(ops.from_c8(x)), None
         elif isinstance(l, LeakyReLUConvTranspose2d):
             c = l.model[0]
-            x = l(ops.to_c8(x) if ops.c8_convT_s2_ok(x, c.weight, c.stride, c.padding, c.output_padding) else ops.from_c8(x))
+            if ops.c8_convT_s2_ok(x, c.weight, c.stride, c.padding, c.output_padding):
+                xin = ops.to_c8(x)
+                own = ops.ActHolder(LRELU_SLOPE)
+                x = ops.convT3x3s2_c8(xin, c.weight, c.bias, LRELU_SLOPE, prev if xin is x else None, own)
+                prev = own
+            else:
+                x, prev = l(ops.from_c8(x)), None
         elif isinstance(l, GaussianNoiseLayer):
-            x = l(x, noise)
+            x, prev = l(x, noise), None
         elif isinstance(l, ConvTranspose2d) and ops.c8_pw1_ok(x, l.weight, l.stride, l.padding, l.output_padding):
-            x = ops.pw1_c8(x, l.weight, l.bias, l.act, LRELU_SLOPE)      # 1x1 output head (+ Tanh) straight from the C8 tensor
+            x, prev = ops.pw1_c8(x, l.weight, l.bias, l.act, LRELU_SLOPE, prev), None      # 1x1 output head (+ Tanh) straight from C8
+        elif isinstance(l, _Fused):
+            pass
         else:
-            x = l(ops.from_c8(x))
+            x, prev = l(ops.from_c8(x)), None
     return x
 
 

@@ -185,3 +185,103 @@ def test_c8_pw1_head(N, C, H):
     _lib.check(L.lsps_c8_pw1_wgrad(xc.data_ptr(), dpre.data_ptr(), dw.data_ptr(), db.data_ptr(), N, C, H * H, ws, wsb, st), 'pw1 wgrad')
     assert _rel(dw.view(C), (xd * dpre.double().cpu()).sum((0, 2, 3))) <= 1e-4
     assert _rel(db, dpre.double().cpu().sum().view(1)) <= 1e-4
+
+
+@pytest.mark.parametrize("N,C,H,K", [(3, 64, 128, 128), (5, 128, 32, 256), (21, 512, 8, 1024), (70, 1024, 4, 2048)])
+def test_c8_conv3x3s2_dgrad_with_fused_previous_activation(N, C, H, K):
+    """conv dgrad whose epilogue applies the PREVIOUS layer's LeakyReLU backward and sums that layer's bias gradient."""
+    _need_gpu()
+    _lib, L, dev, st = _env()
+    g = torch.Generator().manual_seed(N * 3 + C + H + K)
+    w = _rand(g, K, C, 3, 3, scale=1.0 / (3.0 * C ** 0.5))
+    P = H // 2
+    dy = _rand(g, N, K, P, P)
+    yprev = F.leaky_relu(torch.randn(N, C, H, H, generator=g), 0.01).cuda()
+    dyc, yc = _to_c8(dy), _to_c8(yprev)
+    ws, wsb = _ws(L, _lib, dev, N, C, H, K)
+    dx = torch.full((N, C // 8, H, H, 8), 7.0, dtype=BF, device=dev)
+    db = torch.full((C,), 7.0, device=dev)
+    _lib.check(L.lsps_c8_conv3x3s2_dgrad_act(dyc.data_ptr(), w.data_ptr(), yc.data_ptr(), 0.01, dx.data_ptr(), db.data_ptr(), N, C, H, H, K,
+                                             ws, wsb, st), 'dgrad_act')
+    ref = F.conv_transpose2d(_rb(dy).double().cpu(), _rb(w).double().cpu(), stride=2, padding=1, output_padding=1)
+    ref = torch.where(_rb(yprev).double().cpu() > 0, ref, ref * 0.01)
+    got = _from_c8(dx)
+    assert _rel(got, ref) <= C8_TOL
+    assert _rel(db, got.double().cpu().sum((0, 2, 3))) <= 1e-5 * max(1.0, (N * H * H) ** 0.5 / 8)
+
+
+@pytest.mark.parametrize("N,Ci,H,Co", [(3, 256, 32, 128), (3, 128, 64, 64), (19, 128, 2, 64)])
+def test_c8_convT3x3s2_dgrad_with_fused_previous_activation(N, Ci, H, Co):
+    _need_gpu()
+    _lib, L, dev, st = _env()
+    g = torch.Generator().manual_seed(N * 5 + Ci + H + Co)
+    w = _rand(g, Ci, Co, 3, 3, scale=1.0 / (1.5 * Ci ** 0.5))
+    Ho = 2 * H
+    dy = _rand(g, N, Co, Ho, Ho)
+    yprev = F.leaky_relu(torch.randn(N, Ci, H, H, generator=g), 0.01).cuda()
+    dyc, yc = _to_c8(dy), _to_c8(yprev)
+    ws, wsb = _lib.workspace(L.lsps_c8_conv3x3s2_workspace_bytes(N, Co, Ho, Ho, Ci), dev)
+    dx = torch.full((N, Ci // 8, H, H, 8), 7.0, dtype=BF, device=dev)
+    db = torch.full((Ci,), 7.0, device=dev)
+    _lib.check(L.lsps_c8_convT3x3s2_dgrad_act(dyc.data_ptr(), w.data_ptr(), yc.data_ptr(), 0.01, dx.data_ptr(), db.data_ptr(), N, Ci, H, H,
+                                              Co, ws, wsb, st), 'convT dgrad_act')
+    ref = F.conv2d(_rb(dy).double().cpu(), _rb(w).double().cpu(), None, stride=2, padding=1)
+    ref = torch.where(_rb(yprev).double().cpu() > 0, ref, ref * 0.01)
+    got = _from_c8(dx)
+    assert _rel(got, ref) <= C8_TOL
+    assert _rel(db, got.double().cpu().sum((0, 2, 3))) <= 1e-5 * max(1.0, (N * H * H) ** 0.5 / 8)
+
+
+def test_c8_pw1_dgrad_with_fused_previous_activation():
+    _need_gpu()
+    _lib, L, dev, st = _env()
+    N, C, H = 70, 64, 32
+    g = torch.Generator().manual_seed(9)
+    w = _rand(g, C, 1, 1, 1, scale=0.2)
+    dpre = _rand(g, N, 1, H, H)
+    yprev = F.leaky_relu(torch.randn(N, C, H, H, generator=g), 0.01).cuda()
+    yc = _to_c8(yprev)
+    dx = torch.full((N, C // 8, H, H, 8), 7.0, dtype=BF, device=dev)
+    db = torch.full((C,), 7.0, device=dev)
+    ws, wsb = _lib.workspace(L.lsps_c8_pw1_dgrad_act_workspace_bytes(N, C), dev)
+    _lib.check(L.lsps_c8_pw1_dgrad_act(dpre.data_ptr(), w.data_ptr(), yc.data_ptr(), 0.01, dx.data_ptr(), db.data_ptr(), N, C, H * H, ws, wsb,
+                                       st), 'pw1 dgrad_act')
+    ref = F.conv2d(dpre.double().cpu(), w.double().cpu())
+    ref = torch.where(_rb(yprev).double().cpu() > 0, ref, ref * 0.01)
+    got = _from_c8(dx)
+    assert _rel(got, ref) <= C8_TOL
+    assert _rel(db, got.double().cpu().sum((0, 2, 3))) <= 1e-5 * max(1.0, (N * H * H) ** 0.5 / 8)
+
+
+def test_fused_activation_backward_equals_the_separate_pass(monkeypatch):
+    """Decoder tail + encoder head of SharedResGen on the C8 kernels (run_layers): gradients with the LeakyReLU backward fused
+    into the consumers' dgrad epilogues against the same chain with the separate pass (LSPS_C8_FUSE_ACT=0)."""
+    _need_gpu()
+    from lsps_amd import ops
+    from lsps_amd.trainers import common_net as cn
+    torch.manual_seed(3)
+    dev = torch.device('cuda')
+    dec = [cn.LeakyReLUConvTranspose2d(256, 128, 3, 2, 1, 1), cn.LeakyReLUConvTranspose2d(128, 64, 3, 2, 1, 1),
+           cn.ConvTranspose2d(64, 1, 1, 1, 0, act=cn.ACT_TANH)]
+    enc = [cn.LeakyReLUConv2d(1, 64, 7, 1, 3), cn.LeakyReLUConv2d(64, 128, 3, 2, 1), cn.LeakyReLUConv2d(128, 256, 3, 2, 1)]
+    for m in dec + enc:
+        m.to(dev)
+    z = torch.randn(3, 256, 32, 32, device=dev)
+    ops.set_math_mode('bf16')
+    try:
+        res = []
+        for fuse in ('1', '0'):
+            monkeypatch.setenv('LSPS_C8_FUSE_ACT', fuse)
+            for m in dec + enc:
+                for p in m.parameters():
+                    p.grad = None
+            zz = z.clone().requires_grad_(True)
+            out = cn.run_layers(dec, zz)                               # f32 [3, 1, 128, 128]
+            lat = ops.from_c8(cn.run_layers(enc, out))
+            (lat.square().mean() + out.abs().mean()).backward()
+            res.append([zz.grad.clone()] + [p.grad.clone() for m in dec + enc for p in m.parameters()])
+    finally:
+        ops.set_math_mode('f32')
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-12, (a.shape, float((a - b).abs().max()), float(b.abs().max()))
+    assert any(not torch.equal(a, b) for a, b in zip(*res))            # the fused path really ran
