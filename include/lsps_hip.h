@@ -241,6 +241,20 @@ size_t lsps_c8_pw1_dgrad_act_workspace_bytes(int N, int C);
 int lsps_c8_pw1_dgrad_act(const float *dpre, const float *w, const void *act_y, float act_slope, void *dx, float *db_prev,
                           int N, int C, int HW, void *ws, size_t ws_bytes, void *stream);
 
+/* f32 mode: the LeakyReLU backward of two layers folded into kernels that stream their tensors anyway.
+ *   lsps_conv2d_stem_wgrad_act  dw [K,1,R,S] and db [K] (nullable) of a one-input-channel LeakyReLUConv2d (the 7x7 stems,
+ *                               lsps_nets.py:117,184) from the image x, the gradient dy w.r.t. the layer's OUTPUT and the saved
+ *                               output y: replaces lsps_act_bwd_bias + lsps_conv2d_wgrad when no input gradient is needed
+ *   lsps_pw1_dgrad_act          dx [N,C,HW] = w[c] * dpre [N,HW] * LeakyReLU'(act_y [N,C,HW]) of the ConvTranspose2d(C, 1, 1) output
+ *                               head (lsps_nets.py:226-227) with the backward of the layer in front of it fused; db_prev [C]
+ *                               (nullable) = that layer's bias gradient */
+int lsps_conv2d_stem_wgrad_act_ok(int N, int H, int W, int K, int R, int S, int stride, int pad);
+int lsps_conv2d_stem_wgrad_act(const float *x, const float *dy, const float *y, float *dw, float *db /*nullable*/, int N, int H, int W,
+                               int K, int R, int S, int stride, int pad, float slope, void *ws, size_t ws_bytes, void *stream);
+size_t lsps_pw1_dgrad_act_workspace_bytes(int N, int C);
+int lsps_pw1_dgrad_act(const float *dpre, const float *w, const float *act_y, float act_slope, float *dx, float *db_prev /*nullable*/,
+                       int N, int C, int HW, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- ConvTranspose2d: replaces nn.ConvTranspose2d forward/backward -------------------------
  * call sites: common_net.py:262 (LeakyReLUConvTranspose2d), lsps_nets.py:226-227 (1x1 output),
  *             lsps_nets.py:17-23 (Mapping).

@@ -168,6 +168,7 @@ struct C1WParams {
   // T of the same product (its B operand is a row of ones): no separate activation-backward pass over the largest
   // activation of the net.  part is [blocks][K * (T + 1)] then.
   const unsigned short *DYc, *Yc;
+  const float *Yf;               // f32 mode: the layer's saved OUTPUT [N][K][P][Q] (same fusion on f32 tensors, DY = dy); or null
   float slope;
   float *part;                   // [blocks][K * T]
   int N, H, Wd, K, P, Q, R, S, stride, pad;
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void c1_wgrad_kernel(C1WParams p) {
   __shared__ __attribute__((aligned(16))) float lds[64 * C1W_LDA + 2 * C1W_XMAX];
   float *dys = lds, *xs = lds + 64 * C1W_LDA;
   const bool c8 = p.DYc != nullptr;                       // wave-uniform
+  const bool fuse = c8 || p.Yf != nullptr;                // LeakyReLU backward while staging + bias gradient as tap column T
   for (int u = threadIdx.x; u < C1W_XMAX; u += 256) xs[C1W_XMAX + u] = 1.f;      // the bias-gradient "tap" reads ones
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void c1_wgrad_kernel(C1WParams p) {
   for (int j = 0; j < 2; ++j) {
     const int t = j * 32 + l31;
     const int r = t < T ? t / p.S : 0, c = t < T ? t - r * p.S : 0;
-    toff[j] = (c8 && t == T) ? C1W_XMAX : r * p.LW + c;
+    toff[j] = (fuse && t == T) ? C1W_XMAX : r * p.LW + c;
   }
   f32x16 acc[2][2];
 #pragma unroll
@@ -250,6 +252,15 @@ __global__ __launch_bounds__(256, 2) void c1_wgrad_kernel(C1WParams p) {
       const float *dyn = p.DY + (long)n * p.K * PQ + (long)pr * p.Q;
 #pragma unroll
       for (int i = 0; i < 8; ++i) dreg[i] = *reinterpret_cast<const f32x4 *>(dyn + d_off[i]);
+      if (p.Yf) {
+        const float *yn = p.Yf + (long)n * p.K * PQ + (long)pr * p.Q;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 yv = *reinterpret_cast<const f32x4 *>(yn + d_off[i]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dreg[i][e] = yv[e] > 0.f ? dreg[i][e] : dreg[i][e] * p.slope;
+        }
+      }
     }
     const float *xn = p.X + (long)n * HWx;
     const int row0 = pr * p.stride - p.pad;
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void c1_wgrad_kernel(C1WParams p) {
     }
   }
   __syncthreads();
-  const int To = c8 ? T + 1 : T;                           // C8: column T = the bias gradient
+  const int To = fuse ? T + 1 : T;                         // fused form: column T = the bias gradient
   float *out = p.part + (long)blockIdx.x * p.K * To;
   for (int u = tid; u < p.K * To; u += 256) {
     const int k = u / To, t = u - k * To;

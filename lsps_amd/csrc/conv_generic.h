@@ -550,6 +550,47 @@ __global__ __launch_bounds__(256) void pw1_dgrad_kernel(const float *__restrict_
   }
 }
 
+// dx[n][c][pix] = w[c] * dy[n][pix] * (y[n][c][pix] > 0 ? 1 : slope): the 1x1 head's input gradient with the LeakyReLU backward of
+// the layer in front of it (saved output y, dx's shape) fused, and that layer's bias gradient as partial sums part[block][C]
+// (C <= 64; grid = 2 blocks per image: 512 pixel quads each for a 128x128 map ... the quads of a block are strided by 256).
+__global__ __launch_bounds__(256) void pw1_dgrad_act_kernel(const float *__restrict__ dy, const float *__restrict__ w,
+                                                            const float *__restrict__ y, float *__restrict__ dx, float *__restrict__ part,
+                                                            int C, int HW4, float slope) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x >> 1, hb = blockIdx.x & 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q0 = hb * ((HW4 + 1) / 2), q1 = hb ? HW4 : (HW4 + 1) / 2;
+  const f32x4 *yp = reinterpret_cast<const f32x4 *>(y) + (long)n * C * HW4;
+  f32x4 *xp = reinterpret_cast<f32x4 *>(dx) + (long)n * C * HW4;
+  const f32x4 *gp = reinterpret_cast<const f32x4 *>(dy) + (long)n * HW4;
+  float s[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) s[c] = 0.f;
+  for (int q = q0 + tid; q < q1; q += 256) {
+    const f32x4 g = gp[q];
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) {
+      if (c >= C) break;
+      const f32x4 yv = yp[(long)c * HW4 + q];
+      const float wc = w[c];
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = wc * g[e];
+        o[e] = yv[e] > 0.f ? v : v * slope;
+      }
+      xp[(long)c * HW4 + q] = o;
+      s[c] += (o[0] + o[1]) + (o[2] + o[3]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    const float t = wave_sum(s[c]);
+    if (lane == 0) red[wave][c] = t;
+  }
+  __syncthreads();
+  if (tid < C) part[(long)blockIdx.x * C + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
 // part[s][c] = sum over slice s of (n,pix) of x[n][c][pix] * dy[n][pix]   (grid: C x S).  (image, quad) of a thread's
 // element advance incrementally (one division at the start instead of one per element), four independent load pairs in flight.
 __global__ __launch_bounds__(256) void pw1_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,

@@ -1275,13 +1275,14 @@ static size_t c1_wgrad_ws_bytes(int Cs, int R, int S) { return (size_t)C1W_BLOCK
 
 static int run_c1_wgrad(const float *small, const float *big, float *dW, int N, int Hb, int Wb, int Cs, int Hs, int Ws,
                         int R, int S, int st_, int pad, void *ws, size_t ws_bytes, hipStream_t st, const void *dy_c8 = nullptr,
-                        const void *y_c8 = nullptr, float slope = 0.f, float *db = nullptr) {
+                        const void *y_c8 = nullptr, float slope = 0.f, float *db = nullptr, const float *y_f32 = nullptr) {
   C1WParams p;
   memset(&p, 0, sizeof(p));
   p.X = big;
   p.DY = small;
   p.DYc = (const unsigned short *)dy_c8;
   p.Yc = (const unsigned short *)y_c8;
+  p.Yf = y_f32;
   p.slope = slope;
   p.N = N;
   p.H = Hb;
@@ -1300,7 +1301,8 @@ static int run_c1_wgrad(const float *small, const float *big, float *dW, int N, 
   int blocks = p.iters_total < C1W_BLOCKS ? p.iters_total : C1W_BLOCKS;
   p.iters_per_block = ceil_div(p.iters_total, blocks);
   blocks = ceil_div(p.iters_total, p.iters_per_block);
-  const size_t need = dy_c8 ? (size_t)C1W_BLOCKS * Cs * (R * S + 1) * sizeof(float) : c1_wgrad_ws_bytes(Cs, R, S);
+  const bool fused = dy_c8 || y_f32;
+  const size_t need = fused ? (size_t)C1W_BLOCKS * Cs * (R * S + 1) * sizeof(float) : c1_wgrad_ws_bytes(Cs, R, S);
   if (need > ws_bytes) {
     set_error("wgrad workspace too small: need %zu, have %zu", need, ws_bytes);
     return LSPS_E_WS;
@@ -1309,7 +1311,7 @@ static int run_c1_wgrad(const float *small, const float *big, float *dW, int N, 
   hipLaunchKernelGGL(c1_wgrad_kernel, dim3(blocks), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("c1_wgrad");
   note_kernel("c1_wgrad_kernel");
-  if (dy_c8) {
+  if (fused) {
     hipLaunchKernelGGL(c1_wgrad_c8_reduce_kernel, dim3(ceil_div((long)Cs * (R * S + 1), 256)), dim3(256), 0, st, (const float *)p.part, dW,
                        db, Cs, R * S, blocks);
     LSPS_CHECK_LAUNCH("c1_wgrad_c8_reduce");
@@ -1851,6 +1853,42 @@ int lsps_c8_stem_wgrad(const float *x, const void *dy, const void *y, float *dw,
   LSPS_CHECK_ARG(c8_stem_geom(N, H, W, K, R, S, stride, pad, &P, &Q), "c8_stem_wgrad: unsupported geometry (one input channel, K == 64)");
   LSPS_CHECK_ARG(slope >= 0.f, "c8_stem_wgrad: LeakyReLU slope >= 0 (1: no activation)");
   return run_c1_wgrad(nullptr, x, dw, N, H, W, K, P, Q, R, S, stride, pad, ws, ws_bytes, (hipStream_t)stream, dy, y, slope, db);
+}
+
+// ---- f32 mode: activation backward of two layers folded into kernels that stream their tensors anyway ----
+int lsps_conv2d_stem_wgrad_act_ok(int N, int H, int W, int K, int R, int S, int stride, int pad) {
+  if (N <= 0 || K <= 0 || K > 64 || R * S >= 64 || stride <= 0) return 0;
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  return P > 0 && Q > 0 && (Q & 3) == 0 && c1_wgrad_ok(1, H, W, K, P, Q, R, S, stride, pad) ? 1 : 0;
+}
+
+int lsps_conv2d_stem_wgrad_act(const float *x, const float *dy, const float *y, float *dw, float *db, int N, int H, int W, int K, int R,
+                               int S, int stride, int pad, float slope, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(x && dy && y && dw && ws, "conv2d_stem_wgrad_act: null pointer");
+  LSPS_CHECK_ARG(lsps_conv2d_stem_wgrad_act_ok(N, H, W, K, R, S, stride, pad) && slope >= 0.f,
+                 "conv2d_stem_wgrad_act: unsupported geometry (one input channel, K <= 64, R*S < 64)");
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  return run_c1_wgrad(dy, x, dw, N, H, W, K, P, Q, R, S, stride, pad, ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr, slope, db, y);
+}
+
+size_t lsps_pw1_dgrad_act_workspace_bytes(int N, int C) { return (size_t)2 * N * C * sizeof(float) + 256; }
+
+int lsps_pw1_dgrad_act(const float *dpre, const float *w, const float *act_y, float act_slope, float *dx, float *db_prev, int N, int C,
+                       int HW, void *ws, size_t ws_bytes, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(dpre && w && act_y && dx && N > 0 && C > 0 && C <= 64 && HW > 0 && (HW & 3) == 0 && act_slope >= 0.f,
+                 "pw1_dgrad_act: bad arguments (C <= 64, HW %% 4 == 0)");
+  LSPS_CHECK_ARG(ws && ws_bytes >= (size_t)2 * N * C * sizeof(float), "pw1_dgrad_act: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(pw1_dgrad_act_kernel, dim3(2 * N), dim3(256), 0, st, dpre, w, act_y, dx, (float *)ws, C, HW / 4, act_slope);
+  LSPS_CHECK_LAUNCH("pw1_dgrad_act");
+  note_kernel("pw1_dgrad_kernel");
+  if (db_prev) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)ws, db_prev, (long)C, 2 * N);
+    LSPS_CHECK_LAUNCH("reduce_partials");
+  }
+  return 0;
 }
 
 }  // extern "C"

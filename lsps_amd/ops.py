@@ -188,6 +188,27 @@ def _empty(x, out_shape, *params):
     return _EmptyBatchFn.apply(x, tuple(out_shape), *params)
 
 
+class ActHolder(object):
+    """Shared by a C8 layer with a fused LeakyReLU epilogue (the producer) and the ONE layer that consumes its output
+    (common_net.run_layers pairs consecutive layers): the consumer's dgrad kernel multiplies the gradient it hands back by
+    LeakyReLU'(producer output) in its epilogue and leaves the producer's bias gradient here, so the producer's own
+    activation-backward pass (lsps_c8_act_bwd_bias / lsps_act_bwd_bias: three passes over the layer's output) is skipped."""
+    __slots__ = ('slope', 'fused', 'db')
+
+    def __init__(self, slope):
+        self.slope, self.fused, self.db = float(slope), False, None
+
+
+def _fuse_enabled():
+    import os
+    return os.environ.get('LSPS_FUSE_ACT', '1') != '0'
+
+
+def _fusable(prev):
+    import os
+    return prev is not None and prev.slope >= 0 and os.environ.get('LSPS_C8_FUSE_ACT', '1') != '0' and os.environ.get('LSPS_FUSE_ACT', '1') != '0'
+
+
 def _act_backward(L, dy, y, act, slope, want_db, channels, ws, wsb, st):
     """Gradient through the fused output activation of a conv / transposed conv.  When the layer's bias gradient is
     wanted too it comes out of the same pass (db = sum over n, h, w of the pre-activation gradient)."""
@@ -234,7 +255,18 @@ class _Conv2dFn(torch.autograd.Function):
         flops = 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S
         ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, H, W, K, R, S, stride, pad), x.device)
         dx = dw = db = None
-        dy, db = _act_backward(L, dy, y, act, slope, ctx.has_bias and ctx.needs_input_grad[2], K, ws, wsb, st)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if C == 1 and act == ACT_LRELU and slope >= 0 and not ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or want_db) and \
+                _fuse_enabled() and L.lsps_conv2d_stem_wgrad_act_ok(N, H, W, K, R, S, stride, pad) == 1:
+            # one-input-channel stem: the LeakyReLU backward is applied while dy is staged and the bias gradient is one more
+            # column of the same product — no pass over the net's largest activation (csrc/conv_c1.h)
+            dw = torch.empty_like(w)
+            db = torch.empty(K, dtype=torch.float32, device=x.device) if want_db else None
+            with profiler.span(flops):
+                _lib.check(L.lsps_conv2d_stem_wgrad_act(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(dw), _lib.ptr(db), N, H, W, K, R,
+                                                        S, stride, pad, slope, ws, wsb, st), 'conv2d_stem_wgrad_act')
+            return None, dw, db, None, None, None, None
+        dy, db = _act_backward(L, dy, y, act, slope, want_db, K, ws, wsb, st)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             with profiler.span(flops):
@@ -321,11 +353,12 @@ class _ConvT2dFn(torch.autograd.Function):
     """nn.ConvTranspose2d [+ LeakyReLU / Tanh] — common_net.py:262-264; lsps_nets.py:17-23, 226-229."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, outpad, act, slope):
+    def forward(ctx, x, w, b, stride, pad, outpad, act, slope, prev=None, own=None):
         L = _lib.lib()
         x, w = _c(x), _c(w)
         N, Ci, H, W = x.shape
         Ci2, Co, R, S = w.shape
+        ctx.prev, ctx.own = prev, own
         assert Ci == Ci2, "channel mismatch"
         Ho, Wo = convT_out_size(H, R, stride, pad, outpad), convT_out_size(W, S, stride, pad, outpad)
         y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
@@ -348,12 +381,25 @@ class _ConvT2dFn(torch.autograd.Function):
         flops = 2.0 * N * Ci * H * W * Co * R * S
         ws, wsb = _lib.workspace(L.lsps_convT2d_workspace_bytes(N, Ci, H, W, Co, R, S, stride, pad, outpad), x.device)
         dx = dw = db = None
-        dy, db = _act_backward(L, dy, y, act, slope, ctx.has_bias and ctx.needs_input_grad[2], Co, ws, wsb, st)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.own is not None and ctx.own.fused:        # the consumer's dgrad already applied this layer's LeakyReLU'
+            db = ctx.own.db if want_db else None
+            ctx.own.fused, ctx.own.db = False, None
+        else:
+            dy, db = _act_backward(L, dy, y, act, slope, want_db, Co, ws, wsb, st)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             with profiler.span(flops):
-                _lib.check(L.lsps_convT2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, Ci, H, W, Co, R, S, stride,
-                                                pad, outpad, ws, wsb, st), 'convT2d_dgrad')
+                if _fusable(ctx.prev) and (R, S, Co, stride, pad, outpad) == (1, 1, 1, 1, 0, 0) and Ci <= 64 and (H * W) % 4 == 0:
+                    # 1x1 output head: its input is the previous layer's output; that layer's LeakyReLU backward rides along
+                    dbp = torch.empty(Ci, dtype=torch.float32, device=x.device)
+                    wsd, wsdb = _lib.workspace(L.lsps_pw1_dgrad_act_workspace_bytes(N, Ci), x.device)
+                    _lib.check(L.lsps_pw1_dgrad_act(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(x), ctx.prev.slope, _lib.ptr(dx), _lib.ptr(dbp),
+                                                    N, Ci, H * W, wsd, wsdb, st), 'pw1_dgrad_act')
+                    ctx.prev.fused, ctx.prev.db = True, dbp
+                else:
+                    _lib.check(L.lsps_convT2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, Ci, H, W, Co, R, S, stride,
+                                                    pad, outpad, ws, wsb, st), 'convT2d_dgrad')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
             db_here = None
@@ -362,14 +408,15 @@ class _ConvT2dFn(torch.autograd.Function):
             with profiler.span(flops):
                 _lib.check(L.lsps_convT2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db_here), N, Ci, H, W, Co,
                                                 R, S, stride, pad, outpad, ws, wsb, st), 'convT2d_wgrad')
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
-def conv_transpose2d(x, w, b=None, stride=1, pad=0, outpad=0, act=ACT_NONE, slope=LRELU_SLOPE):
+def conv_transpose2d(x, w, b=None, stride=1, pad=0, outpad=0, act=ACT_NONE, slope=LRELU_SLOPE, prev=None, own=None):
+    """`own` / `prev`: ActHolder of this layer / of the layer whose output `x` is (see ActHolder)."""
     if x.shape[0] == 0:
         return _empty(x, (0, w.shape[1], convT_out_size(x.shape[2], w.shape[2], stride, pad, outpad),
                           convT_out_size(x.shape[3], w.shape[3], stride, pad, outpad)), w, b)
-    return _ConvT2dFn.apply(x, w, b, int(stride), int(pad), int(outpad), int(act), float(slope))
+    return _ConvT2dFn.apply(x, w, b, int(stride), int(pad), int(outpad), int(act), float(slope), prev, own)
 
 
 # ------------------------------------------------------------------------------------------
@@ -701,22 +748,6 @@ def c8_convT_s2_ok(x, w, stride, pad, outpad):
     else:
         return False
     return N > 0 and C == w.shape[0] and _lib.lib().lsps_c8_convT3x3s2_ok(N, C, H, W, w.shape[1]) == 1
-
-
-class ActHolder(object):
-    """Shared by a C8 layer with a fused LeakyReLU epilogue (the producer) and the ONE layer that consumes its output
-    (common_net.run_layers pairs consecutive layers): the consumer's dgrad kernel multiplies the gradient it hands back by
-    LeakyReLU'(producer output) in its epilogue and leaves the producer's bias gradient here, so the producer's own
-    activation-backward pass (lsps_c8_act_bwd_bias: 6 bytes per element over the layer's output) is skipped."""
-    __slots__ = ('slope', 'fused', 'db')
-
-    def __init__(self, slope):
-        self.slope, self.fused, self.db = float(slope), False, None
-
-
-def _fusable(prev):
-    import os
-    return prev is not None and prev.slope >= 0 and os.environ.get('LSPS_C8_FUSE_ACT', '1') != '0'
 
 
 def _c8_act_backward(L, dy, y, slope, want_db, channels, st):

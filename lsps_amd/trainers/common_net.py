@@ -141,12 +141,20 @@ def run_layers(layers, x, noise=None):
                 own = ops.ActHolder(LRELU_SLOPE)
                 x = ops.convT3x3s2_c8(xin, c.weight, c.bias, LRELU_SLOPE, prev if xin is x else None, own)
                 prev = own
-            else:
-                x, prev = l(ops.from_c8(x)), None
+            else:                                                       # f32 (or a shape without a C8 kernel)
+                own = ops.ActHolder(LRELU_SLOPE)
+                x = ops.conv_transpose2d(ops.from_c8(x), c.weight, c.bias, c.stride, c.padding, c.output_padding, c.act, LRELU_SLOPE,
+                                         None, own if c.act == ACT_LRELU else None)
+                prev = own if c.act == ACT_LRELU else None
         elif isinstance(l, GaussianNoiseLayer):
             x, prev = l(x, noise), None
         elif isinstance(l, ConvTranspose2d) and ops.c8_pw1_ok(x, l.weight, l.stride, l.padding, l.output_padding):
             x, prev = ops.pw1_c8(x, l.weight, l.bias, l.act, LRELU_SLOPE, prev), None      # 1x1 output head (+ Tanh) straight from C8
+        elif isinstance(l, ConvTranspose2d):                         # f32 output head: the fused form needs the 1x1 / one-channel geometry
+            xin = ops.from_c8(x)
+            x = ops.conv_transpose2d(xin, l.weight, l.bias, l.stride, l.padding, l.output_padding, l.act, LRELU_SLOPE,
+                                     prev if xin is x else None, None)
+            prev = None
         elif isinstance(l, _Fused):
             pass
         else:

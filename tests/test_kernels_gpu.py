@@ -953,3 +953,54 @@ def test_env_selected_kernel_variants(env):
                          timeout=600)
     assert out.returncode == 0 and 'variants ok' in out.stdout, (out.stdout[-400:], out.stderr[-1200:])
 
+
+
+@pytest.mark.parametrize("case", [(2, 1, 128, 128, 64, 7, 1, 3), (3, 1, 128, 128, 64, 7, 2, 3), (3, 1, 32, 64, 40, 5, 1, 2)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_stem_weight_gradient_with_fused_activation_backward(case):
+    """One-input-channel stems whose image needs no gradient: dw and db from ONE kernel (LeakyReLU backward applied while dy is
+    staged, bias gradient as an extra tap column; csrc/conv_c1.h) against torch on the SAME activation mask (taken from the
+    kernel's own forward output, so that no pre-activation that is zero to round-off decides the comparison)."""
+    _need_gpu()
+    from lsps_amd import ops
+    N, C, H, W, K, R, st, pad = case
+    x = _rand(N, C, H, W, seed=1)
+    w = _rand(K, C, R, R, seed=2, scale=0.1)
+    b = _rand(K, seed=3, scale=0.1)
+    xd = x.cuda()
+    wd, bd = (t.cuda().requires_grad_(True) for t in (w, b))
+    ops.kernel_log_begin()
+    y = ops.conv2d(xd, wd, bd, st, pad, ops.ACT_LRELU, 0.01)
+    gy = _rand(*y.shape, seed=4)
+    y.backward(gy.cuda())
+    names = ops.kernel_log_end()
+    assert names.count('c1_wgrad_kernel') == 1 and 'igemm_w_kernel' not in names, names
+    g = torch.where(y.detach().cpu() > 0, gy, gy * 0.01).double()
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), (K, C, R, R), g, stride=st, padding=pad)
+    assert _rel(wd.grad, dw_ref) < 2e-4 and _rel(bd.grad, g.sum((0, 2, 3))) < 2e-4
+
+
+def test_output_head_dgrad_with_fused_activation_backward(monkeypatch):
+    """Decoder tail in f32 (LeakyReLUConvTranspose2d -> ConvTranspose2d(64, 1, 1) + Tanh through run_layers): the head's input
+    gradient carries the previous layer's LeakyReLU backward and bias gradient; against the separate-pass path."""
+    _need_gpu()
+    from lsps_amd import ops
+    from lsps_amd.trainers import common_net as cn
+    torch.manual_seed(5)
+    dev = torch.device('cuda')
+    layers = [cn.LeakyReLUConvTranspose2d(128, 64, 3, 2, 1, 1), cn.ConvTranspose2d(64, 1, 1, 1, 0, act=cn.ACT_TANH)]
+    for m in layers:
+        m.to(dev)
+    z = torch.randn(3, 128, 64, 64, device=dev)
+    res = []
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('LSPS_FUSE_ACT', fuse)
+        for m in layers:
+            for p in m.parameters():
+                p.grad = None
+        zz = z.clone().requires_grad_(True)
+        out = cn.run_layers(layers, zz)
+        (out.square().mean() + out.abs().mean()).backward()
+        res.append([zz.grad.clone()] + [p.grad.clone() for m in layers for p in m.parameters()])
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, (a.shape, float((a - b).abs().max()), float(b.abs().max()))
