@@ -389,7 +389,8 @@ def main():
         roofline = None
         traffic = None
         traffic_file = None
-        for tf in ('r2t_traffic.json', 'r2_traffic.json', 'r1_traffic.json'):   # PMC traffic is collected offline (rocprofv3 --pmc cannot run inside the timed bench)
+        tfiles = ('r2t_traffic.json', 'r2_traffic.json', 'r1_traffic.json') if args.dtype == 'f32' else ('r3l_traffic_bf16.json',)
+        for tf in tfiles:               # PMC traffic is collected offline (rocprofv3 --pmc cannot run inside the timed bench)
             try:
                 with open(os.path.join(REPO, 'profiles', tf)) as f:
                     tj = json.load(f).get(dom_name)
@@ -401,8 +402,6 @@ def main():
                 traffic = None
         if dom:
             mfma = 'v_mfma_f32_32x32x2_f32' if args.dtype == 'f32' else 'v_mfma_f32_32x32x16_bf16'
-            if args.dtype != 'f32':
-                traffic = None          # the PMC passes in profiles/ were taken in the f32 mode
             wino = dom_name in ('wino_f3x3_kernel', 'wino4_f3x3_kernel', 'wino4_w3x3_kernel')
             wino_x = 2.25 if dom_name == 'wino_f3x3_kernel' else 4.0      # algorithmic multiplies per issued MFMA multiply
             roofline = {'bound': 'mfma', 'kernel': dom_name + ((' (fused Winograd F(2x2,3x3) conv on %s)' if wino_x == 2.25 else
@@ -414,7 +413,7 @@ def main():
                         'frac': dom['tflops'] / (wino_x if wino else 1.0) / peak,
                         'algorithmic_frac': dom['tflops'] / peak, 'traffic': traffic,
                         'traffic_note': 'HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE KB, calibrated), '
-                                        'profiles/%s; scaled to this run\'s mean launch size' % (traffic_file or 'r2_traffic.json'),
+                                        'profiles/%s; scaled to this run\'s mean launch size' % (traffic_file or tfiles[0]),
                         'launches': dom['launches'], 'avg_launch_ms': dom['avg_ms'],
                         'algorithmic_gflop_per_launch': dom['gflop_per_launch'],
                         'share_of_step_time': dom['total_ms'] / (1e3 * elapsed),
