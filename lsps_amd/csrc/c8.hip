@@ -6,6 +6,7 @@
 #include "c8wgrad.h"
 #include "c8s2.h"
 #include "c8ends.h"
+#include "c8stem.h"
 
 namespace lsps {
 
@@ -313,6 +314,70 @@ static int c8s2_run_wgrad(const void *small, const void *big, float *dw, int N, 
   LSPS_CHECK_LAUNCH("c8s2_wgrad");
   hipLaunchKernelGGL(c8_wgrad_reduce_kernel, dim3(ceil_div((long)K * C, 256)), dim3(256), 0, st, (const float *)p.part, dw, K * C, p.splits);
   LSPS_CHECK_LAUNCH("c8s2_wgrad_reduce");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// one-input-channel stems on the bf16 matrix pipe (c8stem.h)
+// ------------------------------------------------------------------------------------------------------------------
+#define C8SW_BLOCKS 512
+
+bool c8_stem_bf16_ok(int N, int H, int W, int K, int R, int S, int stride, int pad) {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("LSPS_C8_STEM_BF16");
+    on = !(e && e[0] == '0');
+  }
+  if (!on || N <= 0 || K != 64 || R > 7 || S > 7 || R < 1 || S < 1 || (stride != 1 && stride != 2) || pad < 0) return false;
+  const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  if (P <= 0 || (Q != 32 && Q != 64 && Q != 128) || (P % (128 / Q)) != 0) return false;
+  const int LW = W + 2 * pad + 2, RB = 128 / Q;
+  return ((RB - 1) * stride + 8) * LW <= C8SW_XMAX && (long)K * P * Q * 2 < (1L << 31);
+}
+
+int c8_stem_fwd_bf16(const float *x, const float *w, const float *bias, void *y, int N, int H, int W, int K, int R, int S, int stride,
+                     int pad, float slope, hipStream_t st) {
+  C8StemParams p;
+  p.X = x; p.W = w; p.bias = bias; p.Y = (unsigned short *)y;
+  p.N = N; p.H = H; p.Wd = W; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  p.P = (H + 2 * pad - R) / stride + 1;
+  p.Q = (W + 2 * pad - S) / stride + 1;
+  p.LW = W + 2 * pad + 2;
+  int tp = 8;                                         // output rows per workgroup: >= ~1024 workgroups, <= 64 KB of staged rows
+  while (tp > 1 && ((p.P % tp) != 0 || (long)N * (p.P / tp) < 1024 || (long)((tp - 1) * stride + 8) * p.LW * 4 > 60000)) tp >>= 1;
+  p.TP = tp;
+  p.rows = (tp - 1) * stride + 8;
+  p.lrelu = slope >= 0.f ? slope : 1.f;
+  hipLaunchKernelGGL(c8_stem_fwd_kernel, dim3(p.P / tp, N), dim3(256), (size_t)p.rows * p.LW * sizeof(float), st, p);
+  LSPS_CHECK_LAUNCH("c8_stem_fwd");
+  return 0;
+}
+
+size_t c8_stem_wgrad_bf16_ws_bytes() { return (size_t)C8SW_BLOCKS * 4096 * sizeof(float) + 256; }
+
+int c8_stem_wgrad_bf16(const float *x, const void *dy, const void *y, float *dw, float *db, int N, int H, int W, int K, int R, int S,
+                       int stride, int pad, float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+  if (!ws || ws_bytes < c8_stem_wgrad_bf16_ws_bytes()) {
+    set_error("c8 stem weight gradient: workspace too small (%zu < %zu)", ws_bytes, c8_stem_wgrad_bf16_ws_bytes());
+    return LSPS_E_WS;
+  }
+  C8StemWParams p;
+  p.X = x; p.DY = (const unsigned short *)dy; p.Yc = (const unsigned short *)y; p.part = (float *)ws;
+  p.N = N; p.H = H; p.Wd = W; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  p.P = (H + 2 * pad - R) / stride + 1;
+  p.Q = (W + 2 * pad - S) / stride + 1;
+  p.LW = W + 2 * pad + 2;
+  p.RB = 128 / p.Q;
+  p.xrows = (p.RB - 1) * stride + 8;
+  p.iters_total = N * (p.P / p.RB);
+  int blocks = std::min(p.iters_total, C8SW_BLOCKS);
+  p.iters_per_block = ceil_div(p.iters_total, blocks);
+  blocks = ceil_div(p.iters_total, p.iters_per_block);
+  p.slope = slope;
+  hipLaunchKernelGGL(c8_stem_wgrad_kernel, dim3(blocks), dim3(256), 0, st, p);
+  LSPS_CHECK_LAUNCH("c8_stem_wgrad");
+  hipLaunchKernelGGL(c8_stem_wgrad_reduce_kernel, dim3(16), dim3(256), 0, st, (const float *)p.part, dw, db, R, S, blocks);
+  LSPS_CHECK_LAUNCH("c8_stem_wgrad_reduce");
   return 0;
 }
 

@@ -36,6 +36,14 @@ int lds_optin(const void *kernel, int bytes, const char *name);
 // bytes the caller must fill (*hit = false), or nullptr (no scope open / arena full: pack into the call's workspace).
 void *pack_cache_slot(const float *W, int tag, int M, int C, long sm, long sc, size_t need, bool *hit, hipStream_t st);
 
+// bf16-MFMA forms of the one-input-channel stems (c8stem.h, compiled in c8.hip; called by the lsps_c8_stem_* entries of igemm.hip)
+bool c8_stem_bf16_ok(int N, int H, int W, int K, int R, int S, int stride, int pad);
+int c8_stem_fwd_bf16(const float *x, const float *w, const float *bias, void *y, int N, int H, int W, int K, int R, int S, int stride,
+                     int pad, float slope, hipStream_t st);
+size_t c8_stem_wgrad_bf16_ws_bytes();
+int c8_stem_wgrad_bf16(const float *x, const void *dy, const void *y, float *dw, float *db, int N, int H, int W, int K, int R, int S,
+                       int stride, int pad, float slope, void *ws, size_t ws_bytes, hipStream_t st);
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -29,6 +29,7 @@
 // Reference call sites replaced: every nn.Conv2d / nn.ConvTranspose2d on the path
 // (src/trainers/common_net.py:162-163,250,262; src/trainers/lsps_nets.py:17-23,123-124,226-227)
 // and their autograd backward (total_loss.backward(), src/trainers/lsps_trainer.py:71,130,212,257).
+#include <algorithm>
 #include "common.h"
 #include <stdarg.h>
 #include <string.h>
@@ -1832,7 +1833,9 @@ int lsps_c8_stem_ok(int N, int H, int W, int K, int R, int S, int stride, int pa
   return c8_stem_geom(N, H, W, K, R, S, stride, pad, &P, &Q) ? 1 : 0;
 }
 
-size_t lsps_c8_stem_workspace_bytes(int K, int R, int S) { return (size_t)C1W_BLOCKS * K * (R * S + 1) * sizeof(float) + 256; }
+size_t lsps_c8_stem_workspace_bytes(int K, int R, int S) {
+  return std::max((size_t)C1W_BLOCKS * K * (R * S + 1) * sizeof(float) + 256, c8_stem_wgrad_bf16_ws_bytes());
+}
 
 int lsps_c8_stem_fwd(const float *x, const float *w, const float *bias, void *y, int N, int H, int W, int K, int R, int S, int stride,
                      int pad, float slope, void *stream) {
@@ -1841,6 +1844,10 @@ int lsps_c8_stem_fwd(const float *x, const float *w, const float *bias, void *y,
   LSPS_CHECK_ARG(x && w && y, "c8_stem_fwd: null pointer");
   LSPS_CHECK_ARG(c8_stem_geom(N, H, W, K, R, S, stride, pad, &P, &Q), "c8_stem_fwd: unsupported geometry (one input channel, K == 64)");
   LSPS_CHECK_ARG(slope <= 1.f, "c8_stem_fwd: LeakyReLU slope in [0, 1] (or < 0: no activation)");
+  if (c8_stem_bf16_ok(N, H, W, K, R, S, stride, pad)) {      // K = 8 x 8 tap grid on the bf16 matrix pipe (c8stem.h)
+    note_kernel("c8_stem_fwd_kernel");
+    return c8_stem_fwd_bf16(x, w, bias, y, N, H, W, K, R, S, stride, pad, slope, (hipStream_t)stream);
+  }
   return run_c1_fwd(x, w, bias, (float *)y, N, H, W, K, P, Q, R, S, stride, pad, slope >= 0.f ? LSPS_ACT_LRELU : LSPS_ACT_NONE, slope,
                     (hipStream_t)stream, 1);
 }
@@ -1852,6 +1859,10 @@ int lsps_c8_stem_wgrad(const float *x, const void *dy, const void *y, float *dw,
   LSPS_CHECK_ARG(x && dy && y && dw && ws, "c8_stem_wgrad: null pointer");
   LSPS_CHECK_ARG(c8_stem_geom(N, H, W, K, R, S, stride, pad, &P, &Q), "c8_stem_wgrad: unsupported geometry (one input channel, K == 64)");
   LSPS_CHECK_ARG(slope >= 0.f, "c8_stem_wgrad: LeakyReLU slope >= 0 (1: no activation)");
+  if (c8_stem_bf16_ok(N, H, W, K, R, S, stride, pad)) {
+    note_kernel("c8_stem_wgrad_kernel");
+    return c8_stem_wgrad_bf16(x, dy, y, dw, db, N, H, W, K, R, S, stride, pad, slope, ws, ws_bytes, (hipStream_t)stream);
+  }
   return run_c1_wgrad(nullptr, x, dw, N, H, W, K, P, Q, R, S, stride, pad, ws, ws_bytes, (hipStream_t)stream, dy, y, slope, db);
 }
 

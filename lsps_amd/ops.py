@@ -905,7 +905,7 @@ class _StemC8Fn(torch.autograd.Function):
         K, _, R, S = w.shape
         P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
         y = torch.empty((N, K // 8, P, Q, 8), dtype=BF16, device=x.device)
-        with profiler.span(2.0 * N * K * P * Q * R * S, 'c1_fwd_kernel'):
+        with profiler.span(2.0 * N * K * P * Q * R * S):
             _lib.check(L.lsps_c8_stem_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y, BF16), N, H, W, K, R, S, stride, pad, slope,
                                           _lib.stream()), 'c8_stem_fwd')
         ctx.geom = (N, H, W, K, R, S, stride, pad, slope, P, Q)
@@ -927,7 +927,7 @@ class _StemC8Fn(torch.autograd.Function):
             dw = torch.empty_like(w)
             db = torch.empty(K, dtype=torch.float32, device=x.device) if want_db else None
             ws, wsb = _lib.workspace(L.lsps_c8_stem_workspace_bytes(K, R, S), x.device)
-            with profiler.span(flops, 'c1_wgrad_kernel'):
+            with profiler.span(flops):
                 _lib.check(L.lsps_c8_stem_wgrad(_lib.ptr(x), _lib.ptr(dy, BF16), _lib.ptr(y, BF16), _lib.ptr(dw), _lib.ptr(db), N, H, W, K,
                                                 R, S, stride, pad, slope if slope >= 0 else 1.0, ws, wsb, st), 'c8_stem_wgrad')
         if ctx.needs_input_grad[0]:
