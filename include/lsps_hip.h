@@ -143,7 +143,8 @@ int lsps_conv3x3s2_chwn_wgrad(const float *x, const float *dy, float *dw, int N,
  * statistics and accumulation are f32.  Geometry: H = W = 32; conv entries C % 16 == 0 and K % 64 == 0 (outputs), the
  * weight gradient C % 64 == 0 and K % 128 == 0.
  *   lsps_c8_from_nchw / _to_nchw   layout + precision conversion at the ends of the chain (x [N,C,HW] f32)
- *   lsps_c8_add                    GaussianNoiseLayer on a C8 tensor (common_net.py:39-40), n = element count
+ *   lsps_c8_add / lsps_c8_add_nchw GaussianNoiseLayer on a C8 tensor (common_net.py:39-40), n = element count; _nchw: the noise
+ *                                  as the f32 [N,C,HW] tensor it was drawn into (no conversion pass)
  *   lsps_c8_conv3x3_fwd            y = conv3x3(x, w) (+ addend)                                   (common_net.py:162)
  *   lsps_c8_conv3x3_in_fwd         residual == NULL: y = LeakyReLU_slope(InstanceNorm(conv(x, w))) (:162-169, slope < 0: none)
  *                                  residual != NULL: y = InstanceNorm(conv(x, w)) + residual       (:163-181); rstd [N*K] out
@@ -159,6 +160,7 @@ size_t lsps_c8_conv3x3_wgrad_workspace_bytes(int N, int C, int K);
 int lsps_c8_from_nchw(const float *x, void *y, int N, int C, int HW, void *stream);
 int lsps_c8_to_nchw(const void *x, float *y, int N, int C, int HW, void *stream);
 int lsps_c8_add(const void *a, const void *b, void *out, long n, void *stream);
+int lsps_c8_add_nchw(const void *a, const float *b /* f32 [N,C,HW] */, void *out, int N, int C, int HW, void *stream);
 int lsps_c8_conv3x3_fwd(const void *x, const float *w, const void *addend /*nullable*/, void *y, int N, int C, int H, int W, int K,
                         void *ws, size_t ws_bytes, void *stream);
 int lsps_c8_conv3x3_in_fwd(const void *x, const float *w, const void *residual /*nullable*/, void *y, float *rstd,

@@ -69,6 +69,7 @@ _SIGNATURES = {
     'lsps_c8_from_nchw': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'lsps_c8_to_nchw': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'lsps_c8_add': (c_int, [_P, _P, _P, c_long, _P]),
+    'lsps_c8_add_nchw': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     'lsps_c8_conv3x3_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
     'lsps_c8_conv3x3_in_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [c_float, c_float, _P, c_size_t, _P]),
     'lsps_c8_conv3x3_dgrad_acc': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),

@@ -418,6 +418,16 @@ int lsps_c8_add(const void *a, const void *b, void *out, long n, void *stream) {
   return 0;
 }
 
+int lsps_c8_add_nchw(const void *a, const float *b, void *out, int N, int C, int HW, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(a && b && out && N > 0 && C > 0 && (C & 7) == 0 && HW > 0, "c8_add_nchw: bad arguments (C %% 8 == 0)");
+  const long units = (long)N * (C >> 3) * HW;
+  hipLaunchKernelGGL(c8_add_nchw_kernel, dim3(ceil_div(units, 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)a, b,
+                     (unsigned short *)out, HW, units);
+  LSPS_CHECK_LAUNCH("c8_add_nchw");
+  return 0;
+}
+
 int lsps_c8_conv3x3_fwd(const void *x, const float *w, const void *addend, void *y, int N, int C, int H, int W, int K, void *ws,
                         size_t ws_bytes, void *stream) {
   (void)hipGetLastError();

@@ -110,6 +110,21 @@ __global__ __launch_bounds__(256) void c8_add_kernel(const unsigned short *__res
   *reinterpret_cast<bf16x8 *>(out + u * 8) = o;
 }
 
+// out = a + b with b an f32 [N][C][HW] tensor (GaussianNoiseLayer's fresh draw, common_net.py:39-40): no conversion pass for b
+__global__ __launch_bounds__(256) void c8_add_nchw_kernel(const unsigned short *__restrict__ a, const float *__restrict__ b,
+                                                          unsigned short *__restrict__ out, int HW, long units) {
+  const long u = (long)blockIdx.x * 256 + threadIdx.x;
+  if (u >= units) return;
+  const int px = (int)(u % HW);
+  const long ncg = u / HW;                                     // n * (C/8) + cg
+  const float *src = b + ncg * 8 * HW + px;
+  const bf16x8 x = *reinterpret_cast<const bf16x8 *>(a + u * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)x[e] + src[(long)e * HW]);
+  *reinterpret_cast<bf16x8 *>(out + u * 8) = o;
+}
+
 // Backward of InstanceNorm (+ residual | + LeakyReLU) from the OUTPUT on C8 tensors (norm_act.hip: inorm_bwd_kernel in this
 // layout).  residual variant (res != null): g = dout, xh = out - res;  activation variant (slope > 0): g = dout * lrelu'(out),
 // xh = out > 0 ? out : out / slope;  dy = rstd * (g - mean(g) - xh * mean(g * xh)).  One workgroup per (n, channel group).

@@ -700,8 +700,14 @@ class _AddC8Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         a, b = _c(a), _c(b)
-        assert a.shape == b.shape
         out = torch.empty_like(a)
+        if not is_c8(b):                                 # f32 [N, C, H, W]: the draw as it was made
+            N, G, H, W, _ = a.shape
+            assert tuple(b.shape) == (N, G * 8, H, W)
+            _lib.check(_lib.lib().lsps_c8_add_nchw(_lib.ptr(a, BF16), _lib.ptr(b), _lib.ptr(out, BF16), N, G * 8, H * W, _lib.stream()),
+                       'c8_add_nchw')
+            return out
+        assert a.shape == b.shape
         _lib.check(_lib.lib().lsps_c8_add(_lib.ptr(a, BF16), _lib.ptr(b, BF16), _lib.ptr(out, BF16), a.numel(), _lib.stream()), 'c8_add')
         return out
 

@@ -101,7 +101,7 @@ class GaussianNoiseLayer(nn.Module):
             N, G, H, W, _ = x.shape
             if noise is None:
                 noise = torch.randn((N, G * 8, H, W), device=x.device, dtype=torch.float32)
-            return ops.add_c8(x, ops.to_c8(noise.detach()))
+            return ops.add_c8(x, noise.detach())           # the f32 draw is added as it is (no conversion pass)
         if noise is None:
             noise = torch.randn(x.size(), device=x.device, dtype=x.dtype)
         return ops.axpy(x, noise, 1.0)

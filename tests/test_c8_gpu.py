@@ -162,6 +162,17 @@ def test_c8_inorm_bwd(N, C):
     assert _rel(_from_c8(out), ref) < C8_TOL
 
 
+def test_c8_add_nchw_noise():
+    _need_gpu()
+    _lib, L, dev, st = _env()
+    g = torch.Generator().manual_seed(4)
+    x, nz = _rand(g, 3, 24, 5, 7), _rand(g, 3, 24, 5, 7)
+    xc = _to_c8(x)
+    out = torch.empty_like(xc)
+    _lib.check(L.lsps_c8_add_nchw(xc.data_ptr(), nz.data_ptr(), out.data_ptr(), 3, 24, 35, st), 'add_nchw')
+    assert torch.equal(_from_c8(out), (_rb(x) + nz).to(BF).float())
+
+
 def test_c8_entries_reject_what_they_cannot_do():
     _need_gpu()
     _lib, L, dev, st = _env()
