@@ -182,6 +182,24 @@ def test_full_batch_properties():
 
 
 def test_full_size_step_gradients_equal_the_mean_of_chunk_gradients():
+    _chunk_mean_property(cases.hp_for('full'), 128, 8, 108, None, 5e-3, 5e-4)
+
+
+def test_config5_full_size_bf16_step_gradients_equal_the_mean_of_chunk_gradients():
+    """The same property at BASELINE config 5's size and mode: exps/nicvl.yaml, bf16 math mode, 256 samples per domain — the C8
+    kernels at their bench grids (tiles of whole images on the discriminator trunk's small maps with 1536 images, 512-image
+    residual convs, one round of weight-gradient workgroups) against thirty-two 8-sample chunks through the same kernels at
+    small grids.  Per sample the bf16 kernels do the same arithmetic at any batch size; what differs is tile mapping, ragged
+    last tiles and the f32 summation order of the weight gradients and bias-gradient partial sums."""
+    from lsps_amd import ops
+    ops.set_math_mode('bf16')
+    try:
+        _chunk_mean_property(cases.load_hp('nicvl'), 256, 8, 48, 'bf16', 1e-4, 2e-5)      # measured: worst 4.6e-6, 90 % below 9.3e-7
+    finally:
+        ops.set_math_mode('f32')
+
+
+def _chunk_mean_property(hp, n, ch, label_dim, mode, tol_worst, tol_90):
     """BASELINE's full size (bs=128 per domain, full width), backward included: every loss of dis_update / gen_update is a
     batch mean and InstanceNorm has no batch statistics, so the gradients of the 128-sample step are the MEAN of the gradients
     of its sixteen 8-sample chunks (same weights, the chunks' rows of the same noise), and so are the loss scalars.  The full
@@ -189,10 +207,8 @@ def test_full_size_step_gradients_equal_the_mean_of_chunk_gradients():
     kernels at full grids, the batch-innermost trunk); the chunks run the small-grid paths that the reference's golden
     vectors pin at N = 2 ... 8: a wrong dgrad / wgrad / norm-backward at full size shows as a broken mean."""
     A = _adapter()
-    hp = cases.hp_for('full')
     sds = cases.make_weights(hp, lsps_ref)
-    n, ch = 128, 8
-    b = cases.make_inputs(n)
+    b = cases.make_inputs(n, label_dim=label_dim)
     lat2, lat1 = cases.latent_shape(hp, 2 * n), cases.latent_shape(hp, n)
     nz_d = cases.noise(lat2, 11)
     nz_g = (cases.noise(lat2, 21), cases.noise(lat1, 31), cases.noise(lat1, 41))
@@ -247,8 +263,9 @@ def test_full_size_step_gradients_equal_the_mean_of_chunk_gradients():
     # into the last trunk layers: measured 1.5e-3 of the tensor's abs-max there, median over all tensors 1e-4).  A wrong
     # kernel is off by O(0.1 .. 1).  The golden step-gradient bound of tests/golden/cases.py is 2e-2.
     errs.sort(reverse=True)
-    assert errs[0][0] <= 5e-3, errs[:5]
-    assert errs[len(errs) // 10][0] <= 5e-4, errs[len(errs) // 10]          # 90 % of the tensors
+    print("chunk-mean property (%s): worst %s, 90th percentile %s" % (mode or 'f32', errs[0], errs[len(errs) // 10]))
+    assert errs[0][0] <= tol_worst, errs[:5]
+    assert errs[len(errs) // 10][0] <= tol_90, errs[len(errs) // 10]          # 90 % of the tensors
     for key, names in (('dis_s', ('dis_loss', 'dis_ad_loss', 'dis_feat_loss', 'dis_true_acc', 'dis_fake_acc')),
                        ('gen_s', ('gen_total_loss',))):
         for name in names:
