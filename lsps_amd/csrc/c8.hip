@@ -228,6 +228,10 @@ static int c8s2_run_fwd(const void *big, const float *w, long sm, long sc, const
     set_error("c8 stride-2 conv (forward direction): unsupported geometry N=%d C=%d %dx%d M=%d", N, Cx, H, W, M);
     return LSPS_E_ARG;
   }
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) {     // the epilogue reads it in 16-byte pieces
+    set_error("c8 stride-2 conv: the bias must be 16-byte aligned");
+    return LSPS_E_ARG;
+  }
   const unsigned short *wq = nullptr;
   if (int rc = c8s2_pack(w, M, Cx, sm, sc, 128, ws, ws_bytes, st, &wq)) return rc;
   p.X = (const unsigned short *)big;
@@ -266,6 +270,10 @@ static int c8s2_run_tr(const void *small, const float *w, long sm, long sc, cons
   C8S2Params p;
   if (!c8s2_tr_geom(N, Cx, H, W, M, &p)) {
     set_error("c8 stride-2 conv (transposed direction): unsupported geometry N=%d C=%d -> %dx%d M=%d", N, Cx, H, W, M);
+    return LSPS_E_ARG;
+  }
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) {
+    set_error("c8 stride-2 conv: the bias must be 16-byte aligned");
     return LSPS_E_ARG;
   }
   const unsigned short *wq = nullptr;
