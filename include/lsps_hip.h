@@ -224,6 +224,11 @@ int lsps_c8_stem_fwd(const float *x, const float *w, const float *bias /*nullabl
                      int stride, int pad, float slope, void *stream);
 int lsps_c8_stem_wgrad(const float *x, const void *dy, const void *y, float *dw, float *db /*nullable*/, int N, int H, int W, int K,
                        int R, int S, int stride, int pad, float slope, void *ws, size_t ws_bytes, void *stream);
+/* dx [N,1,H,W] f32 of a stem from the C8 gradient dy w.r.t. its OUTPUT and its saved C8 output y (LeakyReLU backward applied on
+ * the fly): the discriminator stems inside gen_update; bf16 tap GEMM + deterministic in-LDS col2im in one kernel */
+int lsps_c8_stem_dgrad_ok(int N, int H, int W, int K, int R, int S, int stride, int pad);
+int lsps_c8_stem_dgrad(const void *dy, const void *y, const float *w, float *dx, int N, int H, int W, int K, int R, int S,
+                       int stride, int pad, float slope, void *stream);
 size_t lsps_c8_pw1_workspace_bytes(int N, int C);
 int lsps_c8_pw1_fwd(const void *x, const float *w, const float *bias /*nullable*/, float *y, int N, int C, int HW, int act, float slope,
                     void *stream);

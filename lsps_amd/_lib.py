@@ -92,6 +92,8 @@ _SIGNATURES = {
     'lsps_c8_stem_workspace_bytes': (c_size_t, [c_int] * 3),
     'lsps_c8_stem_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [c_float, _P]),
     'lsps_c8_stem_wgrad': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 8 + [c_float, _P, c_size_t, _P]),
+    'lsps_c8_stem_dgrad_ok': (c_int, [c_int] * 8),
+    'lsps_c8_stem_dgrad': (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [c_float, _P]),
     'lsps_c8_pw1_workspace_bytes': (c_size_t, [c_int] * 2),
     'lsps_c8_pw1_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     'lsps_c8_pw1_dgrad': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

@@ -361,6 +361,23 @@ int c8_stem_fwd_bf16(const float *x, const float *w, const float *bias, void *y,
   return 0;
 }
 
+int c8_stem_dgrad_bf16(const void *dy, const void *y, const float *w, float *dx, int N, int H, int W, int K, int R, int S, int stride,
+                       int pad, float slope, hipStream_t st) {
+  C8StemDParams p;
+  p.DY = (const unsigned short *)dy; p.Yc = (const unsigned short *)y; p.W = w; p.dX = dx;
+  p.N = N; p.H = H; p.Wd = W; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  p.P = (H + 2 * pad - R) / stride + 1;
+  p.Q = (W + 2 * pad - S) / stride + 1;
+  p.LW = (p.Q - 1) * stride + 8 + 1;                   // widest LDS column touched: (Q - 1) stride + 7
+  if (p.LW < W + pad) p.LW = W + pad;
+  p.slope = slope;
+  const size_t lds = ((size_t)4 * C8SD_TY * p.LW + 256) * sizeof(float);
+  if (int rc = lds_optin(reinterpret_cast<const void *>(c8_stem_dgrad_kernel), (int)lds, "c8_stem_dgrad")) return rc;
+  hipLaunchKernelGGL(c8_stem_dgrad_kernel, dim3(ceil_div(H, C8SD_TY), N), dim3(256), lds, st, p);
+  LSPS_CHECK_LAUNCH("c8_stem_dgrad");
+  return 0;
+}
+
 size_t c8_stem_wgrad_bf16_ws_bytes() { return (size_t)C8SW_BLOCKS * 4096 * sizeof(float) + 256; }
 
 int c8_stem_wgrad_bf16(const float *x, const void *dy, const void *y, float *dw, float *db, int N, int H, int W, int K, int R, int S,

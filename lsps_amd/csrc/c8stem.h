@@ -278,5 +278,145 @@ __global__ __launch_bounds__(256) void c8_stem_wgrad_reduce_kernel(const float *
     db[k] = s;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Input gradient of a stem (the discriminator's, inside gen_update: the generated images need it):
+//   dx[n][y][x] = sum_{k,r,c : y = p s + r - pad, x = q s + c - pad} w[k][r][c] g[n][k][p][q],   g = dy * (y_saved > 0 ? 1 : slope)
+// as a tap GEMM on the bf16 pipe, Z[t = 8 r + c][pixel] = sum_k w[k][t] g[k][pixel] (64 taps x 64 channels: 8 MFMAs per 32 pixels,
+// the g fragments straight from the C8 tensors with the activation mask applied in registers), whose rows are then added into the
+// image at their tap's offset.  Workgroup = one image x a band of TY image rows; every wave owns a PRIVATE LDS copy of the band
+// (ds_add_f32 in program order: lanes of one instruction hit distinct columns, so the sum order is fixed = deterministic), the
+// four copies are summed in a fixed order when the band is written.  Replaces: activation pass + C8 -> NCHW conversion + f32
+// tap GEMM + col2im.
+// ------------------------------------------------------------------------------------------------------------------
+#define C8SD_TY 32
+
+struct C8StemDParams {
+  const unsigned short *DY, *Yc;   // [N][8][P][Q][8]
+  const float *W;                  // [64][R * S]
+  float *dX;                       // [N][H][Wd]
+  int N, H, Wd, P, Q, R, S, stride, pad, LW;
+  float slope;
+};
+
+__global__ __launch_bounds__(256) void c8_stem_dgrad_kernel(C8StemDParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sd_lds[];      // [4 waves][TY][LW] + [4][64] dummy slots
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int n = blockIdx.y, y0 = blockIdx.x * C8SD_TY;
+  const int tile = C8SD_TY * p.LW;
+  for (int u = tid; u < 4 * tile + 256; u += 256) sd_lds[u] = 0.f;
+
+  // A operands: Wt[t = 32 i + l31][k = 16 ks + 8 half + e], t = 8 r + c
+  bf16x8 af[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = 32 * i + l31, r = t >> 3, c = t & 7;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        v[e] = (r < p.R && c < p.S) ? p.W[(long)(16 * ks + 8 * half + e) * p.R * p.S + min(r, p.R - 1) * p.S + min(c, p.S - 1)] : 0.f;
+      af[ks][i] = c8_cvt8(v);
+    }
+  __syncthreads();
+
+  // small-map rows that reach the band: p * stride + r - pad in [y0, y0 + TY) for some r in [0, R)
+  const int p_lo = max(0, (y0 + p.pad - (p.R - 1) + p.stride - 1) / p.stride);
+  const int p_hi = min(p.P - 1, (y0 + C8SD_TY - 1 + p.pad) / p.stride);
+  const int qblocks = p.Q / 32, nitems = (p_hi - p_lo + 1) * qblocks;
+  const long PQ = (long)p.P * p.Q;
+  const u32x4 *dq = reinterpret_cast<const u32x4 *>(p.DY) + (long)n * 8 * PQ;
+  const u32x4 *yq = reinterpret_cast<const u32x4 *>(p.Yc) + (long)n * 8 * PQ;
+  float *mine = sd_lds + wave * tile;
+  float *dummy = sd_lds + 4 * tile + wave * 64 + lane;           // where the adds of tap column 7 (zero weights) go
+  // the C8 units of an item are fetched one item ahead (a wave's items are independent; with two workgroups per CU nothing
+  // else hides the HBM latency of a load -> mask -> MFMA -> scatter chain)
+  auto fetch = [&](int item, u32x4 (&dv)[4], u32x4 (&yv)[4]) {
+    const int pr = p_lo + item / qblocks, q0 = (item % qblocks) * 32;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const long u = (long)(2 * ks + half) * PQ + (long)pr * p.Q + q0 + l31;
+      dv[ks] = dq[u];
+      yv[ks] = yq[u];
+    }
+  };
+  auto process = [&](int item, const u32x4 (&dvr)[4], const u32x4 (&yvr)[4]) {
+    const int pr = p_lo + item / qblocks, q0 = (item % qblocks) * 32;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 dv = __builtin_bit_cast(bf16x8, dvr[ks]), yv = __builtin_bit_cast(bf16x8, yvr[ks]);
+      bf16x8 g;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)dv[e];
+        g[e] = (__bf16)c8_sel_nonpos((float)yv[e], d * p.slope, d);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], g, acc[i], 0, 0, 0);
+    }
+    // acc[i][rr]: tap t = 32 i + (rr & 3) + 8 (rr >> 2) + 4 half -> r = 4 i + (rr >> 2), c = (rr & 3) + 4 half, pixel (pr, q0 + l31)
+    const int xb = (q0 + l31) * p.stride;                       // LDS column of tap column 0 (= image column + pad)
+    // Scatter-add into the wave's private band by plain read - add - write (LDS float atomics run at well under one lane per
+    // cycle on this part: the first build, ds_add_f32, spent 95 % of its time in them).  Four rounds, every lane active in
+    // each: lanes 0-31 take tap column e, lanes 32-63 column 4 + ((e + 1) & 3) - columns of opposite parity, so (image columns
+    // advance by `stride` per lane) no two lanes of an instruction ever meet on one address; the one column beyond the tap grid
+    // (c = 7) goes to a per-lane dummy slot.  A round reads all tap rows, then writes them: rows never alias, and the LDS
+    // executes one wave's instructions in order, so round e + 1 reads what round e wrote.
+    typedef volatile float __attribute__((address_space(3))) *vlp;
+    // (Odd strides: columns of opposite parity can still meet, so the two half-waves take turns: `phases` = 2.)
+    const int phases = (p.stride & 1) ? 2 : 1;
+    for (int ph = 0; ph < phases; ++ph)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int e1 = (e + 1) & 3;
+      const int c = half ? 4 + e1 : e;
+      const bool mine_turn = phases == 1 || half == ph;
+      float old[8];
+      vlp dst[8];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int r = 4 * i + rq, yy = pr * p.stride + r - p.pad - y0;     // uniform
+          const bool ok = r < p.R && yy >= 0 && yy < C8SD_TY;
+          dst[r] = (vlp)((ok && c < p.S && mine_turn) ? mine + yy * p.LW + xb + c : dummy);
+          old[r] = *dst[r];
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int r = 4 * i + rq;
+          *dst[r] = old[r] + (half ? acc[i][rq * 4 + e1] : acc[i][rq * 4 + e]);
+        }
+    }
+  };
+  u32x4 da[4], ya[4], db_[4], yb[4];
+  if (wave < nitems) fetch(wave, da, ya);
+  for (int item = wave; item < nitems; item += 8) {
+    if (item + 4 < nitems) fetch(item + 4, db_, yb);
+    process(item, da, ya);
+    if (item + 4 < nitems) {
+      if (item + 8 < nitems) fetch(item + 8, da, ya);
+      process(item + 4, db_, yb);
+    }
+  }
+  __syncthreads();
+  float *dxn = p.dX + (long)n * p.H * p.Wd;
+  for (int u = tid; u < C8SD_TY * p.Wd; u += 256) {
+    const int yy = u / p.Wd, xx = u - yy * p.Wd;
+    if (y0 + yy >= p.H) continue;
+    const int o = yy * p.LW + xx + p.pad;
+    dxn[(long)(y0 + yy) * p.Wd + xx] = (sd_lds[o] + sd_lds[tile + o]) + (sd_lds[2 * tile + o] + sd_lds[3 * tile + o]);
+  }
+}
+
 }  // namespace lsps
 #endif

@@ -44,6 +44,9 @@ size_t c8_stem_wgrad_bf16_ws_bytes();
 int c8_stem_wgrad_bf16(const float *x, const void *dy, const void *y, float *dw, float *db, int N, int H, int W, int K, int R, int S,
                        int stride, int pad, float slope, void *ws, size_t ws_bytes, hipStream_t st);
 
+int c8_stem_dgrad_bf16(const void *dy, const void *y, const float *w, float *dx, int N, int H, int W, int K, int R, int S, int stride,
+                       int pad, float slope, hipStream_t st);
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 

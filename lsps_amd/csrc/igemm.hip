@@ -1902,4 +1902,17 @@ int lsps_pw1_dgrad_act(const float *dpre, const float *w, const float *act_y, fl
   return 0;
 }
 
+int lsps_c8_stem_dgrad(const void *dy, const void *y, const float *w, float *dx, int N, int H, int W, int K, int R, int S, int stride,
+                       int pad, float slope, void *stream) {
+  (void)hipGetLastError();
+  LSPS_CHECK_ARG(dy && y && w && dx && slope >= 0.f, "c8_stem_dgrad: null pointer / slope < 0");
+  LSPS_CHECK_ARG(c8_stem_bf16_ok(N, H, W, K, R, S, stride, pad), "c8_stem_dgrad: unsupported geometry (see lsps_c8_stem_dgrad_ok)");
+  note_kernel("c8_stem_dgrad_kernel");
+  return c8_stem_dgrad_bf16(dy, y, w, dx, N, H, W, K, R, S, stride, pad, slope, (hipStream_t)stream);
+}
+
+int lsps_c8_stem_dgrad_ok(int N, int H, int W, int K, int R, int S, int stride, int pad) {
+  return c8_stem_bf16_ok(N, H, W, K, R, S, stride, pad) ? 1 : 0;
+}
+
 }  // extern "C"

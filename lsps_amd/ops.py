@@ -936,8 +936,14 @@ class _StemC8Fn(torch.autograd.Function):
             with profiler.span(flops):
                 _lib.check(L.lsps_c8_stem_wgrad(_lib.ptr(x), _lib.ptr(dy, BF16), _lib.ptr(y, BF16), _lib.ptr(dw), _lib.ptr(db), N, H, W, K,
                                                 R, S, stride, pad, slope if slope >= 0 else 1.0, ws, wsb, st), 'c8_stem_wgrad')
-        if ctx.needs_input_grad[0]:
-            # gradient w.r.t. the image (the discriminator's stems inside gen_update): the f32 path of the layer
+        if ctx.needs_input_grad[0] and slope >= 0 and L.lsps_c8_stem_dgrad_ok(N, H, W, K, R, S, stride, pad) == 1:
+            # gradient w.r.t. the image (the discriminator's stems inside gen_update): bf16 tap GEMM + in-LDS col2im, one kernel
+            dx = torch.empty_like(x)
+            with profiler.span(flops):
+                _lib.check(L.lsps_c8_stem_dgrad(_lib.ptr(dy, BF16), _lib.ptr(y, BF16), _lib.ptr(w), _lib.ptr(dx), N, H, W, K, R, S, stride,
+                                                pad, slope, st), 'c8_stem_dgrad')
+        elif ctx.needs_input_grad[0]:
+            # shapes without that kernel: the f32 path of the layer
             g, _ = _c8_act_backward(L, dy, y, slope, False, K, st)
             g32 = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
             _lib.check(L.lsps_c8_to_nchw(_lib.ptr(g, BF16), _lib.ptr(g32), N, K, P * Q, st), 'c8_to_nchw')

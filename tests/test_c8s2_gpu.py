@@ -162,6 +162,19 @@ def test_c8_stem_forward_and_weight_gradient(N, H, stride):
     wref = torch.nn.grad.conv2d_weight(xr.double().cpu(), (K, 1, R, R), gd, stride=stride, padding=pad)
     assert _rel(dw, wref) <= 1e-4
     assert _rel(db, gd.sum((0, 2, 3))) <= 1e-4
+    # input gradient (the discriminator stems inside gen_update): bf16 tap GEMM + in-LDS col2im
+    if L.lsps_c8_stem_dgrad_ok(N, H, H, K, R, R, stride, pad) == 1:
+        dx = torch.full((N, 1, H, H), 7.0, device=dev)
+        for rep in range(2):                                  # deterministic: the same bits twice
+            _lib.check(L.lsps_c8_stem_dgrad(dyc.data_ptr(), y.data_ptr(), w.data_ptr(), dx.data_ptr(), N, H, H, K, R, R, stride, pad, 0.01,
+                                            st), 'stem dgrad')
+            if rep == 0:
+                first = dx.clone()
+        assert torch.equal(first, dx)
+        gq = torch.where(yd > 0, dyd, _rb((dyd * 0.01).float()).double())     # the kernel rounds the masked gradient to bf16
+        ref = F.conv_transpose2d(gq, _rb(w).double().cpu(), stride=stride, padding=pad, output_padding=H + 2 * pad - R - (P - 1) * stride)
+        assert ref.shape == dx.shape
+        assert _rel(dx, ref) <= 1e-4
 
 
 @pytest.mark.parametrize("N,C,H", [(3, 64, 128), (5, 16, 8)])
