@@ -1,4 +1,6 @@
-import sys; sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python
+"""Times lsps_c8_stem_dgrad (csrc/c8stem.h) at the discriminator stem geometry (7x7 / stride 2, 128x128 images) for N = 64 / 256 / 512."""
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lsps_amd import _lib
 L=_lib.lib(); dev=torch.device('cuda'); st=_lib.stream(); BF=torch.bfloat16
