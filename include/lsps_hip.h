@@ -245,8 +245,9 @@ int lsps_c8_conv3x3s2_dgrad_act(const void *dy, const float *w, const void *act_
 int lsps_c8_convT3x3s2_dgrad_act(const void *dy, const float *w, const void *act_y, float act_slope, void *dx, float *db_prev,
                                  int N, int Ci, int H, int W, int Co, void *ws, size_t ws_bytes, void *stream);
 size_t lsps_c8_pw1_dgrad_act_workspace_bytes(int N, int C);
+/* dw [C], db [1] (both nullable): the head's OWN weight / bias gradient from the same pass (act_y is its input) */
 int lsps_c8_pw1_dgrad_act(const float *dpre, const float *w, const void *act_y, float act_slope, void *dx, float *db_prev,
-                          int N, int C, int HW, void *ws, size_t ws_bytes, void *stream);
+                          float *dw, float *db, int N, int C, int HW, void *ws, size_t ws_bytes, void *stream);
 
 /* f32 mode: the LeakyReLU backward of two layers folded into kernels that stream their tensors anyway.
  *   lsps_conv2d_stem_wgrad_act  dw [K,1,R,S] and db [K] (nullable) of a one-input-channel LeakyReLUConv2d (the 7x7 stems,

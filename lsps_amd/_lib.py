@@ -101,7 +101,7 @@ _SIGNATURES = {
     'lsps_c8_conv3x3s2_dgrad_act': (c_int, [_P, _P, _P, c_float, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
     'lsps_c8_convT3x3s2_dgrad_act': (c_int, [_P, _P, _P, c_float, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
     'lsps_c8_pw1_dgrad_act_workspace_bytes': (c_size_t, [c_int] * 2),
-    'lsps_c8_pw1_dgrad_act': (c_int, [_P, _P, _P, c_float, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    'lsps_c8_pw1_dgrad_act': (c_int, [_P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     'lsps_conv2d_stem_wgrad_act_ok': (c_int, [c_int] * 8),
     'lsps_conv2d_stem_wgrad_act': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 8 + [c_float, _P, c_size_t, _P]),
     'lsps_pw1_dgrad_act_workspace_bytes': (c_size_t, [c_int] * 2),

@@ -688,19 +688,26 @@ int lsps_c8_convT3x3s2_dgrad_act(const void *dy, const float *w, const void *act
                       act_slope, db_prev);
 }
 
-size_t lsps_c8_pw1_dgrad_act_workspace_bytes(int N, int C) { return align_up(((size_t)N + 64) * C * sizeof(float), 256); }
+// [N][C] partials of the previous layer's bias gradient + [64][C] scratch + [N][C + 1] partials of the head's own gradients
+size_t lsps_c8_pw1_dgrad_act_workspace_bytes(int N, int C) { return align_up(((size_t)2 * N + 64) * (C + 1) * sizeof(float), 256); }
 
-int lsps_c8_pw1_dgrad_act(const float *dpre, const float *w, const void *act_y, float act_slope, void *dx, float *db_prev, int N, int C,
-                          int HW, void *ws, size_t ws_bytes, void *stream) {
+int lsps_c8_pw1_dgrad_act(const float *dpre, const float *w, const void *act_y, float act_slope, void *dx, float *db_prev, float *dw,
+                          float *db, int N, int C, int HW, void *ws, size_t ws_bytes, void *stream) {
   (void)hipGetLastError();
   LSPS_CHECK_ARG(dpre && w && act_y && dx && N > 0 && C > 0 && (C & 7) == 0 && C <= 64 && HW > 0 && act_slope >= 0.f,
                  "c8_pw1_dgrad_act: bad arguments (C %% 8 == 0, C <= 64)");
-  LSPS_CHECK_ARG(ws && ws_bytes >= ((size_t)N + 64) * C * sizeof(float), "c8_pw1_dgrad_act: workspace too small");
+  LSPS_CHECK_ARG(ws && ws_bytes >= lsps_c8_pw1_dgrad_act_workspace_bytes(N, C) - 256, "c8_pw1_dgrad_act: workspace too small");
   hipStream_t st = (hipStream_t)stream;
+  float *part = (float *)ws, *scratch = part + (size_t)N * C, *wpart = dw ? scratch + (size_t)64 * (C + 1) : nullptr;
   hipLaunchKernelGGL(c8_pw1_dgrad_act_kernel, dim3(N), dim3(256), 0, st, dpre, w, (const unsigned short *)act_y, (unsigned short *)dx,
-                     (float *)ws, C, HW, act_slope);
+                     part, wpart, C, HW, act_slope);
   LSPS_CHECK_LAUNCH("c8_pw1_dgrad_act");
-  if (db_prev) return c8_colsum((const float *)ws, db_prev, C, N, (float *)ws + (size_t)N * C, st);
+  if (db_prev)
+    if (int rc = c8_colsum(part, db_prev, C, N, scratch, st)) return rc;
+  if (dw) {                                                     // the head's own weight gradient [C] (+ bias gradient [1]) from the same pass
+    hipLaunchKernelGGL(c8_pw1_wgrad_reduce_kernel, dim3(ceil_div(C + 1, 256)), dim3(256), 0, st, (const float *)wpart, dw, db, C, N);
+    LSPS_CHECK_LAUNCH("c8_pw1_wgrad_reduce");
+  }
   return 0;
 }
 

@@ -43,18 +43,23 @@ __global__ __launch_bounds__(256) void c8_pw1_dgrad_kernel(const float *__restri
 // dx[n][c][pix] = w[c] * dpre[n][pix] * (y[n][c][pix] > 0 ? 1 : slope): the head's input gradient with the LeakyReLU backward of
 // the layer in front of it (whose saved output is y) fused, and that layer's bias gradient as per-image partial sums
 // part[n][c] (C <= 64).  One workgroup per image.
+// wpart (nullable): per-image partial sums of the head's OWN weight gradient, wpart[n][c] = sum_pix y[n][c][pix] * dpre[n][pix]
+// (y is the head's input), and wpart[n][C] = sum_pix dpre (its bias gradient): the same two operands stream through here
+// anyway, so the separate c8_pw1_wgrad pass over y disappears.
 __global__ __launch_bounds__(256) void c8_pw1_dgrad_act_kernel(const float *__restrict__ dpre, const float *__restrict__ w,
                                                                const unsigned short *__restrict__ y, unsigned short *__restrict__ dx,
-                                                               float *__restrict__ part, int C, int HW, float slope) {
+                                                               float *__restrict__ part, float *__restrict__ wpart, int C, int HW,
+                                                               float slope) {
   __shared__ float red[4][64];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = C >> 3;
   const u32x4 *yp = reinterpret_cast<const u32x4 *>(y) + (long)n * G * HW;
   u32x4 *xp = reinterpret_cast<u32x4 *>(dx) + (long)n * G * HW;
-  float s[64];
+  float s[64], sw[64], sd = 0.f;
 #pragma unroll
-  for (int e = 0; e < 64; ++e) s[e] = 0.f;
+  for (int e = 0; e < 64; ++e) s[e] = sw[e] = 0.f;
   for (int px = tid; px < HW; px += 256) {
     const float d = dpre[(long)n * HW + px];
+    sd += d;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       if (g >= G) break;
@@ -65,6 +70,7 @@ __global__ __launch_bounds__(256) void c8_pw1_dgrad_act_kernel(const float *__re
         const float x = w[g * 8 + e] * d;
         v[e] = (__bf16)c8_sel_nonpos((float)yv[e], x * slope, x);
         s[g * 8 + e] += (float)v[e];
+        sw[g * 8 + e] = fmaf((float)yv[e], d, sw[g * 8 + e]);
       }
       xp[(long)g * HW + px] = __builtin_bit_cast(u32x4, v);
     }
@@ -76,6 +82,21 @@ __global__ __launch_bounds__(256) void c8_pw1_dgrad_act_kernel(const float *__re
   }
   __syncthreads();
   if (tid < C) part[(long)n * C + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  if (wpart) {                                                  // uniform
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 64; ++e) {
+      const float t = wave_sum(sw[e]);
+      if (lane == 0) red[wave][e] = t;
+    }
+    sd = wave_sum(sd);
+    __syncthreads();
+    if (tid < C) wpart[(long)n * (C + 1) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    __syncthreads();
+    if (lane == 0) red[wave][0] = sd;
+    __syncthreads();
+    if (tid == 0) wpart[(long)n * (C + 1) + C] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+  }
 }
 
 // part[split][c] = sum over the split's images and all pixels of x[n][c][pix] * dpre[n][pix];  part[split][C] = sum of dpre

@@ -995,19 +995,27 @@ class _Pw1C8Fn(torch.autograd.Function):
             _lib.check(L.lsps_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dpre), dy.numel(), act, slope, st), 'act_bwd')
         else:
             dpre = dy
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        want_w = ctx.needs_input_grad[1] or want_db
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             with profiler.span(flops, 'pw1_dgrad_kernel'):
                 if _fusable(ctx.prev) and C <= 64:
+                    # one pass over the head's input: its gradient with the previous layer's LeakyReLU backward and bias gradient,
+                    # AND the head's own weight / bias gradient (same two operands)
                     dbp = torch.empty(C, dtype=torch.float32, device=x.device)
+                    if want_w:
+                        dw = torch.empty_like(w)
+                        db = torch.empty(1, dtype=torch.float32, device=x.device) if want_db else None
                     wsd, wsdb = _lib.workspace(L.lsps_c8_pw1_dgrad_act_workspace_bytes(N, C), x.device)
                     _lib.check(L.lsps_c8_pw1_dgrad_act(_lib.ptr(dpre), _lib.ptr(w), _lib.ptr(x, BF16), ctx.prev.slope, _lib.ptr(dx, BF16),
-                                                       _lib.ptr(dbp), N, C, H * W, wsd, wsdb, st), 'c8_pw1_dgrad_act')
+                                                       _lib.ptr(dbp), _lib.ptr(dw), _lib.ptr(db), N, C, H * W, wsd, wsdb, st),
+                               'c8_pw1_dgrad_act')
                     ctx.prev.fused, ctx.prev.db = True, dbp
+                    want_w = False
                 else:
                     _lib.check(L.lsps_c8_pw1_dgrad(_lib.ptr(dpre), _lib.ptr(w), _lib.ptr(dx, BF16), N, C, H * W, st), 'c8_pw1_dgrad')
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] or want_db:
+        if want_w:
             dw = torch.empty_like(w)
             db = torch.empty(1, dtype=torch.float32, device=x.device) if want_db else None
             ws, wsb = _lib.workspace(L.lsps_c8_pw1_workspace_bytes(N, C), x.device)

@@ -261,13 +261,17 @@ def test_c8_pw1_dgrad_with_fused_previous_activation():
     dx = torch.full((N, C // 8, H, H, 8), 7.0, dtype=BF, device=dev)
     db = torch.full((C,), 7.0, device=dev)
     ws, wsb = _lib.workspace(L.lsps_c8_pw1_dgrad_act_workspace_bytes(N, C), dev)
-    _lib.check(L.lsps_c8_pw1_dgrad_act(dpre.data_ptr(), w.data_ptr(), yc.data_ptr(), 0.01, dx.data_ptr(), db.data_ptr(), N, C, H * H, ws, wsb,
-                                       st), 'pw1 dgrad_act')
+    dwh, dbh = torch.full((C, 1, 1, 1), 7.0, device=dev), torch.full((1,), 7.0, device=dev)
+    _lib.check(L.lsps_c8_pw1_dgrad_act(dpre.data_ptr(), w.data_ptr(), yc.data_ptr(), 0.01, dx.data_ptr(), db.data_ptr(), dwh.data_ptr(),
+                                       dbh.data_ptr(), N, C, H * H, ws, wsb, st), 'pw1 dgrad_act')
     ref = F.conv2d(dpre.double().cpu(), w.double().cpu())
     ref = torch.where(_rb(yprev).double().cpu() > 0, ref, ref * 0.01)
     got = _from_c8(dx)
     assert _rel(got, ref) <= C8_TOL
     assert _rel(db, got.double().cpu().sum((0, 2, 3))) <= 1e-5 * max(1.0, (N * H * H) ** 0.5 / 8)
+    # the head's own gradients from the same pass (its input is yprev)
+    assert _rel(dwh.view(C), (_rb(yprev).double().cpu() * dpre.double().cpu()).sum((0, 2, 3))) <= 1e-4
+    assert _rel(dbh, dpre.double().cpu().sum().view(1)) <= 1e-4
 
 
 def test_fused_activation_backward_equals_the_separate_pass(monkeypatch):
