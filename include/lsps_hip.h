@@ -261,6 +261,7 @@ int lsps_conv2d_stem_wgrad_act(const float *x, const float *dy, const float *y, 
                                int K, int R, int S, int stride, int pad, float slope, void *ws, size_t ws_bytes, void *stream);
 size_t lsps_pw1_dgrad_act_workspace_bytes(int N, int C);
 int lsps_pw1_dgrad_act(const float *dpre, const float *w, const float *act_y, float act_slope, float *dx, float *db_prev /*nullable*/,
+                       float *dw /*nullable: the head's own weight gradient [C]*/, float *db /*nullable: its bias gradient [1]*/,
                        int N, int C, int HW, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- ConvTranspose2d: replaces nn.ConvTranspose2d forward/backward -------------------------

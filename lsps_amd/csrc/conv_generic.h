@@ -553,20 +553,23 @@ __global__ __launch_bounds__(256) void pw1_dgrad_kernel(const float *__restrict_
 // dx[n][c][pix] = w[c] * dy[n][pix] * (y[n][c][pix] > 0 ? 1 : slope): the 1x1 head's input gradient with the LeakyReLU backward of
 // the layer in front of it (saved output y, dx's shape) fused, and that layer's bias gradient as partial sums part[block][C]
 // (C <= 64; grid = 2 blocks per image: 512 pixel quads each for a 128x128 map ... the quads of a block are strided by 256).
+// wpart (nullable): partial sums of the head's OWN gradients from the same pass, wpart[block][c] = sum y[c][pix] * dy[pix] (y is its
+// input) and wpart[block][C] = sum dy.
 __global__ __launch_bounds__(256) void pw1_dgrad_act_kernel(const float *__restrict__ dy, const float *__restrict__ w,
                                                             const float *__restrict__ y, float *__restrict__ dx, float *__restrict__ part,
-                                                            int C, int HW4, float slope) {
+                                                            float *__restrict__ wpart, int C, int HW4, float slope) {
   __shared__ float red[4][64];
   const int n = blockIdx.x >> 1, hb = blockIdx.x & 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q0 = hb * ((HW4 + 1) / 2), q1 = hb ? HW4 : (HW4 + 1) / 2;
   const f32x4 *yp = reinterpret_cast<const f32x4 *>(y) + (long)n * C * HW4;
   f32x4 *xp = reinterpret_cast<f32x4 *>(dx) + (long)n * C * HW4;
   const f32x4 *gp = reinterpret_cast<const f32x4 *>(dy) + (long)n * HW4;
-  float s[64];
+  float s[64], sw[64], sd = 0.f;
 #pragma unroll
-  for (int c = 0; c < 64; ++c) s[c] = 0.f;
+  for (int c = 0; c < 64; ++c) s[c] = sw[c] = 0.f;
   for (int q = q0 + tid; q < q1; q += 256) {
     const f32x4 g = gp[q];
+    sd += (g[0] + g[1]) + (g[2] + g[3]);
 #pragma unroll 8
     for (int c = 0; c < 64; ++c) {
       if (c >= C) break;
@@ -580,6 +583,7 @@ __global__ __launch_bounds__(256) void pw1_dgrad_act_kernel(const float *__restr
       }
       xp[(long)c * HW4 + q] = o;
       s[c] += (o[0] + o[1]) + (o[2] + o[3]);
+      sw[c] += (yv[0] * g[0] + yv[1] * g[1]) + (yv[2] * g[2] + yv[3] * g[3]);
     }
   }
 #pragma unroll
@@ -589,6 +593,34 @@ __global__ __launch_bounds__(256) void pw1_dgrad_act_kernel(const float *__restr
   }
   __syncthreads();
   if (tid < C) part[(long)blockIdx.x * C + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  if (wpart) {                                                  // uniform
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+      const float t = wave_sum(sw[c]);
+      if (lane == 0) red[wave][c] = t;
+    }
+    sd = wave_sum(sd);
+    __syncthreads();
+    if (tid < C) wpart[(long)blockIdx.x * (C + 1) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    __syncthreads();
+    if (lane == 0) red[wave][0] = sd;
+    __syncthreads();
+    if (tid == 0) wpart[(long)blockIdx.x * (C + 1) + C] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+  }
+}
+
+// dW[c] = sum_b wpart[b][c] (c < C), db[0] = sum_b wpart[b][C]   (C <= 255; one block)
+__global__ __launch_bounds__(256) void pw1_wsplit_reduce_kernel(const float *__restrict__ wpart, float *__restrict__ dW, float *__restrict__ db,
+                                                                int C, int blocks) {
+  const int c = threadIdx.x;
+  if (c > C) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += wpart[(long)b * (C + 1) + c];
+  if (c < C)
+    dW[c] = s;
+  else if (db)
+    db[0] = s;
 }
 
 // part[s][c] = sum over slice s of (n,pix) of x[n][c][pix] * dy[n][pix]   (grid: C x S).  (image, quad) of a thread's

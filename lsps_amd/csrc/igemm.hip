@@ -1883,21 +1883,26 @@ int lsps_conv2d_stem_wgrad_act(const float *x, const float *dy, const float *y, 
   return run_c1_wgrad(dy, x, dw, N, H, W, K, P, Q, R, S, stride, pad, ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr, slope, db, y);
 }
 
-size_t lsps_pw1_dgrad_act_workspace_bytes(int N, int C) { return (size_t)2 * N * C * sizeof(float) + 256; }
+size_t lsps_pw1_dgrad_act_workspace_bytes(int N, int C) { return (size_t)2 * N * (2 * C + 1) * sizeof(float) + 256; }
 
-int lsps_pw1_dgrad_act(const float *dpre, const float *w, const float *act_y, float act_slope, float *dx, float *db_prev, int N, int C,
-                       int HW, void *ws, size_t ws_bytes, void *stream) {
+int lsps_pw1_dgrad_act(const float *dpre, const float *w, const float *act_y, float act_slope, float *dx, float *db_prev, float *dw,
+                       float *db, int N, int C, int HW, void *ws, size_t ws_bytes, void *stream) {
   (void)hipGetLastError();
   LSPS_CHECK_ARG(dpre && w && act_y && dx && N > 0 && C > 0 && C <= 64 && HW > 0 && (HW & 3) == 0 && act_slope >= 0.f,
                  "pw1_dgrad_act: bad arguments (C <= 64, HW %% 4 == 0)");
-  LSPS_CHECK_ARG(ws && ws_bytes >= (size_t)2 * N * C * sizeof(float), "pw1_dgrad_act: workspace too small");
+  LSPS_CHECK_ARG(ws && ws_bytes >= (size_t)2 * N * (2 * C + 1) * sizeof(float), "pw1_dgrad_act: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pw1_dgrad_act_kernel, dim3(2 * N), dim3(256), 0, st, dpre, w, act_y, dx, (float *)ws, C, HW / 4, act_slope);
+  float *part = (float *)ws, *wpart = dw ? part + (size_t)2 * N * C : nullptr;
+  hipLaunchKernelGGL(pw1_dgrad_act_kernel, dim3(2 * N), dim3(256), 0, st, dpre, w, act_y, dx, part, wpart, C, HW / 4, act_slope);
   LSPS_CHECK_LAUNCH("pw1_dgrad_act");
   note_kernel("pw1_dgrad_kernel");
   if (db_prev) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)ws, db_prev, (long)C, 2 * N);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)part, db_prev, (long)C, 2 * N);
     LSPS_CHECK_LAUNCH("reduce_partials");
+  }
+  if (dw) {                      // the head's own weight gradient [C] and bias gradient [1] from the same pass: rows of C + 1
+    hipLaunchKernelGGL(pw1_wsplit_reduce_kernel, dim3(1), dim3(256), 0, st, (const float *)wpart, dw, db, C, 2 * N);
+    LSPS_CHECK_LAUNCH("pw1_wsplit_reduce");
   }
   return 0;
 }

@@ -393,10 +393,15 @@ class _ConvT2dFn(torch.autograd.Function):
                 if _fusable(ctx.prev) and (R, S, Co, stride, pad, outpad) == (1, 1, 1, 1, 0, 0) and Ci <= 64 and (H * W) % 4 == 0:
                     # 1x1 output head: its input is the previous layer's output; that layer's LeakyReLU backward rides along
                     dbp = torch.empty(Ci, dtype=torch.float32, device=x.device)
+                    need_w = ctx.needs_input_grad[1]                     # the head's own weight gradient comes out of the same pass
+                    if need_w:                                           # (its bias gradient: from the activation backward above)
+                        dw = torch.empty_like(w)
                     wsd, wsdb = _lib.workspace(L.lsps_pw1_dgrad_act_workspace_bytes(N, Ci), x.device)
                     _lib.check(L.lsps_pw1_dgrad_act(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(x), ctx.prev.slope, _lib.ptr(dx), _lib.ptr(dbp),
-                                                    N, Ci, H * W, wsd, wsdb, st), 'pw1_dgrad_act')
+                                                    _lib.ptr(dw), None, N, Ci, H * W, wsd, wsdb, st), 'pw1_dgrad_act')
                     ctx.prev.fused, ctx.prev.db = True, dbp
+                    if need_w and (db is not None or not want_db):
+                        return dx, dw, db, None, None, None, None, None, None, None
                 else:
                     _lib.check(L.lsps_convT2d_dgrad(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), N, Ci, H, W, Co, R, S, stride,
                                                     pad, outpad, ws, wsb, st), 'convT2d_dgrad')
