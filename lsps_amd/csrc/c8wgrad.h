@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512, 1) void c8_wgrad_kernel(C8WgradParams p) {
       topbot[i] = in ? (r == 0 ? 1u : 0u) | (r == CW8_ROWS + 1 ? 2u : 0u) : 0u;
     }
   }
-  auto issue = [&](int n, int rc, int stage) {                  // image n, chunk rc (rows 4 rc ..) -> LDS stage
+  auto issue = [&](int n, int rc, int stage, int i0 = 0, int i1 = 8) {      // image n, chunk rc (rows 4 rc ..) -> LDS stage; pieces i0 .. i1-1
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short *>(p.DY) + (long)n * (dy_img >> 1), 0, dy_img, 0x00020000);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(512, 1) void c8_wgrad_kernel(C8WgradParams p) {
     const int row_off = rc * (CW8_ROWS * 512);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+      if (i < i0 || i >= i1) continue;
       const int piece = wave + 8 * i;
       if (piece < 32) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -130,14 +131,20 @@ __global__ __launch_bounds__(512, 1) void c8_wgrad_kernel(C8WgradParams p) {
   }
   for (int it = 0; it < total; ++it) {
     const int stage = it & 1;
-#ifndef C8W_ABL_NODMA                    // ablation builds: tools/build_abl_c8.sh
-    if (it + 1 < total) issue(n0 + (it + 1) / chunks_per_img, (it + 1) % chunks_per_img, stage ^ 1);
+    const bool more = it + 1 < total;
+    const int nn = n0 + (it + 1) / chunks_per_img, nrc = (it + 1) % chunks_per_img;
+#if !defined(C8W_ABL_NODMA) && !defined(C8W_SPREAD_DMA)
+    if (more) issue(nn, nrc, stage ^ 1);
 #endif
     const unsigned char *As = c8w_lds + stage * CW8_STAGE + a_base;
     const unsigned char *Bs = c8w_lds + stage * CW8_STAGE + b_base;
 #pragma unroll
     for (int ks = 0; ks < CW8_ROWS * 2; ++ks) {                 // 16 pixels: row ks / 2, columns 16 (ks & 1) ..
       const int rr = ks >> 1, x0 = (ks & 1) * 16;
+#if defined(C8W_SPREAD_DMA) && !defined(C8W_ABL_NODMA)          // experiment: one DMA piece per k-step instead of a burst of eight
+      if (more) issue(nn, nrc, stage ^ 1, ks, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       const bf16x8 af = c8_tr_frag(As + (rr * 32 + x0) * 16, As + (rr * 32 + x0 + 4) * 16);
 #ifdef C8W_ABL_ALLREADS                  // the first build: every tap's fragment by its own two transposing reads (18 per k-step)
 #pragma unroll
