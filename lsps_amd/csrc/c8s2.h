@@ -174,7 +174,9 @@ __global__ __launch_bounds__(512, 1) void c8s2_fwd_kernel(C8S2Params p) {
   __builtin_amdgcn_s_barrier();
   for (int ch = 0; ch < nch; ++ch) {
     const int stage = ch & 1;
+#ifndef C8S2_ABL_NODMA                   // ablation builds: tools/build_abl_c8.sh
     if (ch + 1 < nch) issue(ch + 1, stage ^ 1);
+#endif
     const unsigned char *S = s2_lds + stage * C8S2F_STAGE;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -194,6 +196,19 @@ __global__ __launch_bounds__(512, 1) void c8s2_fwd_kernel(C8S2Params p) {
     __builtin_amdgcn_s_barrier();
   }
 
+#ifdef C8S2_ABL_NOEPI
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 1.2345e30f) p.Y[0] = 1;
+    return;
+  }
+#endif
   // epilogue: acc[i][j][r] = channel mt*128 + wm*64 + i*32 + (r&3) + 8 (r>>2) + 4 half of pixel j; a register quad = 8 bytes
   typedef unsigned long long u64;
   const bool masked = p.ActY != nullptr;                        // uniform
@@ -358,7 +373,9 @@ __global__ __launch_bounds__(512, 1) void c8s2_tr_kernel(C8S2Params p) {
   __builtin_amdgcn_s_barrier();
   for (int ch = 0; ch < nch; ++ch) {
     const int stage = ch & 1;
+#ifndef C8S2_ABL_NODMA
     if (ch + 1 < nch) issue(ch + 1, stage ^ 1);
+#endif
     const unsigned char *S = s2_lds + stage * C8S2T_STAGE;
 #pragma unroll
     for (int ks = 0; ks < C8S2T_KS; ++ks) {
@@ -381,6 +398,19 @@ __global__ __launch_bounds__(512, 1) void c8s2_tr_kernel(C8S2Params p) {
     __builtin_amdgcn_s_barrier();
   }
 
+#ifdef C8S2_ABL_NOEPI
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[c][j][r];
+    if (t == 1.2345e30f) p.Y[0] = 1;
+    return;
+  }
+#endif
   // epilogue.  acc[cls][j][r]: channel mt*64 + wm*32 + (r&3) + 8 (r>>2) + 4 half at output (2p + a, 2q + b).  The two column
   // classes of a row are exchanged across the half-waves (v_permlane32_swap: cdna_hip_programming.md T21) so that lanes 0-31
   // store the whole 16-byte unit of column 2q and lanes 32-63 that of column 2q + 1: 1 KB contiguous per wave instruction.
@@ -596,7 +626,9 @@ __global__ __launch_bounds__(512, 1) void c8s2_wgrad_kernel(C8S2WParams p) {
   }
   for (int it = c0; it < c1; ++it) {
     const int stage = (it - c0) & 1;
+#ifndef C8S2_ABL_NODMA
     if (it + 1 < c1) issue(it + 1, stage ^ 1);
+#endif
     const unsigned char *St = s2_lds + stage * C8S2W_STAGE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
