@@ -354,6 +354,29 @@ def main():
             ops.set_math_mode('bf16')
             t_bf16 = timed(pretrain_step, 2)
             ops.set_math_mode('f32')
+        # BASELINE config 5 itself (exps/nicvl.yaml nets, bf16 activations in the channel-group layout, bs=256): its own
+        # trainer, same seeded-weight recipe; the standalone line is `bench.py --exp nicvl --dtype bf16 --batch 256`
+        t_c5 = None
+        if args.dtype == 'f32' and args.exp == 'nnyu' and os.environ.get('LSPS_BENCH_CONFIG5', '1') != '0':
+            hp5 = load_hp('nicvl')
+            tr5 = trainers.LSPSTrainer(hp5)
+            tr5.cuda(dev_index)
+            for net, seed in ((tr5.gen, 1), (tr5.dis, 2), (tr5.vae, 3)):
+                shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+                net.load_state_dict({k: torch.as_tensor(v) for k, v in synth.make_state_dict(shapes, seed).items()})
+            tr5.gen.train()
+            tr5.dis.train()
+            b5 = make_device_batch(256, dev, seed_offset=rank, label_dim=hp5['vae']['input_dim'])
+
+            def step5():
+                tr5.dis_update(b5['xa'], b5['la'], b5['xb'], b5['lb'], b5['ca'], b5['cb'], hp5)
+                tr5.gen_update(b5['xa'], b5['la'], b5['xb'], b5['lb'], hp5)
+            ops.set_math_mode('bf16')
+            step5()
+            t_c5 = timed(step5, 5)
+            ops.set_math_mode('f32')
+            del tr5, b5
+            torch.cuda.empty_cache()
         # the reference's own shipped batch size (exps/*.yaml `batch_size: 32`), eager and replayed from hipGraphs
         t_ref_bs = t_ref_bs_graph = None
         ref_bs = 32
@@ -380,11 +403,16 @@ def main():
                 'hip_graph_steps_per_s': 1.0 / t_ref_bs_graph,
                 'note': 'same pretrain step at the batch size the shipped exps/*.yaml train with (32 per domain); '
                         'LSPSTrainer.use_graphs (depth_train.py --graphs) replays it from hipGraphs'}
+        if t_c5:
+            extra['config5_pretrain_step_nicvl_bf16_bs256'] = {
+                'steps_per_s': 1.0 / t_c5, 'ms_per_step': 1e3 * t_c5, 'samples_per_s_per_domain': 256.0 / t_c5,
+                'note': 'BASELINE config 5 on one GPU: exps/nicvl.yaml nets, batch 256 per domain, bf16 activations / MFMA operands '
+                        '(f32 accumulate, statistics, losses, Adam); NOT the headline value'}
         if t_bf16:
             extra['pretrain_step_bf16_mfma_bs%d' % args.batch] = {
                 'steps_per_s': 1.0 / t_bf16, 'ms_per_step': 1e3 * t_bf16,
-                'note': 'residual 3x3 convs on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 when staged into LDS, f32 '
-                        'accumulate, f32 tensors/statistics/Adam); NOT the headline value'}
+                'note': 'the headline workload (exps/nnyu.yaml nets) in bf16 mode: bf16 activations in the channel-group layout, '
+                        'v_mfma_f32_32x32x16_bf16 with f32 accumulate, f32 statistics / losses / Adam; NOT the headline value'}
 
     if rank == 0:
         peak = F32_MFMA_PEAK_TFLOPS if args.dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS

@@ -219,6 +219,17 @@ static float *c8s2_dbpart(void *ws, size_t ws_bytes, int ntiles, int M, size_t p
 }
 
 // small[n][m] = act(bias + sum Wt[m][kk][r][s] big[n][kk][2p+r-1][2q+s-1]);  W element (m, kk, t) at m*sm + kk*sc + t
+static int c8_device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    cus = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
 static int c8s2_run_fwd(const void *big, const float *w, long sm, long sc, const float *bias, void *small, int N, int Cx, int H, int W,
                         int M, float slope, void *ws, size_t ws_bytes, hipStream_t st, const void *act_y = nullptr, float act_slope = 0.f,
                         float *db_prev = nullptr) {
@@ -250,7 +261,8 @@ static int c8s2_run_fwd(const void *big, const float *w, long sm, long sc, const
       return LSPS_E_ARG;
     }
   }
-  const dim3 grid((p.ntiles + 7) / 8 * 8 * (M >> 7));
+  // persistent workgroups (one per CU: the kernel's LDS footprint admits no second), each walking tiles grid apart
+  const dim3 grid(std::min((p.ntiles + 7) / 8 * 8 * (M >> 7), c8_device_cus() / 8 * 8));
   if (nj == 2) {
     if (int rc = lds_optin(reinterpret_cast<const void *>(c8s2_fwd_kernel<2>), C8S2F_LDS_BYTES, "c8s2_fwd")) return rc;
     hipLaunchKernelGGL(c8s2_fwd_kernel<2>, grid, dim3(512), C8S2F_LDS_BYTES, st, p);

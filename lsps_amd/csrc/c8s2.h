@@ -88,48 +88,73 @@ __global__ __launch_bounds__(512, 1) void c8s2_fwd_kernel(C8S2Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int wm = wave & 1, wp = wave >> 1;
+  typedef unsigned long long u64;
 
-  // workgroup -> (pixel tile, m tile): the m tiles of a pixel tile are consecutive on ONE XCD (its L2 serves the re-reads)
-  const int MT = p.M >> 7, lin = blockIdx.x, xcd = lin & 7, qq = lin >> 3;
-  const int mt = qq % MT, ptile = xcd + 8 * (qq / MT);
-  if (ptile >= p.ntiles) return;
+  // Persistent workgroups: workgroup b walks the tiles lin = b, b + grid, ... (grid is a multiple of 8, so lin & 7 — the XCD the
+  // hardware placed it on — stays put).  lin -> (pixel tile, m tile): the m tiles of a pixel tile are consecutive on ONE XCD (its
+  // L2 serves the re-reads).  The first chunk of the next tile is requested during the last chunk of the current one, and the
+  // epilogue's stores drain under the next tile's MFMAs: with one workgroup per CU nothing else would overlap them
+  // (profiles/r3g_c8_ablations.txt: a third of the kernel on the 64-channel layers).
+  const int MT = p.M >> 7, G = gridDim.x, nlin = ((p.ntiles + 7) >> 3) * 8 * MT;
   const int TI = p.TI, TR = p.TR, Q = p.Q;
   const int CB = 2 * Q + 1, blk = (2 * TR + 1) * CB, plane = TI * blk, bunits = 2 * plane;
-  int n0, p0;
-  if (TI == 1) {
-    n0 = ptile / p.tiles_per_img;
-    p0 = (ptile - n0 * p.tiles_per_img) * TR;
-  } else {
-    n0 = ptile * TI;
-    p0 = 0;
-  }
-  const int nimg = min(TI, p.N - n0);
   const int HW16 = p.H * p.W * 16, img_bytes = (p.Cx >> 3) * HW16, nch = p.Cx >> 4;
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned short *>(p.X) + (long)n0 * (img_bytes >> 1), 0, nimg * img_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned short *>(p.Wq) + (long)mt * nch * C8S2F_ACHUNK, 0, nch * C8S2F_ACHUNK * 2, 0x00020000);
+  const int PQ = p.P * Q, tpi = TR * Q;
+  const bool masked = p.ActY != nullptr;                        // uniform
 
-  // DMA pieces of this wave: image pieces wave + 8 i (i < 6: up to 48 >= 42), weight pieces wave + 8 i (i < 5: 40 >= 36)
+  int mt, ptile, n0, p0, nimg;                                  // the tile whose DMA set-up is current
+  __amdgpu_buffer_rsrc_t xrs, wrs;
   unsigned voffb[6], voffa[5];
+  // per-lane geometry of the image pieces that does not depend on the tile (piece wave + 8 i, i < 6: up to 48 >= 42)
+  int pimg[6], prow[6];                                         // image within the tile, input row relative to 2 p0  (or -1: dead lane)
+  unsigned pcol[6];                                             // byte offset of (k half, column) within an image row set
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const int u = (wave + 8 * i) * 64 + lane;
-    unsigned v = C8S2_OOB;
+    pimg[i] = -1; prow[i] = 0; pcol[i] = 0;
     if (u < bunits) {
       const int kh = u >= plane ? 1 : 0, rem = u - kh * plane;
       const int img = rem / blk, rem2 = rem - img * blk;
       const int ri = rem2 / CB, ci = rem2 - ri * CB;
-      const int row = ri <= TR ? 2 * (p0 + ri) - 1 : 2 * (p0 + ri - TR - 1);
       const int col = ci <= Q ? 2 * ci - 1 : 2 * (ci - Q - 1);
-      if (row >= 0 && row < p.H && col >= 0 && col < p.W && img < nimg)
-        v = (unsigned)(img * img_bytes + kh * HW16 + (row * p.W + col) * 16);
+      if (col >= 0 && col < p.W) {
+        pimg[i] = img;
+        prow[i] = ri <= TR ? 2 * ri - 1 : 2 * (ri - TR - 1);
+        pcol[i] = (unsigned)(kh * HW16 + col * 16);
+      }
     }
-    voffb[i] = v;
   }
 #pragma unroll
   for (int i = 0; i < 5; ++i) voffa[i] = (unsigned)(((wave + 8 * i) * 64 + lane) * 16);
   const int bpieces = (bunits + 63) >> 6;
+
+  auto decode = [&](int lin, int &mt_, int &ptile_) {
+    const int xcd = lin & 7, qq = lin >> 3;
+    mt_ = qq % MT;
+    ptile_ = xcd + 8 * (qq / MT);
+    return lin < nlin && ptile_ < p.ntiles;
+  };
+  auto setup = [&](int mt_, int ptile_) {
+    mt = mt_; ptile = ptile_;
+    if (TI == 1) {
+      n0 = ptile / p.tiles_per_img;
+      p0 = (ptile - n0 * p.tiles_per_img) * TR;
+    } else {
+      n0 = ptile * TI;
+      p0 = 0;
+    }
+    nimg = min(TI, p.N - n0);
+    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.X) + (long)n0 * (img_bytes >> 1), 0, nimg * img_bytes,
+                                            0x00020000);
+    wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.Wq) + (long)mt * nch * C8S2F_ACHUNK, 0,
+                                            nch * C8S2F_ACHUNK * 2, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int row = 2 * p0 + prow[i];
+      voffb[i] = (pimg[i] >= 0 && pimg[i] < nimg && row >= 0 && row < p.H)
+                     ? (unsigned)(pimg[i] * img_bytes + row * p.W * 16) + pcol[i] : C8S2_OOB;
+    }
+  };
   auto issue = [&](int ch, int stage) {
     unsigned char *base = s2_lds + stage * C8S2F_STAGE;
 #pragma unroll
@@ -147,125 +172,152 @@ __global__ __launch_bounds__(512, 1) void c8s2_fwd_kernel(C8S2Params p) {
     }
   };
 
-  // this lane's output pixels: tile pixel t = wp * 32 NJ + 32 j + l31 -> (image, row, column)
+  // this lane's output pixels: tile pixel t = wp * 32 NJ + 32 j + l31 -> (image, row, column) of the tile
   unsigned bbase[NJ];
-  long ypix[NJ];                                               // unit index of (n, channel group 0, pixel) in Y, or -1
-  const int PQ = p.P * Q, tpi = TR * Q;
+  int yil[NJ], yoff[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int t = wp * (32 * NJ) + 32 * j + l31;
     const int il = t / tpi, rem = t - il * tpi;
     const int pl = rem / Q, ql = rem - pl * Q;
     bbase[j] = (unsigned)((half * plane + il * blk + pl * CB + ql) * 16);
-    ypix[j] = il < nimg ? (long)(n0 + il) * (p.M >> 3) * PQ + (p0 + pl) * Q + ql : -1;
+    yil[j] = il;
+    yoff[j] = pl * Q + ql;
   }
   const unsigned a_base = (unsigned)(C8S2F_BPIECES * 1024 + (half * 128 + wm * 64 + l31) * 16);
 
-  f32x16 acc[2][NJ];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+  int lin = blockIdx.x, stage = 0;
+  {
+    int m_, t_;
+    if (!decode(lin, m_, t_)) return;
+    setup(m_, t_);
+  }
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  for (int ch = 0; ch < nch; ++ch) {
-    const int stage = ch & 1;
-#ifndef C8S2_ABL_NODMA                   // ablation builds: tools/build_abl_c8.sh
-    if (ch + 1 < nch) issue(ch + 1, stage ^ 1);
-#endif
-    const unsigned char *S = s2_lds + stage * C8S2F_STAGE;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int r = t / 3, s = t % 3;
-      const int toff = ((r == 0 ? 0 : (r == 1 ? TR + 1 : 1)) * CB + (s == 0 ? 0 : (s == 1 ? Q + 1 : 1))) * 16;
-      bf16x8 af[2], bf[NJ];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(S + a_base + (t * 256 + i * 32) * 16);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8 *>(S + bbase[j] + toff);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
 
-#ifdef C8S2_ABL_NOEPI
-  {
-    float t = 0.f;
+  while (true) {
+    // the current tile's output addressing (the DMA set-up moves on to the next tile during the last chunk)
+    const int mt_c = mt, ptile_c = ptile;
+    long ypix[NJ];                                               // unit index of (n, channel group 0, pixel) in Y, or -1
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) ypix[j] = yil[j] < nimg ? (long)(n0 + yil[j]) * (p.M >> 3) * PQ + p0 * Q + yoff[j] : -1;
+    int mt_n, ptile_n;
+    const bool more = decode(lin + G, mt_n, ptile_n);
+
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-    if (t == 1.2345e30f) p.Y[0] = 1;
-    return;
-  }
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int ch = 0; ch < nch; ++ch) {
+#ifndef C8S2_ABL_NODMA                   // ablation builds: tools/build_abl_c8.sh
+      if (ch + 1 < nch) {
+        issue(ch + 1, stage ^ 1);
+      } else if (more) {
+        setup(mt_n, ptile_n);
+        issue(0, stage ^ 1);
+      }
 #endif
-  // epilogue: acc[i][j][r] = channel mt*128 + wm*64 + i*32 + (r&3) + 8 (r>>2) + 4 half of pixel j; a register quad = 8 bytes
-  typedef unsigned long long u64;
-  const bool masked = p.ActY != nullptr;                        // uniform
-  u64 ay[2][4][NJ];                                              // the mask operand's pieces, all fetched before the first store
-  if (masked) {
+      const unsigned char *S = s2_lds + stage * C8S2F_STAGE;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int r = t / 3, s = t % 3;
+        const int toff = ((r == 0 ? 0 : (r == 1 ? TR + 1 : 1)) * CB + (s == 0 ? 0 : (s == 1 ? Q + 1 : 1))) * 16;
+        bf16x8 af[2], bf[NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(S + a_base + (t * 256 + i * 32) * 16);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8 *>(S + bbase[j] + toff);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stage ^= 1;
+    }
+    // here: `stage` holds the next tile's first chunk (if any); stage ^ 1 is dead until the next tile's second chunk is requested
+
+#ifdef C8S2_ABL_NOEPI
+    {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+      if (t == 1.2345e30f) p.Y[0] = 1;
+      if (!more) return;
+      lin += G;
+      continue;
+    }
+#endif
+    // epilogue: acc[i][j][r] = channel mt*128 + wm*64 + i*32 + (r&3) + 8 (r>>2) + 4 half of pixel j; a register quad = 8 bytes
+    u64 ay[2][4][NJ];                                              // the mask operand's pieces, all fetched before the first store
+    if (masked) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int m4 = mt_c * 128 + wm * 64 + i * 32 + 8 * rq + 4 * half;
+            ay[i][rq][j] =
+                ypix[j] >= 0 ? reinterpret_cast<const u64 *>(p.ActY)[((ypix[j] + (long)(m4 >> 3) * PQ) << 1) + half] : 0ull;
+          }
+    }
+    float sdb[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) sdb[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq)
+      for (int rq = 0; rq < 4; ++rq) {
+        const int m4 = mt_c * 128 + wm * 64 + i * 32 + 8 * rq + 4 * half;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b4 = *reinterpret_cast<const f32x4 *>(p.bias + m4);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int m4 = mt * 128 + wm * 64 + i * 32 + 8 * rq + 4 * half;
-          ay[i][rq][j] = ypix[j] >= 0 ? reinterpret_cast<const u64 *>(p.ActY)[((ypix[j] + (long)(m4 >> 3) * PQ) << 1) + half] : 0ull;
-        }
-  }
-  float sdb[32];
+          if (ypix[j] < 0) continue;
+          bf16x4 v;
 #pragma unroll
-  for (int e = 0; e < 32; ++e) sdb[e] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const int m4 = mt * 128 + wm * 64 + i * 32 + 8 * rq + 4 * half;
-      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) b4 = *reinterpret_cast<const f32x4 *>(p.bias + m4);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        if (ypix[j] < 0) continue;
-        bf16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x = acc[i][j][rq * 4 + e] + b4[e];
-          x = fmaxf(x, x * p.lrelu);
-          if (masked) {
-            const bf16x4 a = __builtin_bit_cast(bf16x4, ay[i][rq][j]);
-            x = c8_sel_nonpos((float)a[e], x * p.act_slope, x);
+          for (int e = 0; e < 4; ++e) {
+            float x = acc[i][j][rq * 4 + e] + b4[e];
+            x = fmaxf(x, x * p.lrelu);
+            if (masked) {
+              const bf16x4 a = __builtin_bit_cast(bf16x4, ay[i][rq][j]);
+              x = c8_sel_nonpos((float)a[e], x * p.act_slope, x);
+            }
+            v[e] = (__bf16)x;
+            if (masked) sdb[i * 16 + rq * 4 + e] += (float)v[e];
           }
-          v[e] = (__bf16)x;
-          if (masked) sdb[i * 16 + rq * 4 + e] += (float)v[e];
+          reinterpret_cast<u64 *>(p.Y)[((ypix[j] + (long)(m4 >> 3) * PQ) << 1) + half] = __builtin_bit_cast(u64, v);
         }
-        reinterpret_cast<u64 *>(p.Y)[((ypix[j] + (long)(m4 >> 3) * PQ) << 1) + half] = __builtin_bit_cast(u64, v);
       }
-    }
-  if (masked) {
-    // per-channel sums over the workgroup's pixels: butterfly over the 32 pixel lanes of a half, then over the 4 pixel waves
-    c8_reduce_scatter32<16>(sdb, l31);                           // lane (half, l31): slot l31 = i*16 + r of its half
-    float *red = reinterpret_cast<float *>(s2_lds);              // [wave 8][half 2][32]   (the stages are dead: last barrier passed)
-    red[(wave * 2 + half) * 32 + l31] = sdb[0];
-    __syncthreads();
-    if (tid < 128) {                                             // (wm, half, slot)
-      const int w_m = tid >> 6, hf = (tid >> 5) & 1, qs = tid & 31;
-      float t = 0.f;
+    if (masked) {
+      // per-channel sums over the workgroup's pixels: butterfly over the 32 pixel lanes of a half, then over the 4 pixel waves
+      c8_reduce_scatter32<16>(sdb, l31);                           // lane (half, l31): slot l31 = i*16 + r of its half
+      float *red = reinterpret_cast<float *>(s2_lds + (stage ^ 1) * C8S2F_STAGE);   // [wave 8][half 2][32] in the dead stage
+      red[(wave * 2 + half) * 32 + l31] = sdb[0];
+      __syncthreads();
+      if (tid < 128) {                                             // (wm, half, slot)
+        const int w_m = tid >> 6, hf = (tid >> 5) & 1, qs = tid & 31;
+        float t = 0.f;
 #pragma unroll
-      for (int w4 = 0; w4 < 4; ++w4) t += red[((w4 * 2 + w_m) * 2 + hf) * 32 + qs];
-      const int m = mt * 128 + w_m * 64 + (qs >> 4) * 32 + (qs & 3) + 8 * ((qs >> 2) & 3) + 4 * hf;
-      p.dbpart[(long)ptile * p.M + m] = t;
+        for (int w4 = 0; w4 < 4; ++w4) t += red[((w4 * 2 + w_m) * 2 + hf) * 32 + qs];
+        const int m = mt_c * 128 + w_m * 64 + (qs >> 4) * 32 + (qs & 3) + 8 * ((qs >> 2) & 3) + 4 * hf;
+        p.dbpart[(long)ptile_c * p.M + m] = t;
+      }
+      __syncthreads();                                             // before the next tile's DMA lands on `red`
     }
+    if (!more) return;
+    lin += G;
   }
 }
 
@@ -576,23 +628,19 @@ __global__ __launch_bounds__(512, 1) void c8s2_wgrad_kernel(C8S2WParams p) {
       p0 = 0;
     }
     const int nimg = min(TIW, p.N - n);
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short *>(p.S) + (long)n * (s_img >> 1), 0, nimg * s_img, 0x00020000);
-    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short *>(p.B) + (long)n * (b_img >> 1), 0, nimg * b_img, 0x00020000);
-    unsigned char *base = s2_lds + stage * C8S2W_STAGE;
+    // requests issued from inline asm (c8conv.h, c8_dma16_asm): hipcc would wait for them in front of the next transposing read
+    const c8_i32x4 srs = c8_rsrc_words(p.S + (long)n * (s_img >> 1), (unsigned)(nimg * s_img));
+    const c8_i32x4 brs = c8_rsrc_words(p.B + (long)n * (b_img >> 1), (unsigned)(nimg * b_img));
+    const unsigned base = c8_lds_addr(s2_lds) + stage * C8S2W_STAGE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (c8_lds_ptr)(base + (wave + 8 * i) * C8S2W_SPLANE), 16, voffs[i] + p0 * Q * 16, 0, 0,
-                                               0);
+    for (int i = 0; i < 2; ++i) c8_dma16_asm(srs, base + (wave + 8 * i) * C8S2W_SPLANE, (unsigned)(voffs[i] + p0 * Q * 16), 0);
     const int delta = (2 * p0 - 1) * p.W * 16;                  // first staged row is 2 p0 - 1 (out of the image for p0 = 0)
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int piece = wave + 8 * i;
       if (piece < bpieces) {
         const bool dead = voffb[i] < 0 || (p0 == 0 && ((topm >> i) & 1u));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (c8_lds_ptr)(base + C8S2W_SBYTES + piece * 1024), 16,
-                                                 dead ? (int)C8S2_OOB : voffb[i] + delta, 0, 0, 0);
+        c8_dma16_asm(brs, base + C8S2W_SBYTES + piece * 1024, dead ? C8S2_OOB : (unsigned)(voffb[i] + delta), 0);
       }
     }
   };

@@ -88,24 +88,20 @@ __global__ __launch_bounds__(512, 1) void c8_wgrad_kernel(C8WgradParams p) {
     }
   }
   auto issue = [&](int n, int rc, int stage, int i0 = 0, int i1 = 8) {      // image n, chunk rc (rows 4 rc ..) -> LDS stage; pieces i0 .. i1-1
-    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short *>(p.DY) + (long)n * (dy_img >> 1), 0, dy_img, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short *>(p.X) + (long)n * (x_img >> 1), 0, x_img, 0x00020000);
+    const c8_i32x4 drs = c8_rsrc_words(p.DY + (long)n * (dy_img >> 1), dy_img);
+    const c8_i32x4 xrs = c8_rsrc_words(p.X + (long)n * (x_img >> 1), x_img);
     const int row_off = rc * (CW8_ROWS * 512);
+    const unsigned sbase = c8_lds_addr(c8w_lds) + stage * CW8_STAGE;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (i < i0 || i >= i1) continue;
       const int piece = wave + 8 * i;
       if (piece < 32) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            drs, (c8_lds_ptr)(c8w_lds + stage * CW8_STAGE + (piece >> 1) * CW8_DY_PLANE + (piece & 1) * 1024), 16,
-            voff[i] + row_off, 0, 0, 0);
+        c8_dma16_asm(drs, sbase + (piece >> 1) * CW8_DY_PLANE + (piece & 1) * 1024, voff[i] + row_off, 0);
       } else if (piece < CW8_PIECES) {
         const bool dead = ((topbot[i] & 1u) && rc == 0) || ((topbot[i] & 2u) && rc == 32 / CW8_ROWS - 1);
         const int vo = dead ? (int)0x80000000 : voff[i] + row_off;     // halo columns stay out of range: 0x80000000 + small
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (c8_lds_ptr)(c8w_lds + stage * CW8_STAGE + CW8_DY_BYTES + (piece - 32) * 1024),
-                                                 16, vo, 0, 0, 0);
+        c8_dma16_asm(xrs, sbase + CW8_DY_BYTES + (piece - 32) * 1024, vo, 0);
       }
     }
   };
