@@ -306,8 +306,15 @@ static int c8s2_run_tr(const void *small, const float *w, long sm, long sc, cons
       return LSPS_E_ARG;
     }
   }
-  if (int rc = lds_optin(reinterpret_cast<const void *>(c8s2_tr_kernel), C8S2T_LDS_BYTES, "c8s2_tr")) return rc;
-  hipLaunchKernelGGL(c8s2_tr_kernel, dim3((p.ntiles + 7) / 8 * 8 * (M >> 6)), dim3(512), C8S2T_LDS_BYTES, st, p);
+  // persistent workgroups, one per CU
+  const dim3 grid(std::min((p.ntiles + 7) / 8 * 8 * (M >> 6), c8_device_cus() / 8 * 8));
+  if (act_y) {
+    if (int rc = lds_optin(reinterpret_cast<const void *>(c8s2_tr_kernel<true>), C8S2T_LDS_BYTES, "c8s2_tr")) return rc;
+    hipLaunchKernelGGL(c8s2_tr_kernel<true>, grid, dim3(512), C8S2T_LDS_BYTES, st, p);
+  } else {
+    if (int rc = lds_optin(reinterpret_cast<const void *>(c8s2_tr_kernel<false>), C8S2T_LDS_BYTES, "c8s2_tr")) return rc;
+    hipLaunchKernelGGL(c8s2_tr_kernel<false>, grid, dim3(512), C8S2T_LDS_BYTES, st, p);
+  }
   LSPS_CHECK_LAUNCH("c8s2_tr");
   if (act_y && db_prev) return c8_colsum(p.dbpart, db_prev, M, p.ntiles, p.dbpart + (size_t)p.ntiles * M, st);
   return 0;

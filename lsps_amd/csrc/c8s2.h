@@ -282,9 +282,9 @@ __global__ __launch_bounds__(512, 1) void c8s2_fwd_kernel(C8S2Params p) {
         const int m4 = mt_c * 128 + wm * 64 + i * 32 + 8 * rq + 4 * half;
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) b4 = *reinterpret_cast<const f32x4 *>(p.bias + m4);
+        u64 pk[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          if (ypix[j] < 0) continue;
           bf16x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -295,9 +295,27 @@ __global__ __launch_bounds__(512, 1) void c8s2_fwd_kernel(C8S2Params p) {
               x = c8_sel_nonpos((float)a[e], x * p.act_slope, x);
             }
             v[e] = (__bf16)x;
-            if (masked) sdb[i * 16 + rq * 4 + e] += (float)v[e];
+            if (masked && ypix[j] >= 0) sdb[i * 16 + rq * 4 + e] += (float)v[e];
           }
-          reinterpret_cast<u64 *>(p.Y)[((ypix[j] + (long)(m4 >> 3) * PQ) << 1) + half] = __builtin_bit_cast(u64, v);
+          pk[j] = __builtin_bit_cast(u64, v);
+        }
+        if (NJ == 2) {
+          // the two half-waves hold channels 4 half .. of BOTH pixels: exchange (v_permlane32_swap) so that lanes 0-31 store the
+          // whole 16-byte unit of pixel j = 0 and lanes 32-63 that of j = 1: 8 store instructions of 16 B instead of 16 of 8 B
+          typedef unsigned s2_u32x2 __attribute__((ext_vector_type(2)));
+          s2_u32x2 A = __builtin_bit_cast(s2_u32x2, pk[0]), B = __builtin_bit_cast(s2_u32x2, pk[NJ - 1]);
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(A[d], B[d], false, false);
+            A[d] = sw[0];
+            B[d] = sw[1];
+          }
+          const long yp = half ? ypix[NJ - 1] : ypix[0];
+          if (yp >= 0) reinterpret_cast<u32x4 *>(p.Y)[yp + (long)(m4 >> 3) * PQ] = u32x4{A[0], A[1], B[0], B[1]};
+        } else {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            if (ypix[j] >= 0) reinterpret_cast<u64 *>(p.Y)[((ypix[j] + (long)(m4 >> 3) * PQ) << 1) + half] = pk[j];
         }
       }
     if (masked) {
@@ -335,51 +353,64 @@ __global__ __launch_bounds__(512, 1) void c8s2_fwd_kernel(C8S2Params p) {
 #define C8S2T_STAGE ((C8S2T_BPIECES + C8S2T_APIECES) * 1024)
 #define C8S2T_LDS_BYTES (2 * C8S2T_STAGE)                   // 147456
 
+template <bool MASKED>
 __global__ __launch_bounds__(512, 1) void c8s2_tr_kernel(C8S2Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s2_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int wm = wave & 1, wp = wave >> 1;
+  typedef unsigned long long u64;
 
-  const int MT = p.M >> 6, lin = blockIdx.x, xcd = lin & 7, qq = lin >> 3;
-  const int mt = qq % MT, ptile = xcd + 8 * (qq / MT);
-  if (ptile >= p.ntiles) return;
+  // persistent workgroups, as c8s2_fwd_kernel: tiles lin = blockIdx.x, + grid, ...; the next tile's first chunk is requested
+  // during the last chunk of the current one and the epilogue's stores drain under the next tile's MFMAs
+  const int MT = p.M >> 6, G = gridDim.x, nlin = ((p.ntiles + 7) >> 3) * 8 * MT;
   const int TI = p.TI, TR = p.TR, Q = p.Q;
   const int CB = Q + 1, blk = (TR + 1) * CB, plane = TI * blk, bunits = 2 * C8S2T_KS * plane;   // 2 KS k-half planes
-  int n0, p0;
-  if (TI == 1) {
-    n0 = ptile / p.tiles_per_img;
-    p0 = (ptile - n0 * p.tiles_per_img) * TR;
-  } else {
-    n0 = ptile * TI;
-    p0 = 0;
-  }
-  const int nimg = min(TI, p.N - n0);
   const int PQ16 = p.P * Q * 16, img_bytes = (p.Cx >> 3) * PQ16, nch = p.Cx / (16 * C8S2T_KS);
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned short *>(p.X) + (long)n0 * (img_bytes >> 1), 0, nimg * img_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned short *>(p.Wq) + (long)mt * (p.Cx >> 4) * C8S2T_ACHUNK16, 0, (p.Cx >> 4) * C8S2T_ACHUNK16 * 2, 0x00020000);
+  constexpr bool masked = MASKED;                               // p.ActY != nullptr
 
+  int mt, ptile, n0, p0, nimg;                                  // the tile whose DMA set-up is current
+  __amdgpu_buffer_rsrc_t xrs, wrs;
   constexpr int NB = (C8S2T_BPIECES + 7) / 8, NA = (C8S2T_APIECES + 7) / 8;
-  unsigned voffb[NB], voffa[NA];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int u = (wave + 8 * i) * 64 + lane;
-    unsigned v = C8S2_OOB;
-    if (u < bunits) {
-      const int kh = u / plane, rem = u - kh * plane;
-      const int img = rem / blk, rem2 = rem - img * blk;
-      const int ri = rem2 / CB, ci = rem2 - ri * CB;
-      const int row = p0 + ri;
-      if (row < p.P && ci < Q && img < nimg) v = (unsigned)(img * img_bytes + kh * PQ16 + (row * Q + ci) * 16);
-    }
-    voffb[i] = v;
-  }
-#pragma unroll
-  for (int i = 0; i < NA; ++i) voffa[i] = (unsigned)(((wave + 8 * i) * 64 + lane) * 16);
+  unsigned voffb[NB];                                           // recomputed per tile (registers are scarce here: 128 accumulators)
+  const unsigned voffa = (unsigned)((wave * 64 + lane) * 16);   // weight piece wave + 8 i: + i * 8192 through the scalar offset
   const int bpieces = (bunits + 63) >> 6;
+
+  auto decode = [&](int lin, int &mt_, int &ptile_) {
+    const int xcd = lin & 7, qq = lin >> 3;
+    mt_ = qq % MT;
+    ptile_ = xcd + 8 * (qq / MT);
+    return lin < nlin && ptile_ < p.ntiles;
+  };
+  auto setup = [&](int mt_, int ptile_) {
+    mt = mt_; ptile = ptile_;
+    if (TI == 1) {
+      n0 = ptile / p.tiles_per_img;
+      p0 = (ptile - n0 * p.tiles_per_img) * TR;
+    } else {
+      n0 = ptile * TI;
+      p0 = 0;
+    }
+    nimg = min(TI, p.N - n0);
+    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.X) + (long)n0 * (img_bytes >> 1), 0, nimg * img_bytes,
+                                            0x00020000);
+    wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.Wq) + (long)mt * (p.Cx >> 4) * C8S2T_ACHUNK16, 0,
+                                            (p.Cx >> 4) * C8S2T_ACHUNK16 * 2, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int u = (wave + 8 * i) * 64 + lane;
+      unsigned v = C8S2_OOB;
+      if (u < bunits) {
+        const int kh = u / plane, rem = u - kh * plane;
+        const int img = rem / blk, rem2 = rem - img * blk;
+        const int ri = rem2 / CB, ci = rem2 - ri * CB;
+        const int row = p0 + ri;
+        if (row < p.P && ci < Q && img < nimg) v = (unsigned)(img * img_bytes + kh * PQ16 + (row * Q + ci) * 16);
+      }
+      voffb[i] = v;
+    }
+  };
   auto issue = [&](int ch, int stage) {
     unsigned char *base = s2_lds + stage * C8S2T_STAGE;
 #pragma unroll
@@ -393,13 +424,13 @@ __global__ __launch_bounds__(512, 1) void c8s2_tr_kernel(C8S2Params p) {
     for (int i = 0; i < NA; ++i) {
       const int piece = wave + 8 * i;
       if (piece < C8S2T_APIECES)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (c8_lds_ptr)(base + (C8S2T_BPIECES + piece) * 1024), 16, voffa[i],
-                                                 ch * (C8S2T_KS * C8S2T_ACHUNK16 * 2), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (c8_lds_ptr)(base + (C8S2T_BPIECES + piece) * 1024), 16, voffa,
+                                                 ch * (C8S2T_KS * C8S2T_ACHUNK16 * 2) + i * 8192, 0, 0);
     }
   };
 
   unsigned bbase[2];
-  long ypix[2];                                                // unit index of (n, channel group 0, row 2p, column 2q) in Y, or -1
+  int ygeo[2];                                                  // image << 20 | row << 10 | column of this lane's two tile pixels
   const int tpi = TR * Q;
   const long HWl = (long)p.H * p.W;
 #pragma unroll
@@ -408,142 +439,171 @@ __global__ __launch_bounds__(512, 1) void c8s2_tr_kernel(C8S2Params p) {
     const int il = t / tpi, rem = t - il * tpi;
     const int pl = rem / Q, ql = rem - pl * Q;
     bbase[j] = (unsigned)((half * plane + il * blk + pl * CB + ql) * 16);
-    ypix[j] = il < nimg ? (long)(n0 + il) * (p.M >> 3) * HWl + (long)(2 * (p0 + pl)) * p.W + 2 * ql : -1;
+    ygeo[j] = il << 20 | pl << 10 | ql;
   }
   const unsigned a_base = (unsigned)(C8S2T_BPIECES * 1024 + (half * 64 + wm * 32 + l31) * 16);
 
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
-
+  int lin = blockIdx.x, stage = 0;
+  {
+    int m_, t_;
+    if (!decode(lin, m_, t_)) return;
+    setup(m_, t_);
+  }
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  for (int ch = 0; ch < nch; ++ch) {
-    const int stage = ch & 1;
-#ifndef C8S2_ABL_NODMA
-    if (ch + 1 < nch) issue(ch + 1, stage ^ 1);
-#endif
-    const unsigned char *S = s2_lds + stage * C8S2T_STAGE;
-#pragma unroll
-    for (int ks = 0; ks < C8S2T_KS; ++ks) {
-      bf16x8 bf[4][2];
-#pragma unroll
-      for (int sh = 0; sh < 4; ++sh)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          bf[sh][j] = *reinterpret_cast<const bf16x8 *>(S + bbase[j] + (ks * 2 * plane + (sh >> 1) * CB + (sh & 1)) * 16);
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int r = t / 3, s = t % 3;
-        const int cls = (r != 1 ? 2 : 0) + (s != 1 ? 1 : 0), sh = (r == 0 ? 2 : 0) + (s == 0 ? 1 : 0);
-        const bf16x8 af = *reinterpret_cast<const bf16x8 *>(S + a_base + (ks * 1152 + t * 128) * 16);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[cls][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[sh][j], acc[cls][j], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
 
-#ifdef C8S2_ABL_NOEPI
-  {
-    float t = 0.f;
+  while (true) {
+    const int mt_c = mt, ptile_c = ptile;
+    long ypix[2];                                                // unit index of (n, channel group 0, row 2p, column 2q) in Y, or -1
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int il = ygeo[j] >> 20, pl = (ygeo[j] >> 10) & 1023, ql = ygeo[j] & 1023;
+      ypix[j] = il < nimg ? (long)(n0 + il) * (p.M >> 3) * HWl + (long)(2 * (p0 + pl)) * p.W + 2 * ql : -1;
+    }
+    int mt_n, ptile_n;
+    const bool more = decode(lin + G, mt_n, ptile_n);
+
+    f32x16 acc[4][2];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[c][j][r];
-    if (t == 1.2345e30f) p.Y[0] = 1;
-    return;
-  }
+        for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
+
+    for (int ch = 0; ch < nch; ++ch) {
+#ifndef C8S2_ABL_NODMA
+      if (ch + 1 < nch) {
+        issue(ch + 1, stage ^ 1);
+      } else if (more) {
+        setup(mt_n, ptile_n);
+        issue(0, stage ^ 1);
+      }
 #endif
-  // epilogue.  acc[cls][j][r]: channel mt*64 + wm*32 + (r&3) + 8 (r>>2) + 4 half at output (2p + a, 2q + b).  The two column
-  // classes of a row are exchanged across the half-waves (v_permlane32_swap: cdna_hip_programming.md T21) so that lanes 0-31
-  // store the whole 16-byte unit of column 2q and lanes 32-63 that of column 2q + 1: 1 KB contiguous per wave instruction.
-  typedef unsigned long long u64;
-  const bool masked = p.ActY != nullptr;                        // uniform
-  u64 ay[4][2][2][2];                                            // [rq][a][j][b]: the mask operand's pieces, fetched before the first store
-  if (masked) {
+      const unsigned char *S = s2_lds + stage * C8S2T_STAGE;
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq)
+      for (int ks = 0; ks < C8S2T_KS; ++ks) {
+        bf16x8 bf[4][2];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+        for (int sh = 0; sh < 4; ++sh)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            bf[sh][j] = *reinterpret_cast<const bf16x8 *>(S + bbase[j] + (ks * 2 * plane + (sh >> 1) * CB + (sh & 1)) * 16);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int r = t / 3, s = t % 3;
+          const int cls = (r != 1 ? 2 : 0) + (s != 1 ? 1 : 0), sh = (r == 0 ? 2 : 0) + (s == 0 ? 1 : 0);
+          const bf16x8 af = *reinterpret_cast<const bf16x8 *>(S + a_base + (ks * 1152 + t * 128) * 16);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[cls][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[sh][j], acc[cls][j], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stage ^= 1;
+    }
+    // here: `stage` holds the next tile's first chunk (if any); stage ^ 1 is dead until the next tile's second chunk is requested
+
+#ifdef C8S2_ABL_NOEPI
+    {
+      float t = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const int m8 = mt * 64 + wm * 32 + 8 * rq;
-            ay[rq][a][j][b] = ypix[j] >= 0
-                                  ? reinterpret_cast<const u64 *>(p.ActY)[((ypix[j] + (long)(m8 >> 3) * HWl + (long)a * p.W + b) << 1) + half]
-                                  : 0ull;
-          }
-  }
-  float sdb[32];
-#pragma unroll
-  for (int e = 0; e < 32; ++e) sdb[e] = 0.f;
-#pragma unroll
-  for (int rq = 0; rq < 4; ++rq) {
-    const int m8 = mt * 64 + wm * 32 + 8 * rq;                  // channel group's first channel
-    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) b4 = *reinterpret_cast<const f32x4 *>(p.bias + m8 + 4 * half);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        unsigned w[2][2];                                        // [b][dword]
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          bf16x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x = acc[a * 2 + b][j][rq * 4 + e] + b4[e];
-            x = fmaxf(x, x * p.lrelu);
-            if (masked) {
-              const bf16x4 m_ = __builtin_bit_cast(bf16x4, ay[rq][a][j][b]);
-              x = c8_sel_nonpos((float)m_[e], x * p.act_slope, x);
-            }
-            v[e] = (__bf16)x;
-            if (masked && ypix[j] >= 0) sdb[rq * 4 + e] += (float)v[e];
-          }
-          const uint2 u = __builtin_bit_cast(uint2, v);
-          w[b][0] = u.x;
-          w[b][1] = u.y;
-        }
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(w[0][d], w[1][d], false, false);
-          w[0][d] = sw[0];
-          w[1][d] = sw[1];
-        }
-        if (ypix[j] < 0) continue;
-        const long unit = ypix[j] + (long)(m8 >> 3) * HWl + (long)a * p.W + half;
-        u32x4 o = {w[0][0], w[0][1], w[1][0], w[1][1]};
-        reinterpret_cast<u32x4 *>(p.Y)[unit] = o;
-      }
-  }
-  if (masked) {
-    // 16 channel slots per lane: add the two 16-lane halves of the 32 pixel lanes, butterfly over the remaining four bits,
-    // then sum the 4 pixel waves through LDS
-#pragma unroll
-    for (int e = 0; e < 16; ++e) sdb[e] += __shfl_xor(sdb[e], 16, 64);
-    c8_reduce_scatter32<8>(sdb, l31);                            // lane: slot (l31 & 15) = r of its half
-    float *red = reinterpret_cast<float *>(s2_lds);              // [wave 8][half 2][16]
-    if ((l31 & 16) == 0) red[(wave * 2 + half) * 16 + l31] = sdb[0];
-    __syncthreads();
-    if (tid < 64) {                                              // (wm, half, slot)
-      const int w_m = tid >> 5, hf = (tid >> 4) & 1, qs = tid & 15;
-      float t = 0.f;
-#pragma unroll
-      for (int w4 = 0; w4 < 4; ++w4) t += red[((w4 * 2 + w_m) * 2 + hf) * 16 + qs];
-      const int m = mt * 64 + w_m * 32 + (qs & 3) + 8 * (qs >> 2) + 4 * hf;
-      p.dbpart[(long)ptile * p.M + m] = t;
+          for (int r = 0; r < 16; ++r) t += acc[c][j][r];
+      if (t == 1.2345e30f) p.Y[0] = 1;
+      if (!more) return;
+      lin += G;
+      continue;
     }
+#endif
+    // epilogue.  acc[cls][j][r]: channel mt*64 + wm*32 + (r&3) + 8 (r>>2) + 4 half at output (2p + a, 2q + b).  The two column
+    // classes of a row are exchanged across the half-waves (v_permlane32_swap: cdna_hip_programming.md T21) so that lanes 0-31
+    // store the whole 16-byte unit of column 2q and lanes 32-63 that of column 2q + 1: 1 KB contiguous per wave instruction.
+    u64 ay[4][2][2][2];                                            // [rq][a][j][b]: the mask operand's pieces, fetched before the first store
+    if (masked) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const int m8 = mt_c * 64 + wm * 32 + 8 * rq;
+              ay[rq][a][j][b] =
+                  ypix[j] >= 0
+                      ? reinterpret_cast<const u64 *>(p.ActY)[((ypix[j] + (long)(m8 >> 3) * HWl + (long)a * p.W + b) << 1) + half]
+                      : 0ull;
+            }
+    }
+    float sdb[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) sdb[e] = 0.f;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int m8 = mt_c * 64 + wm * 32 + 8 * rq;                // channel group's first channel
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) b4 = *reinterpret_cast<const f32x4 *>(p.bias + m8 + 4 * half);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned w[2][2];                                        // [b][dword]
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = acc[a * 2 + b][j][rq * 4 + e] + b4[e];
+              x = fmaxf(x, x * p.lrelu);
+              if (masked) {
+                const bf16x4 m_ = __builtin_bit_cast(bf16x4, ay[rq][a][j][b]);
+                x = c8_sel_nonpos((float)m_[e], x * p.act_slope, x);
+              }
+              v[e] = (__bf16)x;
+              if (masked && ypix[j] >= 0) sdb[rq * 4 + e] += (float)v[e];
+            }
+            const uint2 u = __builtin_bit_cast(uint2, v);
+            w[b][0] = u.x;
+            w[b][1] = u.y;
+          }
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(w[0][d], w[1][d], false, false);
+            w[0][d] = sw[0];
+            w[1][d] = sw[1];
+          }
+          if (ypix[j] < 0) continue;
+          const long unit = ypix[j] + (long)(m8 >> 3) * HWl + (long)a * p.W + half;
+          u32x4 o = {w[0][0], w[0][1], w[1][0], w[1][1]};
+          reinterpret_cast<u32x4 *>(p.Y)[unit] = o;
+        }
+    }
+    if (masked) {
+      // 16 channel slots per lane: add the two 16-lane halves of the 32 pixel lanes, butterfly over the remaining four bits,
+      // then sum the 4 pixel waves through LDS
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sdb[e] += __shfl_xor(sdb[e], 16, 64);
+      c8_reduce_scatter32<8>(sdb, l31);                            // lane: slot (l31 & 15) = r of its half
+      float *red = reinterpret_cast<float *>(s2_lds + (stage ^ 1) * C8S2T_STAGE);   // [wave 8][half 2][16] in the dead stage
+      if ((l31 & 16) == 0) red[(wave * 2 + half) * 16 + l31] = sdb[0];
+      __syncthreads();
+      if (tid < 64) {                                              // (wm, half, slot)
+        const int w_m = tid >> 5, hf = (tid >> 4) & 1, qs = tid & 15;
+        float t = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) t += red[((w4 * 2 + w_m) * 2 + hf) * 16 + qs];
+        const int m = mt_c * 64 + w_m * 32 + (qs & 3) + 8 * (qs >> 2) + 4 * hf;
+        p.dbpart[(long)ptile_c * p.M + m] = t;
+      }
+      __syncthreads();                                             // before the next tile's DMA lands on `red`
+    }
+    if (!more) return;
+    lin += G;
   }
 }
 
