@@ -686,7 +686,7 @@ int lsps_c8_pw1_wgrad(const void *x, const float *dpre, float *dw, float *db, in
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(c8_pw1_wgrad_kernel, dim3(C >> 3, splits), dim3(256), 0, st, (const unsigned short *)x, dpre, (float *)ws, N, C, HW, ips);
   LSPS_CHECK_LAUNCH("c8_pw1_wgrad");
-  hipLaunchKernelGGL(c8_pw1_wgrad_reduce_kernel, dim3(ceil_div(C + 1, 256)), dim3(256), 0, st, (const float *)ws, dw, db, C, splits);
+  hipLaunchKernelGGL(c8_pw1_wgrad_reduce_kernel, dim3(C + 1), dim3(256), 0, st, (const float *)ws, dw, db, C, splits);
   LSPS_CHECK_LAUNCH("c8_pw1_wgrad_reduce");
   return 0;
 }
@@ -707,8 +707,9 @@ int lsps_c8_convT3x3s2_dgrad_act(const void *dy, const float *w, const void *act
                       act_slope, db_prev);
 }
 
-// [N][C] partials of the previous layer's bias gradient + [64][C] scratch + [N][C + 1] partials of the head's own gradients
-size_t lsps_c8_pw1_dgrad_act_workspace_bytes(int N, int C) { return align_up(((size_t)2 * N + 64) * (C + 1) * sizeof(float), 256); }
+// [rows][C] partials of the previous layer's bias gradient + [64][C] scratch + [rows][C + 1] partials of the head's own gradients
+// (rows = N x up to 8 pixel segments per image)
+size_t lsps_c8_pw1_dgrad_act_workspace_bytes(int N, int C) { return align_up(((size_t)16 * N + 64) * (C + 1) * sizeof(float), 256); }
 
 int lsps_c8_pw1_dgrad_act(const float *dpre, const float *w, const void *act_y, float act_slope, void *dx, float *db_prev, float *dw,
                           float *db, int N, int C, int HW, void *ws, size_t ws_bytes, void *stream) {
@@ -717,14 +718,18 @@ int lsps_c8_pw1_dgrad_act(const float *dpre, const float *w, const void *act_y, 
                  "c8_pw1_dgrad_act: bad arguments (C %% 8 == 0, C <= 64)");
   LSPS_CHECK_ARG(ws && ws_bytes >= lsps_c8_pw1_dgrad_act_workspace_bytes(N, C) - 256, "c8_pw1_dgrad_act: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  float *part = (float *)ws, *scratch = part + (size_t)N * C, *wpart = dw ? scratch + (size_t)64 * (C + 1) : nullptr;
-  hipLaunchKernelGGL(c8_pw1_dgrad_act_kernel, dim3(N), dim3(256), 0, st, dpre, w, (const unsigned short *)act_y, (unsigned short *)dx,
-                     part, wpart, C, HW, act_slope);
+  // pixel segments per image: >= ~4096 workgroups on the chip, >= 512 pixels each
+  int S = 1;
+  while (S < 8 && (long)N * S < 4096 && HW / (2 * S) >= 512) S *= 2;
+  const int rows = N * S;
+  float *part = (float *)ws, *scratch = part + (size_t)rows * C, *wpart = dw ? scratch + (size_t)64 * (C + 1) : nullptr;
+  hipLaunchKernelGGL(c8_pw1_dgrad_act_kernel, dim3(rows), dim3(256), 0, st, dpre, w, (const unsigned short *)act_y, (unsigned short *)dx,
+                     part, wpart, C, HW, S, act_slope);
   LSPS_CHECK_LAUNCH("c8_pw1_dgrad_act");
   if (db_prev)
-    if (int rc = c8_colsum(part, db_prev, C, N, scratch, st)) return rc;
+    if (int rc = c8_colsum(part, db_prev, C, rows, scratch, st)) return rc;
   if (dw) {                                                     // the head's own weight gradient [C] (+ bias gradient [1]) from the same pass
-    hipLaunchKernelGGL(c8_pw1_wgrad_reduce_kernel, dim3(ceil_div(C + 1, 256)), dim3(256), 0, st, (const float *)wpart, dw, db, C, N);
+    hipLaunchKernelGGL(c8_pw1_wgrad_reduce_kernel, dim3(C + 1), dim3(256), 0, st, (const float *)wpart, dw, db, C, rows);
     LSPS_CHECK_LAUNCH("c8_pw1_wgrad_reduce");
   }
   return 0;

@@ -41,61 +41,74 @@ __global__ __launch_bounds__(256) void c8_pw1_dgrad_kernel(const float *__restri
 }
 
 // dx[n][c][pix] = w[c] * dpre[n][pix] * (y[n][c][pix] > 0 ? 1 : slope): the head's input gradient with the LeakyReLU backward of
-// the layer in front of it (whose saved output is y) fused, and that layer's bias gradient as per-image partial sums
-// part[n][c] (C <= 64).  One workgroup per image.
-// wpart (nullable): per-image partial sums of the head's OWN weight gradient, wpart[n][c] = sum_pix y[n][c][pix] * dpre[n][pix]
-// (y is the head's input), and wpart[n][C] = sum_pix dpre (its bias gradient): the same two operands stream through here
+// the layer in front of it (whose saved output is y) fused, and that layer's bias gradient as partial sums part[row][c]
+// (C <= 64).  Workgroup = one of S pixel segments of an image (row = n * S + segment); a 32-lane group owns ONE channel group
+// (16 accumulators per lane instead of 128: eight waves per SIMD keep the two 1 GB streams in flight), 32 consecutive pixels
+// per step = 512 contiguous bytes, four steps of loads in flight.
+// wpart (nullable): partial sums of the head's OWN weight gradient, wpart[row][c] = sum_pix y[n][c][pix] * dpre[n][pix]
+// (y is the head's input), and wpart[row][C] = sum_pix dpre (its bias gradient): the same two operands stream through here
 // anyway, so the separate c8_pw1_wgrad pass over y disappears.
 __global__ __launch_bounds__(256) void c8_pw1_dgrad_act_kernel(const float *__restrict__ dpre, const float *__restrict__ w,
                                                                const unsigned short *__restrict__ y, unsigned short *__restrict__ dx,
                                                                float *__restrict__ part, float *__restrict__ wpart, int C, int HW,
-                                                               float slope) {
-  __shared__ float red[4][64];
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = C >> 3;
-  const u32x4 *yp = reinterpret_cast<const u32x4 *>(y) + (long)n * G * HW;
-  u32x4 *xp = reinterpret_cast<u32x4 *>(dx) + (long)n * G * HW;
-  float s[64], sw[64], sd = 0.f;
+                                                               int S, float slope) {
+  const int row = blockIdx.x, n = row / S, seg = row - n * S, tid = threadIdx.x;
+  const int g = tid >> 5, lp = tid & 31, G = C >> 3;
+  if (g >= G) return;                                           // no barrier below
+  const int per = (HW + S - 1) / S, px0 = seg * per, px1 = min(HW, px0 + per);
+  const u32x4 *yp = reinterpret_cast<const u32x4 *>(y) + ((long)n * G + g) * HW;
+  u32x4 *xp = reinterpret_cast<u32x4 *>(dx) + ((long)n * G + g) * HW;
+  const float *dp = dpre + (long)n * HW;
+  float wg[8], s[8], sw[8], sd = 0.f;
 #pragma unroll
-  for (int e = 0; e < 64; ++e) s[e] = sw[e] = 0.f;
-  for (int px = tid; px < HW; px += 256) {
-    const float d = dpre[(long)n * HW + px];
-    sd += d;
+  for (int e = 0; e < 8; ++e) {
+    wg[e] = w[g * 8 + e];
+    s[e] = sw[e] = 0.f;
+  }
+  for (int px = px0 + lp; px < px1; px += 128) {
+    u32x4 yv[4];
+    float d[4];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (g >= G) break;
-      const bf16x8 yv = __builtin_bit_cast(bf16x8, yp[(long)g * HW + px]);
+    for (int u = 0; u < 4; ++u) {
+      const int q = px + 32 * u;
+      const bool in = q < px1;
+      yv[u] = in ? __builtin_nontemporal_load(yp + q) : u32x4{0u, 0u, 0u, 0u};
+      d[u] = in ? dp[q] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = px + 32 * u;
+      const bf16x8 a = __builtin_bit_cast(bf16x8, yv[u]);
       bf16x8 v;
+      sd += d[u];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float x = w[g * 8 + e] * d;
-        v[e] = (__bf16)c8_sel_nonpos((float)yv[e], x * slope, x);
-        s[g * 8 + e] += (float)v[e];
-        sw[g * 8 + e] = fmaf((float)yv[e], d, sw[g * 8 + e]);
+        const float x = wg[e] * d[u];
+        v[e] = (__bf16)c8_sel_nonpos((float)a[e], x * slope, x);
+        s[e] += (float)v[e];
+        sw[e] = fmaf((float)a[e], d[u], sw[e]);
       }
-      xp[(long)g * HW + px] = __builtin_bit_cast(u32x4, v);
+      if (q < px1) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), xp + q);
     }
   }
+  // sums over the 32 lanes of the group
 #pragma unroll
-  for (int e = 0; e < 64; ++e) {
-    const float t = wave_sum(s[e]);
-    if (lane == 0) red[wave][e] = t;
-  }
-  __syncthreads();
-  if (tid < C) part[(long)n * C + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-  if (wpart) {                                                  // uniform
-    __syncthreads();
+  for (int off = 16; off >= 1; off >>= 1) {
 #pragma unroll
-    for (int e = 0; e < 64; ++e) {
-      const float t = wave_sum(sw[e]);
-      if (lane == 0) red[wave][e] = t;
+    for (int e = 0; e < 8; ++e) {
+      s[e] += __shfl_xor(s[e], off, 64);
+      sw[e] += __shfl_xor(sw[e], off, 64);
     }
-    sd = wave_sum(sd);
-    __syncthreads();
-    if (tid < C) wpart[(long)n * (C + 1) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-    __syncthreads();
-    if (lane == 0) red[wave][0] = sd;
-    __syncthreads();
-    if (tid == 0) wpart[(long)n * (C + 1) + C] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    sd += __shfl_xor(sd, off, 64);
+  }
+  if (lp == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[(long)row * C + g * 8 + e] = s[e];
+    if (wpart) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wpart[(long)row * (C + 1) + g * 8 + e] = sw[e];
+      if (g == 0) wpart[(long)row * (C + 1) + C] = sd;
+    }
   }
 }
 
@@ -133,14 +146,20 @@ __global__ __launch_bounds__(256) void c8_pw1_wgrad_kernel(const unsigned short 
 // dW[c] = sum_s part[s][c] (c < C), db[0] = sum_s part[s][C]
 __global__ __launch_bounds__(256) void c8_pw1_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db,
                                                                   int C, int splits) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c > C) return;
+  __shared__ float red[4];
+  const int c = blockIdx.x, tid = threadIdx.x;                  // one workgroup per column (c == C: the bias gradient)
   float s = 0.f;
-  for (int i = 0; i < splits; ++i) s += part[(long)i * (C + 1) + c];
-  if (c < C)
-    dW[c] = s;
-  else if (db)
-    db[0] = s;
+  for (int i = tid; i < splits; i += 256) s += part[(long)i * (C + 1) + c];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    s = red[0] + red[1] + red[2] + red[3];
+    if (c < C)
+      dW[c] = s;
+    else if (db)
+      db[0] = s;
+  }
 }
 
 }  // namespace lsps

@@ -249,10 +249,10 @@ def test_c8_convT3x3s2_dgrad_with_fused_previous_activation(N, Ci, H, Co):
     assert _rel(db, got.double().cpu().sum((0, 2, 3))) <= 1e-5 * max(1.0, (N * H * H) ** 0.5 / 8)
 
 
-def test_c8_pw1_dgrad_with_fused_previous_activation():
+@pytest.mark.parametrize('N,C,H', [(70, 64, 32), (5, 64, 20), (3, 16, 128), (9, 40, 11)])
+def test_c8_pw1_dgrad_with_fused_previous_activation(N, C, H):
     _need_gpu()
     _lib, L, dev, st = _env()
-    N, C, H = 70, 64, 32
     g = torch.Generator().manual_seed(9)
     w = _rand(g, C, 1, 1, 1, scale=0.2)
     dpre = _rand(g, N, 1, H, H)
