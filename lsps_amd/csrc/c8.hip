@@ -339,7 +339,7 @@ static int c8s2_run_wgrad(const void *small, const void *big, float *dw, int N, 
   const int tiles = (K >> 7) * (C >> 6);
   hipLaunchKernelGGL(c8s2_wgrad_kernel, dim3((p.splits + 7) / 8 * 8 * tiles), dim3(512), C8S2W_LDS_BYTES, st, p);
   LSPS_CHECK_LAUNCH("c8s2_wgrad");
-  hipLaunchKernelGGL(c8_wgrad_reduce_kernel, dim3(ceil_div((long)K * C, 256)), dim3(256), 0, st, (const float *)p.part, dw, K * C, p.splits);
+  hipLaunchKernelGGL(c8_wgrad_reduce_kernel, dim3(ceil_div((long)K * C, 64)), dim3(256), 0, st, (const float *)p.part, dw, K * C, p.splits);
   LSPS_CHECK_LAUNCH("c8s2_wgrad_reduce");
   return 0;
 }
@@ -420,7 +420,7 @@ int c8_stem_wgrad_bf16(const float *x, const void *dy, const void *y, float *dw,
   p.slope = slope;
   hipLaunchKernelGGL(c8_stem_wgrad_kernel, dim3(blocks), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("c8_stem_wgrad");
-  hipLaunchKernelGGL(c8_stem_wgrad_reduce_kernel, dim3(16), dim3(256), 0, st, (const float *)p.part, dw, db, R, S, blocks);
+  hipLaunchKernelGGL(c8_stem_wgrad_reduce_kernel, dim3(64), dim3(256), 0, st, (const float *)p.part, dw, db, R, S, blocks);
   LSPS_CHECK_LAUNCH("c8_stem_wgrad_reduce");
   return 0;
 }
@@ -540,7 +540,7 @@ int lsps_c8_conv3x3_wgrad(const void *x, const void *dy, float *dw, int N, int C
   const int tiles = (K >> 7) * (C >> 6);
   hipLaunchKernelGGL(c8_wgrad_kernel, dim3((p.splits + 7) / 8 * 8 * tiles), dim3(512), CW8_LDS_BYTES, st, p);
   LSPS_CHECK_LAUNCH("c8_wgrad");
-  hipLaunchKernelGGL(c8_wgrad_reduce_kernel, dim3(ceil_div((long)K * C, 256)), dim3(256), 0, st, (const float *)p.part, dw, K * C, p.splits);
+  hipLaunchKernelGGL(c8_wgrad_reduce_kernel, dim3(ceil_div((long)K * C, 64)), dim3(256), 0, st, (const float *)p.part, dw, K * C, p.splits);
   LSPS_CHECK_LAUNCH("c8_wgrad_reduce");
   return 0;
 }

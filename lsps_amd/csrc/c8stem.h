@@ -265,16 +265,21 @@ __global__ __launch_bounds__(256) void c8_stem_wgrad_kernel(C8StemWParams p) {
 // dW[k][r * S + c] = sum_b part[b][k][8 r + c],  db[k] = sum_b part[b][k][63]
 __global__ __launch_bounds__(256) void c8_stem_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db,
                                                                    int R, int S, int blocks) {
-  const int u = blockIdx.x * 256 + threadIdx.x;
-  if (u >= 4096) return;
+  // workgroup = 64 consecutive elements x 4 interleaved slices of the partial blocks (fixed summation order)
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, u = blockIdx.x * 64 + (tid & 63), sl = tid >> 6;
   const int k = u >> 6, t = u & 63, r = t >> 3, c = t & 7;
   const bool isw = r < R && c < S, isb = t == 63;
-  if (!isw && !isb) return;
   float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += part[(long)b * 4096 + u];
+  if (isw || isb)
+    for (int b = sl; b < blocks; b += 4) s += part[(long)b * 4096 + u];
+  red[sl][tid & 63] = s;
+  __syncthreads();
+  if (sl != 0) return;
+  s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   if (isw)
     dW[(long)k * R * S + r * S + c] = s;
-  else if (db)
+  else if (isb && db)
     db[k] = s;
 }
 

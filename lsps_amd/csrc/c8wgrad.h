@@ -197,16 +197,25 @@ __global__ __launch_bounds__(512, 1) void c8_wgrad_kernel(C8WgradParams p) {
 
 // dW[k][c][t] = sum_s part[s][t][k][c]
 __global__ __launch_bounds__(256) void c8_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, int KC, int splits) {
-  const int kc = blockIdx.x * 256 + threadIdx.x;
-  if (kc >= KC) return;
+  // workgroup = 64 consecutive (k, c) x 4 interleaved slices of the splits (4 waves per SIMD stream the partial sums; fixed order)
+  __shared__ float red[4][9][64];
+  const int tid = threadIdx.x, l = tid & 63, sl = tid >> 6, kc = blockIdx.x * 64 + l;
   float s[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) s[t] = 0.f;
-  for (int sp = 0; sp < splits; ++sp)
+  if (kc < KC)
+    for (int sp = sl; sp < splits; sp += 4)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) s[t] += part[((long)sp * 9 + t) * KC + kc];
+      for (int t = 0; t < 9; ++t) s[t] += part[((long)sp * 9 + t) * KC + kc];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) dW[(long)kc * 9 + t] = s[t];
+  for (int t = 0; t < 9; ++t) red[sl][t][l] = s[t];
+  __syncthreads();
+  // 576 outputs of the workgroup, contiguous in dW: element e = l * 9 + t
+  for (int e = tid; e < 576; e += 256) {
+    const int ll = e / 9, t = e - ll * 9;
+    if (blockIdx.x * 64 + ll < KC)
+      dW[(long)blockIdx.x * 576 + e] = (red[0][t][ll] + red[1][t][ll]) + (red[2][t][ll] + red[3][t][ll]);
+  }
 }
 
 }  // namespace lsps

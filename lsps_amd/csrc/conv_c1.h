@@ -350,10 +350,16 @@ __global__ __launch_bounds__(256, 2) void c1_wgrad_kernel(C1WParams p) {
 // dW[k][t] = sum_b part[b][k][t] (t < T), db[k] = sum_b part[b][k][T]
 __global__ __launch_bounds__(256) void c1_wgrad_c8_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db,
                                                                  int K, int T, int blocks) {
-  const int u = blockIdx.x * 256 + threadIdx.x, To = T + 1;
-  if (u >= K * To) return;
+  // workgroup = 64 consecutive elements x 4 interleaved slices of the partial blocks (fixed summation order)
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, u = blockIdx.x * 64 + (tid & 63), sl = tid >> 6, To = T + 1;
   float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += part[(long)b * K * To + u];
+  if (u < K * To)
+    for (int b = sl; b < blocks; b += 4) s += part[(long)b * K * To + u];
+  red[sl][tid & 63] = s;
+  __syncthreads();
+  if (sl != 0 || u >= K * To) return;
+  s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   const int k = u / To, t = u - k * To;
   if (t < T)
     dW[k * T + t] = s;

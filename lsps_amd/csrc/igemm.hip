@@ -1313,7 +1313,7 @@ static int run_c1_wgrad(const float *small, const float *big, float *dW, int N, 
   LSPS_CHECK_LAUNCH("c1_wgrad");
   note_kernel("c1_wgrad_kernel");
   if (fused) {
-    hipLaunchKernelGGL(c1_wgrad_c8_reduce_kernel, dim3(ceil_div((long)Cs * (R * S + 1), 256)), dim3(256), 0, st, (const float *)p.part, dW,
+    hipLaunchKernelGGL(c1_wgrad_c8_reduce_kernel, dim3(ceil_div((long)Cs * (R * S + 1), 64)), dim3(256), 0, st, (const float *)p.part, dW,
                        db, Cs, R * S, blocks);
     LSPS_CHECK_LAUNCH("c1_wgrad_c8_reduce");
     return 0;
