@@ -610,13 +610,18 @@ __global__ __launch_bounds__(256) void pw1_dgrad_act_kernel(const float *__restr
   }
 }
 
-// dW[c] = sum_b wpart[b][c] (c < C), db[0] = sum_b wpart[b][C]   (C <= 255; one block)
+// dW[c] = sum_b wpart[b][c] (c < C), db[0] = sum_b wpart[b][C]: one workgroup per column c (grid C + 1), fixed summation order
 __global__ __launch_bounds__(256) void pw1_wsplit_reduce_kernel(const float *__restrict__ wpart, float *__restrict__ dW, float *__restrict__ db,
                                                                 int C, int blocks) {
-  const int c = threadIdx.x;
-  if (c > C) return;
+  __shared__ float red[4];
+  const int c = blockIdx.x, tid = threadIdx.x;
   float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += wpart[(long)b * (C + 1) + c];
+  for (int b = tid; b < blocks; b += 256) s += wpart[(long)b * (C + 1) + c];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid != 0) return;
+  s = (red[0] + red[1]) + (red[2] + red[3]);
   if (c < C)
     dW[c] = s;
   else if (db)

@@ -1901,7 +1901,7 @@ int lsps_pw1_dgrad_act(const float *dpre, const float *w, const float *act_y, fl
     LSPS_CHECK_LAUNCH("reduce_partials");
   }
   if (dw) {                      // the head's own weight gradient [C] and bias gradient [1] from the same pass: rows of C + 1
-    hipLaunchKernelGGL(pw1_wsplit_reduce_kernel, dim3(1), dim3(256), 0, st, (const float *)wpart, dw, db, C, 2 * N);
+    hipLaunchKernelGGL(pw1_wsplit_reduce_kernel, dim3(C + 1), dim3(256), 0, st, (const float *)wpart, dw, db, C, 2 * N);
     LSPS_CHECK_LAUNCH("pw1_wsplit_reduce");
   }
   return 0;
