@@ -22,9 +22,11 @@ CONV_GEOMS = [(3, 64, 128, 128),        # generator down 1            (lsps_nets
               (6, 256, 16, 512),
               (21, 512, 8, 1024),
               (70, 1024, 4, 2048),
-              (1, 64, 16, 128)]
+              (1, 64, 16, 128),
+              (18, 64, 128, 128)]       # 288 pixel tiles: the persistent workgroups walk 1.125 rounds (ragged last round)
 # (N, Ci, H = W of the transposed conv INPUT, Co)
-CONVT_GEOMS = [(3, 256, 32, 128), (3, 128, 64, 64), (5, 128, 4, 64), (19, 128, 2, 64)]
+CONVT_GEOMS = [(3, 256, 32, 128), (3, 128, 64, 64), (5, 128, 4, 64), (19, 128, 2, 64),
+               (18, 128, 64, 64)]       # 288 pixel tiles of the persistent kernels
 
 
 def _ws(L, _lib, dev, N, C, H, K):
@@ -204,7 +206,7 @@ def test_c8_pw1_head(N, C, H):
     assert _rel(db, dpre.double().cpu().sum().view(1)) <= 1e-4
 
 
-@pytest.mark.parametrize("N,C,H,K", [(3, 64, 128, 128), (5, 128, 32, 256), (21, 512, 8, 1024), (70, 1024, 4, 2048)])
+@pytest.mark.parametrize("N,C,H,K", [(3, 64, 128, 128), (5, 128, 32, 256), (21, 512, 8, 1024), (70, 1024, 4, 2048), (18, 64, 128, 128)])
 def test_c8_conv3x3s2_dgrad_with_fused_previous_activation(N, C, H, K):
     """conv dgrad whose epilogue applies the PREVIOUS layer's LeakyReLU backward and sums that layer's bias gradient."""
     _need_gpu()
@@ -227,7 +229,7 @@ def test_c8_conv3x3s2_dgrad_with_fused_previous_activation(N, C, H, K):
     assert _rel(db, got.double().cpu().sum((0, 2, 3))) <= 1e-5 * max(1.0, (N * H * H) ** 0.5 / 8)
 
 
-@pytest.mark.parametrize("N,Ci,H,Co", [(3, 256, 32, 128), (3, 128, 64, 64), (19, 128, 2, 64)])
+@pytest.mark.parametrize("N,Ci,H,Co", [(3, 256, 32, 128), (3, 128, 64, 64), (19, 128, 2, 64), (18, 128, 64, 64)])
 def test_c8_convT3x3s2_dgrad_with_fused_previous_activation(N, Ci, H, Co):
     _need_gpu()
     _lib, L, dev, st = _env()
