@@ -50,14 +50,16 @@ def _run_steps(hp, sds, b, nz):
     return sd, scal
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, config='tiny', mode='f32'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        hp = cases.hp_for('tiny')
+        from lsps_amd import ops
+        ops.set_math_mode(mode)
+        hp = cases.hp_for(config)
         sds = cases.make_weights(hp, lsps_ref)
         b, nz = cases.make_inputs(N), _noise(hp)
         per = N // world
@@ -73,22 +75,30 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_global_batch_step():
+@pytest.mark.parametrize('config,mode', [('tiny', 'f32'), ('full', 'bf16')])
+def test_two_rank_step_equals_global_batch_step(config, mode):
+    """('full', 'bf16'): BASELINE configs 4 x 5 — the data-parallel step on the bf16 channel-group kernels at full width (bias
+    gradients arrive from the CONSUMER layer's dgrad epilogue there; the reducer must still see every gradient)."""
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
+    from lsps_amd import ops
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, config, mode)) for r in range(2)]
     for p in procs:
         p.start()
     sd_dp, scal_dp = out.get(timeout=600)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    hp = cases.hp_for('tiny')
+    hp = cases.hp_for(config)
     sds = cases.make_weights(hp, lsps_ref)
-    sd_1, scal_1 = _run_steps(hp, sds, cases.make_inputs(N), _noise(hp))
+    ops.set_math_mode(mode)
+    try:
+        sd_1, scal_1 = _run_steps(hp, sds, cases.make_inputs(N), _noise(hp))
+    finally:
+        ops.set_math_mode('f32')
     init = {('gen.' + k): np.asarray(v) for k, v in sds['gen'].items()}
     init.update({('dis.' + k): np.asarray(v) for k, v in sds['dis'].items()})
     moved = 0
