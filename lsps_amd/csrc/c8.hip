@@ -161,8 +161,8 @@ static bool c8s2_wgrad_geom(int N, int K, int C, int H, int W, C8S2WParams *p) {
   if ((long)TI * (C >> 3) * H * W * 16 >= (1l << 31) || (long)TI * (K >> 3) * P * Q * 16 >= (1l << 31)) return false;
   const int tiles = (K >> 7) * (C >> 6);
   int s = (c8_wgrad_queue() * 256 + tiles - 1) / tiles;
-  s = (s + 7) / 8 * 8;                                           // a split lives on ONE XCD (workgroup -> tile mapping): use all 8
-  if (s > nc) s = nc;
+  if (s > 1) s = (s + 7) / 8 * 8;                                // a split lives on ONE XCD (workgroup -> tile mapping): use all 8
+  if (s > nc) s = nc;                                            // s == 1: the tiles alone fill the chip (kernel: plain tile mapping)
   const int cps = (nc + s - 1) / s;
   s = (nc + cps - 1) / cps;
   if (p) {
@@ -337,7 +337,7 @@ static int c8s2_run_wgrad(const void *small, const void *big, float *dw, int N, 
   p.part = (float *)ws;
   if (int rc = lds_optin(reinterpret_cast<const void *>(c8s2_wgrad_kernel), C8S2W_LDS_BYTES, "c8s2_wgrad")) return rc;
   const int tiles = (K >> 7) * (C >> 6);
-  hipLaunchKernelGGL(c8s2_wgrad_kernel, dim3((p.splits + 7) / 8 * 8 * tiles), dim3(512), C8S2W_LDS_BYTES, st, p);
+  hipLaunchKernelGGL(c8s2_wgrad_kernel, dim3(p.splits == 1 ? tiles : (p.splits + 7) / 8 * 8 * tiles), dim3(512), C8S2W_LDS_BYTES, st, p);
   LSPS_CHECK_LAUNCH("c8s2_wgrad");
   hipLaunchKernelGGL(c8_wgrad_reduce_kernel, dim3(ceil_div((long)K * C, 64)), dim3(256), 0, st, (const float *)p.part, dw, K * C, p.splits);
   LSPS_CHECK_LAUNCH("c8s2_wgrad_reduce");

@@ -639,8 +639,9 @@ __global__ __launch_bounds__(512, 1) void c8s2_wgrad_kernel(C8S2WParams p) {
 
   const int CT = p.C >> 6, KT = p.K >> 7, tiles = CT * KT;
   const int lin = blockIdx.x, xcd = lin & 7, qq = lin >> 3;
-  const int tile = qq % tiles, split = xcd + 8 * (qq / tiles);
-  if (split >= p.splits) return;
+  // splits == 1 (>= 256 output tiles: the last trunk layer): one workgroup per tile over all XCDs, no partial sums to add up
+  const int tile = p.splits == 1 ? lin : qq % tiles, split = p.splits == 1 ? 0 : xcd + 8 * (qq / tiles);
+  if (split >= p.splits || tile >= tiles) return;
   const int kt = tile / CT, ct = tile - kt * CT;
   const int c0 = split * p.chunks_per_split, c1 = min(p.nchunks, c0 + p.chunks_per_split);
 
