@@ -476,7 +476,7 @@ def main():
             issued = sum(a['tflops'] * a['total_ms'] * 1e9 / wx.get(k, 1.0) for k, a in prof_all.items()) / prof_all_steps
             step_issued_frac = issued / (elapsed / args.steps) / (peak * 1e12)
         out = {
-            'metric': 'depth_train steps/sec (128x128x1, bs=128)', 'value': world * args.steps / elapsed,
+            'metric': 'depth_train steps/sec (128x128x1, bs=%d)' % args.batch, 'value': world * args.steps / elapsed,
             'unit': 'steps/s',
             'n_gpus': world, 'n_ranks': n_ranks, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',

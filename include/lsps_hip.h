@@ -7,8 +7,16 @@
  * them through ctypes from torch.autograd.Function.forward/backward.
  *
  * Conventions
- *   - plain pointers and sizes only; every tensor is float32, contiguous, NCHW (row-major),
- *     resident in device (HBM) memory; `stream` is a hipStream_t passed as void*;
+ *   - plain pointers and sizes only; every tensor is contiguous and resident in device (HBM) memory;
+ *     `stream` is a hipStream_t passed as void*;
+ *   - two tensor conventions, fixed per entry point by its name:
+ *       lsps_<op>...     : float32, NCHW (row-major) — the reference's own layout and dtype;
+ *       lsps_c8_<op>...  : the bf16 mode of BASELINE config 5: activations are bfloat16 (passed as
+ *                          `const void*` / `void*`, 2 bytes per element) in the channel-group layout
+ *                          "C8" [N][C/8][H][W][8] (the 8 consecutive channels of a pixel = one 16-byte
+ *                          unit, C a multiple of 8); weights, biases, statistics, gradients of weights,
+ *                          loss scalars and everything an optimizer touches stay float32 in torch layout;
+ *                          f32 NCHW <-> C8 conversion entries are lsps_c8_from_nchw / lsps_c8_to_nchw;
  *   - every call is asynchronous on `stream`, never allocates and never synchronises: scratch
  *     memory is handed in by the caller (`ws`, sized by the matching *_workspace_bytes);
  *   - return value 0 = launched, negative = rejected (LSPS_E_*); lsps_last_error() explains.

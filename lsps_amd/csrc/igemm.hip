@@ -1225,7 +1225,11 @@ static size_t w3x3s2_ws_bytes(int N, int M, int C, int Hs, int Ws) {
 
 static int run_w3x3s2(const float *small, const float *big, float *dW, int N, int C, int M, int Hs, int Ws, void *ws,
                       size_t ws_bytes, hipStream_t st) {
-  if (int rc = lds_optin(reinterpret_cast<const void *>(igemm_w3x3s2_kernel<false>), (int)WS2_LDS_BYTES, "igemm_w3x3s2")) return rc;
+  // opt in the instantiation that is launched below (the bf16 one has its own function handle)
+  if (int rc = g_math_mode == 1
+                   ? lds_optin(reinterpret_cast<const void *>(igemm_w3x3s2_kernel<true>), (int)WS2_LDS_BYTES, "igemm_w3x3s2<bf16>")
+                   : lds_optin(reinterpret_cast<const void *>(igemm_w3x3s2_kernel<false>), (int)WS2_LDS_BYTES, "igemm_w3x3s2"))
+    return rc;
   WS2Params p;
   memset(&p, 0, sizeof(p));
   p.Small = small;

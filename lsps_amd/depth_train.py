@@ -92,11 +92,15 @@ def run(opts, trainer_factory=None, loader_a=None, loader_b=None, test_batches=N
         import torch
         from . import trainers
         from . import dist as ldist
-        if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not torch.distributed.is_initialized():
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            torch.distributed.init_process_group('nccl')
         gpu = int(os.environ.get('LOCAL_RANK', opts.gpu))
         device = torch.device('cuda', gpu)
+        # Bind this rank to ITS GPU before the first collective: resume() below (reference order, depth_train.py:103-107,
+        # is resume THEN cuda) already broadcasts rank 0's iteration count, and with every rank still on cuda:0 RCCL would
+        # see duplicate devices.
+        torch.cuda.set_device(device)
+        if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not torch.distributed.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            torch.distributed.init_process_group('nccl', device_id=device)
         trainer = getattr(trainers, hp['trainer'])(hp)                                   # :99-102
         iterations = 0
         if opts.resume == 1:                                                             # :109-113

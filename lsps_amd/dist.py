@@ -171,7 +171,8 @@ class GradReducer(object):
             # ranks agree on which buckets carry gradients because they run the same step
             if not self._launched[b] and any(touched[i0:i1]):
                 self._launch(b)
-        timed = self.collect_stats and self.arena.flat_g.is_cuda
+        # never inside a hipGraph capture: a captured event has no elapsed time (take_stats would raise)
+        timed = self.collect_stats and self.arena.flat_g.is_cuda and not torch.cuda.is_current_stream_capturing()
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -215,13 +216,67 @@ def broadcast_from_rank0(tensors, group=None):
         dist.broadcast(t, 0, group=group)
 
 
-def agree_from_rank0(value):
-    """Rank 0's python value on every rank (e.g. the iteration count a resume() found); identity in a single process."""
+def local_device():
+    """The HIP device this rank's collectives must stage on.  RCCL refuses two ranks on one device, and
+    `torch.cuda.current_device()` is still 0 on every rank until somebody calls `set_device` — which the reference's
+    call order does late (depth_train.py:103-107: `resume()` BEFORE `cuda(gpu)`), so a collective issued from `resume()`
+    cannot rely on it: the launcher's LOCAL_RANK decides.  None for host-side backends (gloo)."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != 'nccl':
+        return None
+    return torch.device('cuda', int(os.environ.get('LOCAL_RANK', torch.cuda.current_device())))
+
+
+def agree_from_rank0(value, device=None):
+    """Rank 0's python value on every rank (e.g. the iteration count a resume() found); identity in a single process.
+    `device`: where the pickled bytes are staged (default: `local_device()`, i.e. this rank's OWN GPU under RCCL even
+    before the trainer has been moved there)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
     box = [value]
-    dist.broadcast_object_list(box, 0)
+    dist.broadcast_object_list(box, 0, device=device if device is not None else local_device())
     return box[0]
+
+
+def drain_watchdog(timeout_s=5.0):
+    """Blocks until RCCL's watchdog thread has retired every eager collective it tracks; True when that was CONFIRMED.
+
+    Why: the watchdog polls the end events of the collectives on its work list (every ~100 ms); HIP refuses such a query
+    (hipErrorCapturedEvent, which the watchdog turns into a process abort) once the process group's stream has joined a
+    hipGraph capture.  Before a data-parallel step is captured the list must therefore be EMPTY, not just complete.  The
+    list itself is not visible from Python, but the flight recorder is: an entry stays 'active' until the watchdog has
+    seen its work finished and dropped it (`_dump_nccl_trace(onlyActive=True)`).  Needs the recorder on
+    (TORCH_NCCL_TRACE_BUFFER_SIZE > 0, torch's default); with it off, or on a torch without the call, the drain cannot
+    be confirmed and the caller keeps the step eager."""
+    import pickle
+    import time
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != 'nccl':
+        return True                        # no watchdog to race with
+    torch.cuda.synchronize()               # every eager collective has finished on the device
+    try:
+        from torch._C._distributed_c10d import _dump_nccl_trace as dump
+        seen = pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=False)).get('entries')
+    except Exception:                      # noqa: BLE001  (no recorder in this build)
+        return False
+    if not seen:                           # recorder off: an empty 'active' list would prove nothing
+        return False
+    t0 = time.time()
+    while time.time() - t0 < timeout_s:
+        active_ = pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=True)).get('entries')
+        if not active_:
+            return True
+        time.sleep(0.02)
+    return False
+
+
+def agree_all(flag, device=None):
+    """True only if `flag` is true on EVERY rank (one tiny MIN all-reduce); identity in a single process."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bool(flag)
+    dev = device if device is not None else (local_device() or torch.device('cpu'))
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
 
 
 def barrier():

@@ -239,11 +239,14 @@ class LSPSTrainer(nn.Module):
             return eager(self, *args, **kwargs)
         torch.cuda.synchronize()
         if lsps_dist.active():
-            # RCCL's watchdog thread polls the end events of the EAGER collectives it still tracks; HIP refuses such a
-            # query (hipErrorCapturedEvent, which the watchdog turns into an abort) once the process group's stream has
-            # joined a capture.  The device is idle here, so the list drains at the watchdog's next poll (100 ms period).
-            import time
-            time.sleep(0.5)
+            # RCCL's watchdog must have RETIRED every eager collective before its stream joins a capture (dist.drain_watchdog:
+            # confirmed through the flight recorder, not a sleep).  Not confirmed (recorder off) on ANY rank => this call
+            # stays eager everywhere and the capture is tried again at the next one.  The agreement is itself an eager
+            # collective, hence the second drain (should that one fail on a single rank, that rank runs eagerly against the
+            # others' capture + replay: the same collectives in the same order, so the ranks stay aligned).
+            ok = lsps_dist.agree_all(lsps_dist.drain_watchdog())
+            if not (ok and lsps_dist.drain_watchdog()):
+                return eager(self, *args, **kwargs)
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
         g = self._graphs[sig] = _GraphedUpdate(self, eager, args, kwargs, self._graph_pool)
@@ -417,9 +420,15 @@ class LSPSTrainer(nn.Module):
             first_a, first_b = images_a[0:4], images_b[0:4]                       # :238 — only the first 4 samples
             if lsps_dist.active():
                 # exact global-batch parity: every rank evaluates the SAME (global first-4) feature term
-                first = torch.cat((first_a, first_b), 0)                          # ONE 8-image broadcast
-                torch.distributed.broadcast(first, 0)
-                first_a, first_b = first[0:4], first[4:8]
+                na = first_a.size(0)                                              # < 4 when the per-rank batch is
+                if first_a.shape[1:] == first_b.shape[1:]:
+                    first = torch.cat((first_a, first_b), 0)                      # ONE broadcast of the 2 x na images
+                    torch.distributed.broadcast(first, 0)
+                    first_a, first_b = first[:na], first[na:]
+                else:                                                             # input_dim_a != input_dim_b
+                    first_a, first_b = first_a.contiguous(), first_b.contiguous()
+                    torch.distributed.broadcast(first_a, 0)
+                    torch.distributed.broadcast(first_b, 0)
             # The feature branch (generator on 8 samples -> dis.feats on 16) and the regression branch (dis on the whole
             # batch) are independent until the loss is summed, and the first one's launches fill a quarter of the chip at
             # best: it runs on a second HIP stream (forward here, its backward follows it there: autograd replays a node on
@@ -466,7 +475,14 @@ class LSPSTrainer(nn.Module):
     def resume(self, snapshot_prefix, idx=-1, load_opt=False, est=False):
         """Under data parallelism the outcome is rank 0's: a rank that does not see the snapshot (no shared filesystem, a
         half-written file) still enters the same broadcasts as the others and ends up with rank 0's weights and count."""
-        iterations = self._resume_local(snapshot_prefix, idx, load_opt, est)
+        try:
+            iterations = self._resume_local(snapshot_prefix, idx, load_opt, est)
+        except Exception:
+            # single process / rank 0: the reference's behaviour (helpers.get_model_list raises on an empty directory);
+            # another rank must not leave rank 0 alone in the broadcasts below just because ITS disk holds nothing
+            if lsps_dist.world() == 1 or lsps_dist.rank() == 0:
+                raise
+            iterations = 0
         iterations = lsps_dist.agree_from_rank0(iterations)
         self.sync_replicas()
         return iterations

@@ -364,3 +364,60 @@ def test_full_width_default_buckets_launch_in_readiness_order_and_skip_the_idle_
     # what a pretrain step puts on the wire (MB): dis arena + gen part of the gen arena = 173.6 (was 242)
     total_mb = (sum(nb for _, _, _, _, nb in log) + gen_bytes) / 1e6
     assert abs(total_mb - 173.6) < 0.5, total_mb
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 4: resume() under data parallelism runs a collective BEFORE cuda() (reference order,
+# depth_train.py:103-107).  The count every rank continues from is rank 0's, whatever a rank found locally.
+# ---------------------------------------------------------------------------------------------------------------
+def _resume_worker(rank, world, port, root, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        import lsps_amd.trainers as prod
+        from lsps_amd import dist as ldist
+        assert ldist.local_device() is None                     # host-side backend: nothing to bind
+        hp = cases.hp_for('tiny')
+        torch.manual_seed(100 + rank)
+        tr = prod.LSPSTrainer(hp)
+        mine = os.path.join(root, 'rank%d' % rank)
+        os.makedirs(mine, exist_ok=True)
+        if rank == 0:                                           # only rank 0 holds a snapshot (no shared filesystem)
+            torch.save(tr._dense_state(tr.gen), os.path.join(mine, 'pre_gen_%08d.pkl' % 7000))
+            torch.save(tr._dense_state(tr.dis), os.path.join(mine, 'pre_dis_%08d.pkl' % 7000))
+        dist.barrier()
+        assert tr.gpu is None                                   # resume BEFORE cuda(), as the reference's driver calls it
+        it = tr.resume(os.path.join(mine, 'pre'), idx=-1, load_opt=True)
+        flags = (ldist.agree_all(True), ldist.agree_all(rank == 0), ldist.drain_watchdog())
+        out.put((rank, it, flags))
+    except Exception as e:                                       # the parent would otherwise wait for its timeout
+        import traceback
+        out.put((rank, 'error', repr(e) + traceback.format_exc()))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_resume_before_cuda_agrees_on_rank0s_iteration_count(tmp_path):
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_resume_worker, args=(r, 2, port, str(tmp_path), out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(out.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == [7000, 7000], got             # rank 1 found nothing locally and still continues at 7000
+    assert all(g[2] == (True, False, True) for g in got), got   # agree_all = AND over ranks; gloo has no watchdog to drain
+
+
+def test_estimate_first4_broadcast_slices_by_the_real_count():
+    """post_update's data-parallel broadcast of the first images must not assume 4 per rank."""
+    import inspect
+    import lsps_amd.trainers.lsps_trainer as lt
+    src = inspect.getsource(lt.LSPSTrainer.post_update)
+    assert 'first[:na], first[na:]' in src and 'first[0:4], first[4:8]' not in src

@@ -321,3 +321,61 @@ def test_data_parallel_steps_replay_from_hip_graphs_bitwise():
             assert np.array_equal(eager[net][k], graphed[net][k]), k
     e, n = eager['early'][-1]
     assert n >= 2 and e >= n - 1, eager['early']            # eager DP steps still overlap (learned signatures)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 4: `--resume 1` under data parallelism.  Reference order (depth_train.py:103-107): resume() BEFORE
+# cuda().  Rank 1 has no snapshot on its disk; after cuda() both replicas must hold rank 0's snapshot weights and count.
+# ---------------------------------------------------------------------------------------------------------------
+def _resume_worker(rank, world, port, root, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import lsps_amd.trainers as prod
+        hp = cases.hp_for('tiny')
+        torch.manual_seed(900 + rank)
+        saved = prod.LSPSTrainer(hp)                               # the snapshot's weights: rank 0's RNG stream
+        mine = os.path.join(root, 'rank%d' % rank)
+        os.makedirs(mine, exist_ok=True)
+        if rank == 0:
+            torch.save(saved._dense_state(saved.gen), os.path.join(mine, 'pre_gen_%08d.pkl' % 3000))
+            torch.save(saved._dense_state(saved.dis), os.path.join(mine, 'pre_dis_%08d.pkl' % 3000))
+        dist.barrier()
+        torch.manual_seed(1900 + rank)
+        tr = prod.LSPSTrainer(hp)                                  # fresh, different weights on every rank
+        it = tr.resume(os.path.join(mine, 'pre'), idx=-1, load_opt=True)
+        tr.cuda(0)
+        sums = torch.tensor([float(o.arena.flat_p.double().sum()) for o in (tr.dis_opt, tr.gen_opt)], dtype=torch.float64)
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same_as_saved = all(torch.equal(v.cpu(), saved.gen.state_dict()[k]) for k, v in tr.gen.state_dict().items()) and \
+            all(torch.equal(v.cpu(), saved.dis.state_dict()[k]) for k, v in tr.dis.state_dict().items())
+        out.put((rank, it, bool(torch.equal(lo, hi)), bool(same_as_saved) if rank == 0 else None))
+    except Exception as e:                                         # the parent would otherwise wait for its timeout
+        import traceback
+        out.put((rank, 'error', repr(e), traceback.format_exc()))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_resume_before_cuda_ends_on_rank0s_snapshot(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_resume_worker, args=(r, 2, port, str(tmp_path), out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(out.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(g[1] == 3000 for g in got), got
+    assert all(g[2] for g in got), "replicas differ after resume() + cuda()"
+    assert got[0][3] is True, "rank 0's arenas must hold the snapshot's weights"
