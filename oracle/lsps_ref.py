@@ -296,9 +296,8 @@ class RefDis(ParamTable):
     def __init__(self, cfg):
         super(RefDis, self).__init__(dis_shapes(cfg))
         self.cfg = cfg
-        self.n_shared = cfg.get('n_expand_layer', 0) + cfg['n_shared_layer']
-        if cfg.get('n_expand_layer', 0):
-            raise NotImplementedError("n_expand_layer > 0 is not used by the shipped configs")
+        self.n_expand = cfg.get('n_expand_layer', 0)                  # :93 optional key, 0 in both shipped configs
+        self.n_shared = self.n_expand + cfg['n_shared_layer']
 
     def _front(self, d, x):                                      # :101-109
         h = lrelu_conv(x, self.p, 'model_%s.0.model.0' % d, 2, 3)
@@ -307,8 +306,8 @@ class RefDis(ParamTable):
         return h
 
     def _shared(self, h):                                        # :111-126
-        for i in range(self.n_shared):
-            h = lrelu_conv(h, self.p, 'model_S.%d.model.0' % i, 2, 1)
+        for i in range(self.n_shared):                           # :116-118 expand layers: stride 1; :119-121 stride 2
+            h = lrelu_conv(h, self.p, 'model_S.%d.model.0' % i, 1 if i < self.n_expand else 2, 1)
         return h
 
     def _post(self, f):

@@ -84,15 +84,30 @@ def dead_bias_keys(golden):
     return dead
 
 
-def compare(results, golden, rtol, atol_scale=1.0, skip=(), grad_rtol=None):
+# gradients, robust criteria (relative; see `compare`): L2 digest, mean, 1 - cosine, and two quantiles of the element error.
+# Measured floor — the reference against its OWN restatement on the same torch CPU kernels (profiles/r4a_gradient_criterion.txt):
+# L2 1.8e-4, 1 - cosine 1.1e-6, 99th percentile 1.65e-3 at full width (LeakyReLU kinks / sign() of the L1 losses flip
+# isolated elements), which is why the 99 % bound sits at 5e-3 and the 1e-3 bound is asked of 90 % of the elements.
+GRAD_ROBUST = {'l2': 1e-3, 'mean': 1e-3, 'cosine': 1e-3, 'q99': 5e-3, 'q90': 1e-3}
+# ResNeXt generator at 8-64 channels: three LeakyReLU / InstanceNorm stages per block, restatement-vs-reference quantiles 1.4e-2 (99 %) and 1.25e-2 (90 %)
+GRAD_ROBUST_RESX = {'l2': 2e-3, 'mean': 1e-3, 'cosine': 1e-3, 'q99': 3e-2, 'q90': 2e-2}
+
+
+def compare(results, golden, rtol, atol_scale=1.0, skip=(), grad_rtol=None, grad_robust=GRAD_ROBUST, report=None):
     """Returns list of (key, err, tol) failures. Error is relative to the tensor's abs-max.
-    ``grad_rtol`` (default = rtol) applies to '*.grads' cases: gradients of this model are
+    ``grad_rtol`` (default = rtol) applies to the MAX element error of '*.grads' cases: gradients of this model are
     discontinuous in the activations (sign() of the L1 losses, LeakyReLU kinks), so fp32
     round-off differences between two correct implementations flip isolated elements and show
     up at the 1e-3..1e-2 level of a gradient tensor's abs-max (measured: reference vs. its own
-    restatement on the same torch CPU kernels reaches 3.6e-3 at ch=64)."""
+    restatement on the same torch CPU kernels reaches 3.6e-3 at ch=64).
+    Isolated flips cannot hide a systematically wrong gradient, though, so every gradient tensor must
+    ALSO pass the robust criteria of ``grad_robust`` (GRAD_ROBUST): its L2 norm within 1e-3 relative, its mean within 1e-3
+    of abs-max, the cosine between its stored elements (full tensor or the 256 seeded samples) and the reference's within
+    1e-3 of 1, 90 % of those elements within 1e-3 and 99 % within 5e-3 of abs-max (the restatement of the reference on
+    identical kernels already has a 99th percentile of 1.65e-3).  ``report`` (a dict) receives the worst value per criterion."""
     bad = []
     worst = 0.0
+    rep = report if report is not None else {}
     flat = flatten(results)
     dead = dead_bias_keys(golden)
     dead_off = {}
@@ -130,10 +145,32 @@ def compare(results, golden, rtol, atol_scale=1.0, skip=(), grad_rtol=None):
             scale = float(golden[base + '/absmax'])
         else:
             scale = float(abs(g))
-        rt = grad_rtol if (grad_rtol is not None and 'grads' in parts[0]) else rtol
+        is_grad = 'grads' in parts[0]
+        rt = grad_rtol if (grad_rtol is not None and is_grad) else rtol
+        if is_grad and grad_robust is not None and kind in ('l2', 'mean'):
+            rt = min(rt, grad_robust[kind])    # the digests of a gradient tensor do not inherit the max-element tolerance
         tol = rt * max(scale, 1e-30) * atol_scale + 1e-12
         diff = np.abs(np.asarray(v, np.float64) - np.asarray(g, np.float64)) if g.size else np.zeros(1)
         err = float(diff.max())
+        if is_grad and np.isfinite(err):
+            what = 'grad_' + ('max' if kind in ('full', 'sample') else kind)
+            if err / max(scale, 1e-30) >= rep.get(what, (-1.0, ''))[0]:
+                rep[what] = (err / max(scale, 1e-30), key)
+        if is_grad and grad_robust is not None and kind in ('full', 'sample') and g.size > 1 and scale > 0 and np.isfinite(err):
+            a, b_ = np.asarray(v, np.float64).ravel(), np.asarray(g, np.float64).ravel()
+            na, nb = float(np.linalg.norm(a)), float(np.linalg.norm(b_))
+            one_minus_cos = 1.0 - float(a @ b_) / max(na * nb, 1e-300)
+            q99, q90 = float(np.quantile(diff, 0.99)) / scale, float(np.quantile(diff, 0.90)) / scale
+            for what, val in (('grad_one_minus_cosine', one_minus_cos), ('grad_q99', q99), ('grad_q90', q90)):
+                if val >= rep.get(what, (-1.0, ''))[0]:
+                    rep[what] = (val, key)
+            if one_minus_cos > grad_robust['cosine']:
+                bad.append((key + '#1-cosine', one_minus_cos, grad_robust['cosine']))
+            if g.size >= 100:              # below that the quantiles ARE the max, which the max-element rule owns
+                if q99 > grad_robust['q99']:
+                    bad.append((key + '#q99', q99, grad_robust['q99']))
+                if q90 > grad_robust['q90']:
+                    bad.append((key + '#q90', q90, grad_robust['q90']))
         if 'params' in parts[0] and np.isfinite(err):
             # Post-Adam weights: the first Adam steps move every weight by ~lr*sign(g); where g is
             # ~0 its sign is round-off, so isolated elements legitimately differ by up to 2*lr per
@@ -441,6 +478,42 @@ def run_extra_cases(A, shapes_mod, which=('estimate1', 'wide')):
         R['wide.it0.gen_update.outputs'] = OrderedDict(zip(('x_aa', 'x_ba', 'x_ab', 'x_bb', 'x_aba', 'x_bab'), outs[:6]))
         R['wide.it0.dis.params'] = A.params(tr, 'dis')
         R['wide.it0.gen.params'] = A.params(tr, 'gen')
+    return R
+
+
+def run_expand_cases(A, shapes_mod):
+    """Round 4 (golden_expand.npz): `SharedDis` with the optional `n_expand_layer` key (lsps_nets.py:93,116-118): ONE stride-1
+    3x3 LeakyReLUConv2d in front of the stride-2 trunk, tiny width (front 4 -> 8 channels, expand 8 -> 16 on 32 x 32, trunk
+    16 -> 256).  Module outputs (forward incl. n = 1 `.squeeze()`, regress_b, feats) and two iterations of
+    dis_update + post_update(mode 3) with gradients and post-Adam weights."""
+    R = OrderedDict()
+    hp = hp_for('tiny')
+    hp['dis'] = dict(hp['dis'], n_expand_layer=1)
+    sds = make_weights(hp, shapes_mod)
+    tr = A.make_trainer(hp, sds)
+    A.set_train(tr, False)
+    b = make_inputs(2)
+    R['expand.dis.forward'] = OrderedDict(zip(('out_a', 'out_b', 'feats_a', 'feats_b'), A.dis_forward(tr, b['xa'], b['xb'])))
+    R['expand.dis.regress_b'] = OrderedDict(zip(('p0', 'p1', 'p2'), A.dis_regress(tr, 'b', b['xb'])))
+    R['expand.dis.regress_a.n1'] = OrderedDict(zip(('p0', 'p1', 'p2'), A.dis_regress(tr, 'a', b['xa'][:1])))
+    R['expand.dis.feats'] = OrderedDict(zip(('f0', 'f1', 'f2', 'f3'),
+                                            A.dis_feats(tr, b['xa'][:1], b['xa'][1:], b['xb'][:1], b['xb'][1:])))
+    n, post_n, zd = 2, 8, hp['vae']['z_dim']
+    lat2 = latent_shape(hp, 2 * n)
+    tr = A.make_trainer(hp, sds)
+    A.set_train(tr, True)
+    bp = make_inputs(post_n)
+    for it in range(2):
+        A.dis_update(tr, b, hp, noise(lat2, 8100 + it))
+        R['expand.it%d.dis_update.scalars' % it] = A.scalars(tr)
+        if it == 0:
+            _grad_digest(R, 'expand.it0.dis_update.grads', A, tr, 'dis')
+        A.post_update(tr, bp, 3, hp, noise(latent_shape(hp, 8), 8200 + it), noise((post_n, zd), 8300 + it, 0.05),
+                      noise((post_n, zd), 8400 + it, 0.05))
+        R['expand.it%d.estimate3.scalars' % it] = A.scalars(tr)
+        if it == 0:
+            _grad_digest(R, 'expand.it0.estimate3.grads', A, tr, 'dis')
+        R['expand.it%d.dis.params' % it] = A.params(tr, 'dis')
     return R
 
 

@@ -1,7 +1,7 @@
 """Generates tests/golden/golden_*.npz by running the REAL reference (imported from
 /root/reference through ref_shim.py) on the seeded cases of cases.py.
 
-Run in the build container only:  python tests/golden/make_golden.py [tiny|full|extra|blocks|dropout|all]
+Run in the build container only:  python tests/golden/make_golden.py [tiny|full|extra|expand|blocks|dropout|all]
 The reference cannot travel to the GPU box; the committed .npz files are what pins the oracle
 (tests/test_oracle_golden.py) and, through it and directly, the HIP path (tests/test_parity_gpu.py).
 """
@@ -233,6 +233,13 @@ def main(which):
         np.savez_compressed(path, **flat)
         print('extra', len(flat), 'arrays ->', path, os.path.getsize(path) // 1024, 'KiB')
         if which == 'extra':
+            return
+    if which in ('all', 'expand'):
+        flat = cases.flatten(cases.run_expand_cases(A, shapes))
+        path = os.path.join(HERE, 'golden_expand.npz')
+        np.savez_compressed(path, **flat)
+        print('expand', len(flat), 'arrays ->', path, os.path.getsize(path) // 1024, 'KiB')
+        if which == 'expand':
             return
     for config in (['tiny', 'full'] if which == 'all' else [which]):
         R = OrderedDict()

@@ -17,6 +17,8 @@ dev = torch.device('cuda', 0)
 b = bench.make_device_batch(int(os.environ.get('BS', '128')), dev)
 mode = int(os.environ.get('MODE', '3'))
 step = lambda: tr.post_update(b['xa'], b['la'], b['xb'], b['lb'], b['ca'], b['cb'], mode, hp)  # noqa: E731
+if os.environ.get('GRAPHS') == '1':
+    tr.use_graphs(True)
 for _ in range(3):
     step()
 torch.cuda.synchronize()
