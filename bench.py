@@ -243,6 +243,10 @@ def main():
     n_ranks = 1
     if world > 1 or os.environ.get('LSPS_FORCE_DP') == '1':
         if args.backend == 'nccl':
+            # flight recorder on (torch's default is off): lsps_amd.dist.drain_watchdog confirms through it that RCCL's
+            # watchdog holds no eager work before the data-parallel estimate3 step is captured (else that step stays eager)
+            os.environ.setdefault('TORCH_FR_BUFFER_SIZE', os.environ.get('TORCH_NCCL_TRACE_BUFFER_SIZE', '2000'))   # (torch < 2.9: TORCH_NCCL_TRACE_BUFFER_SIZE)
+            os.environ.setdefault('TORCH_NCCL_TRACE_BUFFER_SIZE', os.environ['TORCH_FR_BUFFER_SIZE'])
             dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
         else:
             dist.init_process_group('gloo', rank=rank, world_size=world)

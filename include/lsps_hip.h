@@ -60,6 +60,13 @@ const char *lsps_last_kernel(int *launches);
  * the conv calls).  Without a scope every call packs into its own workspace (stateless, as before). */
 int lsps_pack_cache_begin(void *arena, size_t bytes);
 int lsps_pack_cache_end(void);
+/* Weights in the device address range [lo, hi) stay unchanged ACROSS scopes until the caller says otherwise: their panels
+ * are kept in a second caller-owned arena and found again by every later scope.  The estimate modes of the reference step
+ * dis_opt only (lsps_trainer.py:220-262: the generator is a frozen feature extractor there), so post_update re-packed the
+ * generator's ~45 weight tensors in every step.  The table is dropped when the call names another range, arena or `epoch`
+ * (the caller's change counter of those weights); lo = NULL: the scopes that follow have no frozen weights (entries are
+ * kept for a later call with the same range / arena / epoch).  Process-wide and host-side like the scope itself. */
+int lsps_pack_cache_frozen(const void *lo, const void *hi, void *arena, size_t bytes, unsigned long long epoch);
 /* Math mode of the MFMA conv kernels (process-wide; direct HBM-bound kernels are f32 always): 0 = exact f32 MFMA (default);
  * 1 = operands rounded to bf16 in registers, v_mfma_f32_32x32x16_bf16 with f32 accumulation (BASELINE config 5:
  * "bf16 with MFMA conv path").  Tensors stay f32 in HBM in both modes.                                  */

@@ -27,6 +27,7 @@ _SIGNATURES = {
     'lsps_get_math_mode': (c_int, []),
     'lsps_pack_cache_begin': (c_int, [_P, c_size_t]),
     'lsps_pack_cache_end': (c_int, []),
+    'lsps_pack_cache_frozen': (c_int, [_P, _P, _P, c_size_t, ctypes.c_ulonglong]),
     'lsps_conv2d_workspace_bytes': (c_size_t, [c_int] * 9),
     'lsps_conv2d_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [c_int, c_float, _P, c_size_t, _P]),
     'lsps_conv2d_in_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [c_float, c_float, _P, c_size_t, _P]),

@@ -132,7 +132,14 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
   // workgroup -> (image, k slice).  Workgroups go to the 8 XCDs round-robin in launch order; each XCD has its own 4 MB
   // L2 and a 32-channel slice of U is 1.18 MB (256 input channels): an XCD works on TWO slices (resident in its L2) and
   // half of the images, the two slices of an image adjacent in time so that its second read of the image hits L2.
-  const int KS = p.M >> 5, lin = blockIdx.x;
+  const int KS = p.M >> 5;
+  int lin = blockIdx.x, split = 0;
+  if (p.ksplit > 1) {                              // uniform: (split, image, k slice), see Wino4Params
+    const int per = p.N * KS;
+    split = lin / per;
+    lin -= split * per;
+  }
+  const int ctot = p.ksplit > 1 ? p.Ctot : p.Cx;
   int n, ks;
   if (KS == 8 && (p.N & 1) == 0) {
     const int xcd = lin & 7, q = lin >> 3;
@@ -147,9 +154,9 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
   // Global loads go through buffer descriptors (uniform base in SGPRs + ONE 32-bit lane offset + scalar offset): no
   // 64-bit per-lane addresses, which the flat form costs in VGPR pairs (this kernel has none to spare).
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(p.X + (long)n * p.Cx * HW), 0, p.Cx * HW * 4, 0x00020000);
+      const_cast<float *>(p.X + ((long)n * ctot + (long)split * p.Cx) * HW), 0, p.Cx * HW * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(p.U + (long)ks * nsteps * W4_UREC), 0, nsteps * W4_UREC * 4, 0x00020000);
+      const_cast<float *>(p.U + ((long)ks * (ctot >> 1) + (long)split * nsteps) * W4_UREC), 0, nsteps * W4_UREC * 4, 0x00020000);
   const unsigned u8_off = (unsigned)(((half * 4 + wp) * 32 + l31) * 8) * 4u;
   const unsigned u1_off = (unsigned)(2048 + (half * 4 + wp) * 32 + l31) * 4u;
 
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
   }
   const int kbase = ks * 32 + 8 * (2 * bj + bi) + 4 * half;    // + i
   const int orow = 16 * wt + 4 * tr;
-  float *ybase = p.Y + ((long)n * p.M + kbase) * HW + orow * 32 + 4 * tc;
+  float *ybase = p.Y + (((long)split * p.N + n) * p.M + kbase) * HW + orow * 32 + 4 * tc;
 
   if (p.norm == 3) {
     // BACKWARD of the InstanceNorm + LeakyReLU in front of this (dgrad) conv, recovered from that layer's saved OUTPUT o (p.R)
@@ -559,6 +566,37 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
     case 2: body(w4_int<1>(), w4_int<0>()); epilogue(w4_int<1>(), w4_int<0>()); break;
     default: body(w4_int<1>(), w4_int<1>()); epilogue(w4_int<1>(), w4_int<1>()); break;
   }
+}
+
+// Reduction-split launches (Wino4Params::ksplit): out = IN(sum of the ks partial planes) (+ LeakyReLU | + residual), one
+// workgroup per (n, k) plane of 1024 pixels held in registers; same two-pass statistics as inorm_fwd_kernel (norm_act.hip).
+__global__ __launch_bounds__(256) void w4_split_reduce_in_kernel(const float *__restrict__ part, int ks, long stride,
+                                                                 const float *__restrict__ res, float *__restrict__ out,
+                                                                 float *__restrict__ rstd_out, float eps, float slope) {
+  __shared__ float red[4];
+  const long o = (long)blockIdx.x * 1024 + threadIdx.x * 4;
+  f32x4 v = *reinterpret_cast<const f32x4 *>(part + o);
+  for (int k = 1; k < ks; ++k) v += *reinterpret_cast<const f32x4 *>(part + k * stride + o);
+  auto block_sum = [&](float x) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  const float mean = block_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / 1024.f);
+  const f32x4 d = v - mean;
+  const float var = block_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.f / 1024.f);
+  const float rstd = 1.f / sqrtf(var + eps);
+  if (threadIdx.x == 0) rstd_out[blockIdx.x] = rstd;
+  f32x4 r = d * rstd;
+  if (slope >= 0.f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * slope;
+  }
+  if (res) r += *reinterpret_cast<const f32x4 *>(res + o);
+  *reinterpret_cast<f32x4 *>(out + o) = r;
 }
 
 }  // namespace lsps

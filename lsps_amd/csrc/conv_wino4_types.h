@@ -28,6 +28,11 @@ struct Wino4Params {
   int norm;                      // 0: y = act(conv + bias) + R;  1: y = lrelu_slope(IN(conv)) (slope < 0: none);  2: y = IN(conv) + R
                                  // 3: y = backward of IN + LeakyReLU(slope) applied to conv, from that layer's saved output R and rstd
   float eps;
+  // reduction split for launches that would not fill the chip (few images): workgroup (split, image, k slice) convolves
+  // channels [split * Cx, (split + 1) * Cx) of the Ctot-channel tensors X / U and writes its PARTIAL plain output (norm 0, no
+  // bias / activation / addend) to Y + split * N * M * 1024; w4_split_reduce_in_kernel sums the partials and normalises.
+  int ksplit;                    // 0 | 1: no split (Ctot is ignored, Cx = all channels)
+  int Ctot;
 };
 
 // weight gradient (conv_wino4w.h): partial sums part[split][36 positions][M][C], then dW = G^T (sum of splits) G
@@ -42,6 +47,9 @@ struct Wino4WParams {
 // wino4.hip: 0 or LSPS_E_HIP (lsps_last_error set)
 int wino4_launch_pack(const Wino4Pack &p, hipStream_t st);
 int wino4_launch(const Wino4Params &p, hipStream_t st);
+// sum of `ks` partial conv outputs part[ks][planes][1024] -> InstanceNorm (+ LeakyReLU(slope) | + residual) -> out, rstd[planes]
+int wino4_launch_split_reduce_in(const float *part, int ks, int planes, const float *residual, float *out, float *rstd, float eps,
+                                 float slope, hipStream_t st);
 int wino4_launch_wgrad(const Wino4WParams &p, int splits, float *dW, int waves /*4 or 8 per workgroup*/, hipStream_t st);
 
 }  // namespace lsps

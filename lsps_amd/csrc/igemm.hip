@@ -148,6 +148,25 @@ static char *g_pc_arena = nullptr;
 static size_t g_pc_bytes = 0, g_pc_used = 0;
 static PackEntry g_pc_tab[512];
 static int g_pc_n = 0;
+static unsigned g_pc_scope = 0;            // counts begin() calls
+
+// Second, PERSISTENT table for weights the caller declares frozen across scopes (lsps_pack_cache_frozen): the estimate modes
+// never step the generator (lsps_trainer.py:220-262 steps dis_opt only), yet every post_update re-packed its ~45 weight
+// tensors (64 launches of a ~330-launch step).  Entries live in the caller's second arena until the caller announces a new
+// epoch (its weights changed), another address range or another arena.  An entry packed in an EARLIER scope is complete for
+// every stream (scopes are separated by the caller's stream joins and its optimizer step); inside the scope that packed it
+// the same-stream rule of the step table applies.
+struct FrozenCache {
+  const char *lo = nullptr, *hi = nullptr;
+  char *arena = nullptr;
+  size_t bytes = 0, used = 0;
+  unsigned long long epoch = 0;
+  bool active = false;
+  int n = 0;
+  PackEntry tab[512];
+  unsigned scope[512];
+};
+static FrozenCache g_fz;
 
 static bool pack_key_eq(const PackKey &a, const PackKey &b) {
   return a.W == b.W && a.M == b.M && a.Mp == b.Mp && a.RED == b.RED && a.REDp == b.REDp && a.T == b.T && a.HxWx == b.HxWx &&
@@ -160,6 +179,23 @@ static bool pack_key_eq(const PackKey &a, const PackKey &b) {
 static void *pack_cache_find(const PackKey &k, size_t need, bool *hit, hipStream_t st) {
   *hit = false;
   if (!g_pc_arena) return nullptr;
+  if (g_fz.active && (const char *)k.W >= g_fz.lo && (const char *)k.W < g_fz.hi) {
+    for (int i = 0; i < g_fz.n; ++i)
+      if ((g_fz.tab[i].st == st || g_fz.scope[i] != g_pc_scope) && pack_key_eq(g_fz.tab[i].key, k)) {
+        *hit = true;
+        return g_fz.tab[i].cls;
+      }
+    if (g_fz.n < 512 && g_fz.used + need <= g_fz.bytes) {
+      void *cls = g_fz.arena + g_fz.used;
+      g_fz.used += align_up(need, 256);
+      g_fz.tab[g_fz.n].key = k;
+      g_fz.tab[g_fz.n].cls = cls;
+      g_fz.tab[g_fz.n].st = st;
+      g_fz.scope[g_fz.n] = g_pc_scope;
+      ++g_fz.n;
+      return cls;
+    }
+  }                                        // frozen arena full: the step table below
   for (int i = 0; i < g_pc_n; ++i)
     if (g_pc_tab[i].st == st && pack_key_eq(g_pc_tab[i].key, k)) {
       *hit = true;
@@ -320,11 +356,32 @@ static bool wino4_ok(int N, int Cin, int H, int M) {
   return mode == 2 || (long)N * (M / 32) >= 128;
 }
 
+// Reduction split of the same kernel for the launches 'auto' keeps away from it: the estimate modes run the generator on
+// 4 + 4 samples (lsps_trainer.py:238), i.e. 32 - 64 workgroups.  `ks` splits of >= 32 channels each bring the grid to ~256
+// workgroups; the partial plain outputs are summed by the InstanceNorm kernel that follows anyway (w4_split_reduce_in_kernel).
+// Measured per conv + norm at N = 8 / N = 4 (profiles/r4e_estimate3_kernel_stats.txt): F(2x2) kernel / split direct kernel +
+// reduce + norm 58 / 66 us before.  0 = not applicable.
+static int wino4_split(int N, int Cin, int H, int M) {
+  const int mode = wino_mode();
+  if ((mode != 1 && mode != 2) || g_math_mode != 0 || H != 32 || (M % 32) != 0 || (Cin % 64) != 0) return 0;
+  static int off = -1;
+  if (off < 0) {
+    const char *e = getenv("LSPS_WINO4_SPLIT");
+    off = (e && e[0] == '0') ? 1 : 0;
+  }
+  const long wgs = (long)N * (M / 32);
+  if (off || wgs >= 128) return 0;
+  int ks = (int)(256 / wgs);
+  if (ks > 8) ks = 8;
+  while (ks > 1 && ((Cin % ks) != 0 || ((Cin / ks) % 32) != 0)) --ks;
+  return ks > 1 ? ks : 0;
+}
+
 static size_t wino_bytes(int Cin, int M) { return (size_t)36 * Cin * M * sizeof(float); }   // U: 36 (F4) / 16 (F2) positions x [M][Cin]
 
 static int run_wino4(const float *in, const float *W, const float *bias, float *out, int N, int Cin, int M, long sm, long sc,
                      const TapList &l, int act, float slope, void *ws, size_t ws_bytes, hipStream_t st, const float *addend,
-                     int norm, float *rstd, float eps) {
+                     int norm, float *rstd, float eps, int ksplit = 0) {
   const size_t need = (size_t)36 * Cin * M * sizeof(float);
   PackKey k = {W, M, M, Cin * 36, Cin * 36, 9, 32 * 32, 32, /*cc: marks the F(4x4,3x3) layout*/ 1 << 21, sm, sc, 2166136261u};
   for (int i = 0; i < 9; ++i) k.taphash = (k.taphash ^ (unsigned)(l.idx[i] * 961 + i)) * 16777619u;
@@ -354,13 +411,32 @@ static int run_wino4(const float *in, const float *W, const float *bias, float *
   memset(&p, 0, sizeof(p));
   p.X = in;
   p.U = U;
+  p.M = M;
+  p.N = N;
+  if (ksplit > 1) {
+    // partial plain outputs behind U (when U sits in the call's workspace) / at the head of the workspace (U cached)
+    const size_t uoff = (slot == ws) ? align_up(need, 256) : 0;
+    const size_t part_bytes = (size_t)ksplit * N * M * 1024 * sizeof(float);
+    if (uoff + part_bytes > ws_bytes) {
+      set_error("conv workspace too small: need %zu, have %zu", uoff + part_bytes, ws_bytes);
+      return LSPS_E_WS;
+    }
+    float *part = (float *)((char *)ws + uoff);
+    p.Y = part;
+    p.Cx = Cin / ksplit;
+    p.Ctot = Cin;
+    p.ksplit = ksplit;
+    p.act = LSPS_ACT_NONE;
+    int rc = wino4_launch(p, st);
+    if (rc) return rc;
+    note_kernel("wino4_f3x3_kernel");
+    return wino4_launch_split_reduce_in(part, ksplit, N * M, norm == 2 ? addend : nullptr, out, rstd, eps, norm == 2 ? -1.f : slope, st);
+  }
   p.bias = bias;
   p.R = addend;
   p.Y = out;
   p.rstd = rstd;
   p.Cx = Cin;
-  p.M = M;
-  p.N = N;
   p.act = act;
   p.slope = slope;
   p.norm = norm;
@@ -1534,6 +1610,29 @@ int lsps_pack_cache_begin(void *arena, size_t bytes) {
   g_pc_bytes = bytes;
   g_pc_used = 0;
   g_pc_n = 0;
+  ++g_pc_scope;
+  return 0;
+}
+
+int lsps_pack_cache_frozen(const void *lo, const void *hi, void *arena, size_t bytes, unsigned long long epoch) {
+  using lsps::g_fz;
+  if (!lo) {                               // no frozen weights in the scopes that follow (the table keeps its entries)
+    g_fz.active = false;
+    return 0;
+  }
+  LSPS_CHECK_ARG(hi > lo && arena && bytes >= ((size_t)1 << 20) && (((uintptr_t)arena) & 255) == 0,
+                 "pack_cache_frozen: need lo < hi and a 256-byte aligned arena of >= 1 MiB");
+  if (g_fz.lo != (const char *)lo || g_fz.hi != (const char *)hi || g_fz.arena != (char *)arena || g_fz.bytes != bytes ||
+      g_fz.epoch != epoch) {
+    g_fz.lo = (const char *)lo;
+    g_fz.hi = (const char *)hi;
+    g_fz.arena = (char *)arena;
+    g_fz.bytes = bytes;
+    g_fz.epoch = epoch;
+    g_fz.used = 0;
+    g_fz.n = 0;
+  }
+  g_fz.active = true;
   return 0;
 }
 
@@ -1576,7 +1675,8 @@ int lsps_conv2d_in_fwd(const float *x, const float *w, const float *residual, fl
   LSPS_CHECK_ARG(x && w && y && rstd && ws, "conv2d_in_fwd: null pointer");
   LSPS_CHECK_ARG(conv_args_ok(N, C, H, W, K, 3, 3, 1, 1), "conv2d_in_fwd: unsupported geometry");
   LSPS_CHECK_ARG(!(residual && slope >= 0.f), "conv2d_in_fwd: residual and activation are exclusive (reference block forms)");
-  if (W == 32 && wino4_ok(N, C, H, K)) {
+  const int ksplit = (W == 32 && !wino4_ok(N, C, H, K)) ? wino4_split(N, C, H, K) : 0;
+  if (W == 32 && (ksplit || wino4_ok(N, C, H, K))) {
     TapList l;
     l.T = 9;
     for (int t = 0; t < 9; ++t) {
@@ -1585,7 +1685,7 @@ int lsps_conv2d_in_fwd(const float *x, const float *w, const float *residual, fl
       l.idx[t] = t;
     }
     return run_wino4(x, w, nullptr, y, N, C, K, (long)C * 9, 9L, l, LSPS_ACT_NONE, slope, ws, ws_bytes, (hipStream_t)stream,
-                     residual, residual ? 2 : 1, rstd, eps);
+                     residual, residual ? 2 : 1, rstd, eps, ksplit);
   }
   // other shapes / modes: the conv kernel the dispatcher picks, then the in-place InstanceNorm pass
   int rc = run_forward_dir(x, w, nullptr, y, N, C, H, W, K, H, W, 3, 3, 1, 1, (long)C * 9, 9L, LSPS_ACT_NONE, 1.f, ws, ws_bytes,

@@ -15,8 +15,16 @@ int wino4_launch_pack(const Wino4Pack &p, hipStream_t st) {
 
 int wino4_launch(const Wino4Params &p, hipStream_t st) {
   if (int rc = lds_optin(reinterpret_cast<const void *>(wino4_f3x3_kernel), (int)W4_LDS_BYTES, "wino4_f3x3")) return rc;
-  hipLaunchKernelGGL(wino4_f3x3_kernel, dim3(p.N * (p.M / 32)), dim3(512), W4_LDS_BYTES, st, p);
+  hipLaunchKernelGGL(wino4_f3x3_kernel, dim3(p.N * (p.M / 32) * (p.ksplit > 1 ? p.ksplit : 1)), dim3(512), W4_LDS_BYTES, st, p);
   LSPS_CHECK_LAUNCH("wino4_f3x3");
+  return 0;
+}
+
+int wino4_launch_split_reduce_in(const float *part, int ks, int planes, const float *residual, float *out, float *rstd, float eps,
+                                 float slope, hipStream_t st) {
+  hipLaunchKernelGGL(w4_split_reduce_in_kernel, dim3(planes), dim3(256), 0, st, part, ks, (long)planes * 1024, residual, out, rstd,
+                     eps, slope);
+  LSPS_CHECK_LAUNCH("w4_split_reduce_in");
   return 0;
 }
 

@@ -100,6 +100,10 @@ def run(opts, trainer_factory=None, loader_a=None, loader_b=None, test_batches=N
         torch.cuda.set_device(device)
         if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not torch.distributed.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            # torch's flight recorder is OFF by default (profiles/r4b_drain_probe.txt); dist.drain_watchdog needs it to
+            # confirm that RCCL's watchdog holds no eager work before a data-parallel step is captured into a hipGraph
+            os.environ.setdefault('TORCH_FR_BUFFER_SIZE', os.environ.get('TORCH_NCCL_TRACE_BUFFER_SIZE', '2000'))   # (torch < 2.9: TORCH_NCCL_TRACE_BUFFER_SIZE)
+            os.environ.setdefault('TORCH_NCCL_TRACE_BUFFER_SIZE', os.environ['TORCH_FR_BUFFER_SIZE'])
             torch.distributed.init_process_group('nccl', device_id=device)
         trainer = getattr(trainers, hp['trainer'])(hp)                                   # :99-102
         iterations = 0

@@ -101,6 +101,7 @@ class GradReducer(object):
             for i in range(a0, a1):
                 self.bucket_of[i] = b
         self._pending = None
+        self._seen = {}
         self._works = []
         self._launched = None
         self._sig = None
@@ -115,37 +116,49 @@ class GradReducer(object):
 
     # ---- per-backward protocol -------------------------------------------------------------
     def begin(self, sig=None, expected=None, scalars=None):
-        """Call before backward.  `sig`: hashable step signature (see class doc); `expected`: explicit iterable of
-        parameter indices that WILL get a gradient (overrides what was learned for `sig`).  `scalars`: a small device
-        tensor (the step's loss scalars) summed over ranks by one tiny all-reduce that is launched here, ahead of the
-        buckets, and hides under backward; read it back with `reduced_scalars()` after `finish()`."""
+        """Call before the step's (first) backward.  `sig`: hashable step signature (see class doc); `expected`: explicit
+        iterable of parameter indices that WILL get a gradient (overrides what was learned for `sig`).  `scalars`: a small
+        device tensor (the step's loss scalars) summed over ranks by one tiny all-reduce that is launched here, ahead of the
+        buckets, and hides under backward (`add_scalars` does the same later, for steps whose scalars only exist after a
+        first partial backward); read it back with `reduced_scalars()` after `finish()`.
+        A step may run SEVERAL backward passes between `begin` and `finish` (the estimate modes differentiate their two
+        independent loss terms separately): a parameter's gradient is then accumulated — and its hook fires — once per pass
+        that reaches it, so what is learned and counted down per parameter is the NUMBER of accumulations."""
         self._works = []
         self._launched = [False] * len(self.buckets)
         self._late = False
         self._sig = sig
         self._scalars = None
         self._pending = None
+        self._seen = {}
         if not self.active:
             return
         if scalars is not None:
-            self._scalars = scalars
-            self._works.append(dist.all_reduce(scalars, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.add_scalars(scalars)
         if expected is None and sig is not None:
             expected = self._learned.get(sig)
         if expected is None:
             return
+        self._expected = dict(expected) if isinstance(expected, dict) else dict((i, 1) for i in expected)
         self._pending = [0] * len(self.buckets)
-        self._expected = set(expected)
-        for i in self._expected:
-            self._pending[self.bucket_of[i]] += 1
+        for i, cnt in self._expected.items():
+            self._pending[self.bucket_of[i]] += cnt
+
+    def add_scalars(self, scalars):
+        if self.active and scalars is not None:
+            self._scalars = scalars
+            self._works.append(dist.all_reduce(scalars, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_grad_ready(self, i):
+        self._seen[i] = self._seen.get(i, 0) + 1
         if self._pending is None:
             return
         b = self.bucket_of[i]
-        if self._launched[b] or i not in self._expected:
-            if self._launched[b]:
-                self._late = True             # raised in finish(): raising inside an autograd hook would be swallowed
+        if self._launched[b] or self._seen[i] > self._expected.get(i, 0):
+            # raised in finish(): raising inside an autograd hook would be swallowed.  (An accumulation beyond the learned
+            # count for a bucket still waiting is just as wrong: the bucket would leave one accumulation early.)
+            if self._launched[b] or i in self._expected:
+                self._late = True
             return
         self._pending[b] -= 1
         if self._pending[b] == 0:
@@ -163,8 +176,9 @@ class GradReducer(object):
         if not self.active:
             return
         if self._late:
-            raise RuntimeError("GradReducer: a gradient arrived for a bucket that was already all-reduced; the step "
-                               "signature %r does not determine which parameters get gradients" % (self._sig,))
+            raise RuntimeError("GradReducer: a gradient arrived for a bucket that was already all-reduced (or more often "
+                               "than learned); the step signature %r does not determine which parameters get gradients"
+                               % (self._sig,))
         touched = self.arena.touched
         early = sum(self._launched)
         for b, (i0, i1) in enumerate(self.buckets):
@@ -181,8 +195,8 @@ class GradReducer(object):
         if timed:
             e1.record()                        # the launch stream stalls between e0 and e1 = the exposed part
             self._exposed_events.append((e0, e1))
-        if self._sig is not None:
-            self._learned[self._sig] = tuple(i for i, t in enumerate(touched) if t)
+        if self._sig is not None:                  # accumulations per parameter in this step (hook calls)
+            self._learned[self._sig] = dict((i, self._seen.get(i, 1)) for i, t in enumerate(touched) if t)
         self.stats['steps'] += 1
         self.stats['buckets'] += sum(self._launched)
         self.stats['early'] += early
@@ -245,28 +259,58 @@ def drain_watchdog(timeout_s=5.0):
     (hipErrorCapturedEvent, which the watchdog turns into a process abort) once the process group's stream has joined a
     hipGraph capture.  Before a data-parallel step is captured the list must therefore be EMPTY, not just complete.  The
     list itself is not visible from Python, but the flight recorder is: an entry stays 'active' until the watchdog has
-    seen its work finished and dropped it (`_dump_nccl_trace(onlyActive=True)`).  Needs the recorder on
-    (TORCH_NCCL_TRACE_BUFFER_SIZE > 0, torch's default); with it off, or on a torch without the call, the drain cannot
-    be confirmed and the caller keeps the step eager."""
-    import pickle
+    seen its work finished and dropped it (`_dump_nccl_trace(onlyActive=True)`).  Needs the recorder ON — it is off unless
+    TORCH_FR_BUFFER_SIZE (torch < 2.9: TORCH_NCCL_TRACE_BUFFER_SIZE) is set before the process group is created
+    (profiles/r4b_drain_probe.txt); bench.py and depth_train.py set it.  With it off, or on a torch without the call, the
+    drain cannot be confirmed and the caller keeps the step eager."""
     import time
     if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != 'nccl':
         return True                        # no watchdog to race with
     torch.cuda.synchronize()               # every eager collective has finished on the device
-    try:
-        from torch._C._distributed_c10d import _dump_nccl_trace as dump
-        seen = pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=False)).get('entries')
-    except Exception:                      # noqa: BLE001  (no recorder in this build)
-        return False
-    if not seen:                           # recorder off: an empty 'active' list would prove nothing
+    seen = _fr_entries(False)
+    if not seen:                           # recorder off (or no such call): an empty 'active' list would prove nothing
         return False
     t0 = time.time()
     while time.time() - t0 < timeout_s:
-        active_ = pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=True)).get('entries')
-        if not active_:
+        active_ = _fr_entries(True)
+        if active_ is not None and not [e for e in active_ if _fr_id(e) not in _captured_ids]:
             return True
         time.sleep(0.02)
     return False
+
+
+# Collectives issued WHILE a hipGraph is captured are recorded by the flight recorder too, but the watchdog never tracks them
+# (they only run in replays), so their entries stay 'scheduled' for ever: they must not count as pending eager work.
+_captured_ids = set()
+
+
+def _fr_entries(only_active):
+    import pickle
+    try:
+        from torch._C._distributed_c10d import _dump_nccl_trace as dump
+        return pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=only_active)).get('entries')
+    except Exception:                      # noqa: BLE001  (no recorder in this build)
+        return None
+
+
+def _fr_id(e):
+    return (e.get('pg_id'), e.get('record_id', e.get('collective_seq_id')), e.get('time_created_ns'))
+
+
+def capture_begin():
+    """Call right before a hipGraph capture of a data-parallel step; hand the result to `capture_end`."""
+    if not capturable():
+        return None
+    return set(_fr_id(e) for e in (_fr_entries(False) or ()))
+
+
+def capture_end(before):
+    """Marks the flight-recorder entries born during the capture (see `_captured_ids`)."""
+    if before is None:
+        return
+    for e in (_fr_entries(False) or ()):
+        if _fr_id(e) not in before:
+            _captured_ids.add(_fr_id(e))
 
 
 def agree_all(flag, device=None):

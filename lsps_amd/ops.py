@@ -1399,6 +1399,28 @@ def weight_cache_end():
     _lib.check(_lib.lib().lsps_pack_cache_end(), 'pack_cache_end')
 
 
+_frozen_arenas = {}
+FROZEN_CACHE_BYTES = 1 << 29        # the generator's panels for the forward direction: 28 x 9.4 MB of F(4x4,3x3) U + small ones
+
+
+def weight_cache_frozen(flat_params=None, epoch=0):
+    """Declares the weights inside `flat_params` (a flat parameter arena) unchanged ACROSS the scopes that follow, until
+    `epoch` changes (lsps_pack_cache_frozen): their packed panels survive `weight_cache_end()`.  None: no frozen weights."""
+    import os
+    L = _lib.lib()
+    if flat_params is None or os.environ.get('LSPS_NO_PACK_CACHE') == '1' or os.environ.get('LSPS_NO_FROZEN_PACKS') == '1':
+        _lib.check(L.lsps_pack_cache_frozen(None, None, None, 0, 0), 'pack_cache_frozen')
+        return False
+    key = (flat_params.device.type, flat_params.device.index)
+    buf = _frozen_arenas.get(key)
+    if buf is None:
+        buf = _frozen_arenas[key] = torch.empty(FROZEN_CACHE_BYTES, dtype=torch.uint8, device=flat_params.device)
+    lo = flat_params.data_ptr()
+    _lib.check(L.lsps_pack_cache_frozen(lo, lo + flat_params.numel() * flat_params.element_size(), buf.data_ptr(), buf.numel(),
+                                        int(epoch) & 0xffffffffffffffff), 'pack_cache_frozen')
+    return True
+
+
 def axpy(x, y, alpha=1.0):
     """x + alpha*y (GaussianNoiseLayer: common_net.py:39-40; reparameterisation: lsps_nets.py:78)."""
     if x.numel() == 0:

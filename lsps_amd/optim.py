@@ -39,7 +39,8 @@ class FlatArena(object):
         self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
         self.touched = [False] * len(self.params)
-        self._hooks = []
+        self.generation = 0                             # bumped whenever flat_p is written behind torch's back (Adam kernel,
+        self._hooks = []                                # replica broadcast): see epoch()
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             view = self.flat_p[o:o + p.numel()].view(p.shape)
             view.copy_(p.data)
@@ -58,6 +59,13 @@ class FlatArena(object):
             if self.on_grad_ready is not None:
                 self.on_grad_ready(i)
         return hook
+
+    def epoch(self):
+        """Change counter of the parameter VALUES: the arena's own writers bump `generation`; writers that go through the
+        Parameter objects (load_state_dict, an in-place op under no_grad) bump torch's per-tensor version counters.  Used to
+        keep packed weight panels across steps while a net is frozen (ops.weight_cache_frozen).  (A write through `p.data`
+        is invisible to both: call `arena.generation += 1` after one.)"""
+        return (self.generation << 32) + (sum(p._version for p in self.params) & 0xffffffff)
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -125,6 +133,7 @@ class FlatAdam(torch.optim.Optimizer):
         params = self.param_groups[0]['params']
         steps = torch.tensor([int(self.state[p]['step']) for p in params], dtype=torch.int64, device=self.arena.device)
         ldist.broadcast_from_rank0([self.arena.flat_p, self.flat_m, self.flat_v, steps])
+        self.arena.generation += 1
         for p, t in zip(params, steps.tolist()):
             self.state[p]['step'] = int(t)
 
@@ -169,6 +178,7 @@ class FlatAdam(torch.optim.Optimizer):
                                     self._dev[0].data_ptr(), self._dev[1].data_ptr(), len(params), int(max_len),
                                     float(g['lr']), float(b1), float(b2), float(g['eps']), float(g['weight_decay']),
                                     float(self.grad_scale), _lib.stream()), 'adam_step')
+        a.generation += 1
         return None
 
     def zero_grad(self, set_to_none=True):

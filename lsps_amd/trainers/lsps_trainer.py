@@ -47,6 +47,7 @@ def _weights_constant(fn):
     import functools
 
     def eager(self, images_a, *a, **k):
+        self._declare_frozen(fn.__name__)
         ops.weight_cache_begin(images_a.device)
         try:
             return fn(self, images_a, *a, **k)
@@ -195,6 +196,19 @@ class LSPSTrainer(nn.Module):
         for opt in (self.dis_opt, self.gen_opt, self.vae_opt):
             opt.sync_from_rank0()
 
+    def _declare_frozen(self, method):
+        """post_update never steps the generator (the estimate modes train the discriminator / regressor only,
+        lsps_trainer.py:220-262): its packed weight panels are kept from step to step until the generator's weights change
+        (FlatArena.epoch).  The other update methods declare nothing frozen.  Returns the epoch in force (or None)."""
+        arena = self.gen_opt.arena
+        if method == 'post_update' and arena is not None:
+            ep = arena.epoch()
+            if ops.weight_cache_frozen(arena.flat_p, ep):
+                return ep
+            return None
+        ops.weight_cache_frozen(None)
+        return None
+
     def _side_stream(self, device):
         """Second HIP stream for the independent branch of the estimate modes (LSPS_NO_OVERLAP=1: none).  Also under data
         parallelism: the gradient hooks run in the AccumulateGrad nodes, which the engine executes on the launch stream after
@@ -202,7 +216,8 @@ class LSPSTrainer(nn.Module):
         if os.environ.get('LSPS_NO_OVERLAP') == '1':
             return None
         if self._side is None:
-            self._side = torch.cuda.Stream(device=device)
+            # LSPS_SIDE_PRIO=-1: a high-priority stream (its quarter-chip launches are the step's critical chain)
+            self._side = torch.cuda.Stream(device=device, priority=int(os.environ.get('LSPS_SIDE_PRIO', '0')))
             # the discriminator's AccumulateGrad nodes live on the main stream while part of their gradients now arrive from
             # the side stream: intended (the engine synchronises them), so the advisory warning is switched off
             fn = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
@@ -229,8 +244,15 @@ class LSPSTrainer(nn.Module):
         # math switches of the library, the layout / overlap environment and the arenas' addresses
         sig = (name, _flatten_tensors((args, kwargs), tensors), self.gen.training, self.dis.training, self.vae.training,
                self.map.training, ops.get_winograd(), ops.get_math_mode(),
-               tuple(os.environ.get(k) for k in ('LSPS_CHWN', 'LSPS_CHWN_MIN_N', 'LSPS_NO_OVERLAP', 'LSPS_NO_PACK_CACHE')),
+               tuple(os.environ.get(k) for k in ('LSPS_CHWN', 'LSPS_CHWN_MIN_N', 'LSPS_NO_OVERLAP', 'LSPS_NO_PACK_CACHE', 'LSPS_EST_SPLIT_BACKWARD', 'LSPS_EST_ORDER')),
                tuple(int(o.arena.flat_p.data_ptr()) for o in (self.dis_opt, self.gen_opt, self.vae_opt) if o.arena is not None))
+        if name == 'post_update':
+            # a captured post_update holds no pack launches for the frozen generator (they were cache hits at capture): it is
+            # only valid while that cache is — same generator epoch — and graphs of older epochs can never be replayed again
+            ep = self._declare_frozen(name)
+            sig = sig + (('gen_epoch', ep),)
+            for old in [k for k in self._graphs if k[0] == 'post_update' and k[-1] != ('gen_epoch', ep)]:
+                del self._graphs[old]
         g = self._graphs.get(sig)
         if g is not None:
             return g.replay(self, args, kwargs)
@@ -249,20 +271,29 @@ class LSPSTrainer(nn.Module):
                 return eager(self, *args, **kwargs)
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
-        g = self._graphs[sig] = _GraphedUpdate(self, eager, args, kwargs, self._graph_pool)
+        fence = lsps_dist.capture_begin()
+        try:
+            g = self._graphs[sig] = _GraphedUpdate(self, eager, args, kwargs, self._graph_pool)
+        finally:
+            lsps_dist.capture_end(fence)
         # the capture only recorded the launches: run them once for this call's result
         return g.replay(self, args, kwargs)
 
-    def _step(self, key, opt, loss, names, tensors, sig):
+    def _step(self, key, opt, loss, names, tensors, sig, begun=False):
         """backward + gradient exchange + optimizer step + publication of the step's scalars (stored as numpy values like
         the reference, ONE device->host copy).  `sig` identifies the graph of this step for the reducer: it learns which
         parameters get gradients under that signature and launches each bucket during backward (lsps_amd/dist.py).  Under
         data parallelism the scalars are summed over ranks by one tiny all-reduce launched BEFORE backward (they are
         forward results), so publishing costs no second host synchronisation.  While a hipGraph is being captured the
-        optimizer step and the host copy are left to the replay (`_finish_step`)."""
+        optimizer step and the host copy are left to the replay (`_finish_step`).
+        `begun`: the caller opened the step itself (`_begin_backward`) and already ran a first partial backward; `loss`
+        is the remaining term."""
         red = self._reducers[key]
         scal = torch.stack([t.detach().reshape(()).float() for t in tensors])
-        red.begin(sig, scalars=scal if lsps_dist.active() else None)
+        if begun:
+            red.add_scalars(scal if lsps_dist.active() else None)
+        else:
+            red.begin(sig, scalars=scal if lsps_dist.active() else None)
         try:
             loss.backward()
             red.finish()
@@ -272,6 +303,10 @@ class LSPSTrainer(nn.Module):
             self._capturing.pending = (key, opt, list(names), scal)
             return
         self._finish_step(opt, names, scal, red.reduced_scalars())
+
+    def _begin_backward(self, key, sig):
+        """Opens the gradient exchange of a step whose loss terms are differentiated one by one (post_update)."""
+        self._reducers[key].begin(sig)
 
     def _finish_step(self, opt, names, scal, mean):
         opt.step()
@@ -435,19 +470,71 @@ class LSPSTrainer(nn.Module):
             # the stream of its forward).  Same kernels, same arithmetic; per-stream workspaces and pack-cache entries.
             side = self._side_stream(images_a.device)
             main = torch.cuda.current_stream(images_a.device)
+            # Schedule (profiles/r4c_estimate3_timeline_*.txt).  The two branches share nothing but the discriminator's
+            # weights, and the loss is their weighted SUM, so d loss = reg_w d reg + feature_w_reg d feat can be taken one term
+            # at a time: the regression term is differentiated as soon as its forward has been launched, i.e. its whole
+            # forward + backward (~110 launches that each fill the chip) runs beside the generator pass of the feature
+            # branch (~200 launches that fill a quarter of it) instead of waiting for that pass to end — with ONE backward
+            # over the summed loss nothing of either backward could start before the generator pass had finished.
+            # The two partial gradients meet in the parameters' AccumulateGrad nodes: each discriminator weight gets one
+            # contribution per term, and a + b = b + a in floating point, so the result is bit-identical to the single
+            # backward (tests/test_parity_gpu.py: overlapped == serial, bitwise).  Launch order: regression first — its few
+            # big kernels are in flight while the host (or hipGraphLaunch, which submits nodes in capture order) is still
+            # submitting the feature branch's small ones.
+            split = side is not None and os.environ.get('LSPS_EST_SPLIT_BACKWARD', '1') != '0'
+            sig = ('post_update', int(mode))
+
+            def regression_branch():
+                terms_reg.append(regression(self.dis.regress_a, images_a, labels_a, noise.get('vae_a')))
+                if mode == 4:
+                    terms_reg.append(regression(self.dis.regress_b, images_b, labels_b, noise.get('vae_b')))
             if side is not None:
                 side.wait_stream(main)
-            with torch.cuda.stream(side if side is not None else main):
-                with torch.no_grad():
-                    x_aa, x_ba, x_ab, x_bb, _ = self.gen(first_a, first_b, noise=noise.get('gen'))
-                f_x_aa, f_x_ba, f_x_ab, f_x_bb = self.dis.feats(x_aa, x_ba, x_ab, x_bb)
-                terms_feat.append(self._compute_ll_loss(f_x_ab, f_x_aa))
-                terms_feat.append(self._compute_ll_loss(f_x_ba, f_x_bb))
-            terms_reg.append(regression(self.dis.regress_a, images_a, labels_a, noise.get('vae_a')))
-            if mode == 4:
-                terms_reg.append(regression(self.dis.regress_b, images_b, labels_b, noise.get('vae_b')))
+            def regression_backward():
+                self._begin_backward('dis', sig)
+                (hp['reg_w'] * sum(terms_reg[1:], terms_reg[0])).backward()
+
+            def feature_forward():
+                with torch.cuda.stream(side if side is not None else main):
+                    with torch.no_grad():
+                        outs = self.gen(first_a, first_b, noise=noise.get('gen'))[:4]
+                    f_x_aa, f_x_ba, f_x_ab, f_x_bb = self.dis.feats(*outs)
+                    terms_feat.append(self._compute_ll_loss(f_x_ab, f_x_aa))
+                    terms_feat.append(self._compute_ll_loss(f_x_ba, f_x_bb))
+                return outs
+            # hipGraphLaunch executes the FIRST-captured branch behind a fork while it is still submitting the step's
+            # ~300 nodes; the other branch only starts once everything is submitted (~2.5 ms in; profiles/r4e_*).  Orders:
+            #   'chain'      regression forward, THEN fork: [generator pass, feature forward | regression backward], feature
+            #                backward: the late branch is the regression backward alone (default)
+            #   'feat_first' fork at once: [generator pass, feature forward | regression forward + backward]
+            #   'reg_first'  fork at once: [regression forward + backward | generator pass, feature forward]
+            order = os.environ.get('LSPS_EST_ORDER', 'chain') if split else 'serial'
+            if order == 'chain':
+                regression_branch()
+                side.wait_stream(main)
+                x_aa, x_ba, x_ab, x_bb = feature_forward()
+                regression_backward()
+            elif order == 'reg_first':
+                regression_branch()
+                regression_backward()
+                x_aa, x_ba, x_ab, x_bb = feature_forward()
+            else:
+                x_aa, x_ba, x_ab, x_bb = feature_forward()
+                if split:
+                    regression_branch()
+                    regression_backward()
+            if split:
+                reg_loss = sum(terms_reg[1:], terms_reg[0]).detach()
+            if not split:
+                regression_branch()
             if side is not None:
                 main.wait_stream(side)
+            if split:
+                feat_loss = hp['feature_w_reg'] * (terms_feat[0] + terms_feat[1])
+                total_loss = hp['reg_w'] * reg_loss + feat_loss
+                self._step('dis', self.dis_opt, feat_loss, ['dis_reg_loss', 'dis_total_loss'], [reg_loss, total_loss], sig,
+                           begun=True)
+                return (x_aa, x_ba, x_ab, x_bb, x_aa, x_bb, x_aa, x_bb)
         reg_loss = sum(terms_reg[1:], terms_reg[0])
         total_loss = hp['reg_w'] * reg_loss
         if terms_feat:

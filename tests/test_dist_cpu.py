@@ -421,3 +421,81 @@ def test_estimate_first4_broadcast_slices_by_the_real_count():
     import lsps_amd.trainers.lsps_trainer as lt
     src = inspect.getsource(lt.LSPSTrainer.post_update)
     assert 'first[:na], first[na:]' in src and 'first[0:4], first[4:8]' not in src
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 4: a step may differentiate its loss terms in SEVERAL backward passes (post_update: the regression term first,
+# beside the generator pass of the feature term).  The reducer learns the number of accumulations per parameter and
+# launches a bucket only after the LAST one.
+# ---------------------------------------------------------------------------------------------------------------
+def _multi_pass_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        from lsps_amd import dist as ldist
+        from lsps_amd.optim import FlatArena
+        torch.manual_seed(5)
+        ps = [torch.nn.Parameter(torch.randn(64, 64)) for _ in range(6)]
+        arena = FlatArena(ps)
+        red = ldist.GradReducer(arena, bucket_bytes=2 * 64 * 64 * 4)           # 3 buckets of 2 parameters
+        assert len(red.buckets) == 3
+        x = torch.full((64,), float(rank + 1))
+        log = []
+        orig = red._launch
+
+        def launch(b):
+            log.append(('launch', b, dict(red._seen)))
+            orig(b)
+        red._launch = launch
+        res = []
+        for it in range(3):
+            arena.zero_grad()
+            del log[:]
+            red.begin(('two_terms',))
+            term_a = sum((p @ x).sum() for p in ps[:4])                      # parameters 0..3
+            term_b = sum((p @ x).pow(2).sum() for p in ps[2:])                # parameters 2..5  (2, 3 are reached twice)
+            term_a.backward()
+            launched_after_first = [e[1] for e in log]
+            term_b.backward()
+            early = sum(red._launched)
+            red.finish()
+            res.append(dict(learned=dict(red._learned[('two_terms',)]), after_first=launched_after_first, early=early,
+                            order=[e[1] for e in log], g=arena.flat_g.clone()))
+        # reference: one backward over the sum, all-reduced by hand
+        for p in ps:
+            p.grad = None
+        (sum((p @ x).sum() for p in ps[:4]) + sum((p @ x).pow(2).sum() for p in ps[2:])).backward()
+        ref = torch.cat([p.grad.reshape(-1) for p in ps])
+        dist.all_reduce(ref)
+        out.put((rank, [dict(r, g=bool(torch.equal(r['g'], ref))) for r in res]))
+    except Exception as e:
+        import traceback
+        out.put((rank, 'error', repr(e) + traceback.format_exc()))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_reducer_counts_accumulations_of_a_multi_pass_step():
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_multi_pass_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(out.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in got:
+        assert res != 'error', got
+        first, second, third = res
+        assert first['learned'] == {0: 1, 1: 1, 2: 2, 3: 2, 4: 1, 5: 1}
+        assert first['early'] == 0 and first['g']                          # learning step: everything from finish()
+        for r in (second, third):
+            assert r['g'], "sum of the two passes, all-reduced"
+            # bucket 0 = parameters 4, 5 (readiness order: the arena's tail), bucket 1 = 2, 3, bucket 2 = 0, 1
+            assert r['after_first'] == [2], r                              # only the bucket whose members are done after pass 1
+            assert r['early'] == 3 and sorted(r['order']) == [0, 1, 2], r   # the others DURING the second pass, none early

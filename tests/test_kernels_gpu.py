@@ -794,6 +794,52 @@ def test_conv3x3_winograd_f4_wgrad(case):
         ops.set_winograd(prev)
 
 
+@pytest.mark.parametrize("case", [(8, 256, 256, 4), (4, 256, 256, 8), (2, 256, 256, 8), (15, 256, 256, 2), (5, 128, 64, 4), (1, 64, 32, 2),
+                                  (3, 192, 32, 6), (16, 256, 256, 0), (4, 32, 32, 0)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("form", ["lrelu", "residual"])
+def test_conv3x3_instance_norm_small_batch_reduction_split(case, form, monkeypatch):
+    """The estimate modes run the generator on 4 + 4 samples (lsps_trainer.py:238): under the DEFAULT dispatch such launches take
+    the F(4x4,3x3) kernel with the input channels split over `ks` workgroups per (image, k slice) and the partial outputs
+    summed inside the InstanceNorm kernel (igemm.hip: wino4_split).  Against f64, incl. rstd; case = (N, C, K, expected ks;
+    0 = the path must NOT be taken: grid already fills the chip / channels not splittable)."""
+    _need_gpu()
+    from lsps_amd import _lib, ops
+    N, C, K, ks = case
+    L = _lib.lib()
+    assert ops.get_winograd() == 'auto'
+    x = _rand(N, C, 32, 32, seed=31)
+    w = _rand(K, C, 3, 3, seed=32, scale=0.1)
+    res = _rand(N, K, 32, 32, seed=33) if form == 'residual' else None
+    slope = 0.01 if form == 'lrelu' else -1.0
+    c0 = F.conv2d(x.double(), w.double(), None, padding=1)
+    ref = F.instance_norm(c0, eps=1e-5)
+    ref = F.leaky_relu(ref, 0.01) if form == 'lrelu' else ref + res.double()
+    rstd_ref = 1.0 / torch.sqrt(c0.var(dim=(2, 3), unbiased=False) + 1e-5)
+    xd, wd = x.cuda(), w.cuda()
+    rd = res.cuda() if res is not None else None
+    ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, 32, 32, K, 3, 3, 1, 1), xd.device)
+
+    def run():
+        y = torch.full((N, K, 32, 32), float('nan'), device='cuda')
+        rstd = torch.empty(N * K, device='cuda')
+        _lib.check(L.lsps_conv2d_in_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(rd), _lib.ptr(y), _lib.ptr(rstd), N, C, 32, 32, K,
+                                        slope, 1e-5, ws, wsb, _lib.stream()), 'conv2d_in_fwd')
+        return y, rstd, [L.lsps_last_kernel(None).decode()]
+    y, rstd, names = run()
+    split = ks > 0
+    assert ('wino4_f3x3_kernel' in names) == (split or N * (K // 32) >= 128), names
+    assert _rel(y, ref) < W4_TOL, _rel(y, ref)
+    assert _rel(rstd.view(N, K), rstd_ref) < 2e-5
+    # the switch: LSPS_WINO4_SPLIT is read once per process, so compare against the composed path through the mode instead
+    ops.set_winograd('off')
+    try:
+        y0, rstd0, names0 = run()
+    finally:
+        ops.set_winograd('auto')
+    assert 'wino4_f3x3_kernel' not in names0
+    assert _rel(y, y0.cpu()) < W4_TOL
+
+
 @pytest.mark.parametrize("case", [(3, 256, 32, 256), (4, 64, 32, 64), (2, 8, 32, 32), (2, 64, 16, 64), (3, 24, 8, 40), (1, 16, 32, 48)],
                          ids=lambda c: "x".join(map(str, c)))
 @pytest.mark.parametrize("form", ["lrelu", "residual", "plain"])

@@ -459,6 +459,56 @@ def test_post_update_overlapped_branches_match_serial_bitwise(mode, monkeypatch)
             assert np.array_equal(o[1][k], outs[0][1][k]), k
 
 
+@pytest.mark.parametrize("graphs", [False, True])
+def test_frozen_generator_packs_survive_steps_and_follow_weight_changes(graphs, monkeypatch):
+    """The estimate modes never step the generator (lsps_trainer.py:220-262), so its packed weight panels are kept from one
+    post_update to the next (lsps_pack_cache_frozen).  Bitwise against a run that re-packs in every step, over a sequence that
+    also CHANGES the generator between estimate steps three ways — a gen_update (Adam kernel: arena generation), a
+    load_state_dict (torch version counters), the order post / post / gen_update / post / load / post — eager and from hipGraphs
+    (a captured post_update holds no generator pack launches: it must be re-captured once the weights moved)."""
+    A = _adapter()
+    hp = cases.hp_for('tiny')
+    sds = cases.make_weights(hp, lsps_ref)
+    sds2 = cases.make_weights(hp, lsps_ref)
+    sds2['gen'] = {k: (v * 1.25).astype(v.dtype) for k, v in sds2['gen'].items()}
+    b = cases.make_inputs(8)
+    lat, lat1, zd = cases.latent_shape(hp, 8), cases.latent_shape(hp, 8), hp['vae']['z_dim']
+    outs = []
+    for frozen in (True, False):
+        if frozen:
+            monkeypatch.delenv('LSPS_NO_FROZEN_PACKS', raising=False)
+        else:
+            monkeypatch.setenv('LSPS_NO_FROZEN_PACKS', '1')
+        tr = A.make_trainer(hp, sds)
+        tr.use_graphs(graphs)
+        A.set_train(tr, True)
+        trace, epochs = [], []
+
+        def post(rnd):
+            A.post_update(tr, b, 3, hp, cases.noise(lat, 90 + rnd), cases.noise((8, zd), 91 + rnd, 0.05),
+                          cases.noise((8, zd), 92 + rnd, 0.05))
+            trace.append(A.scalars(tr))
+            epochs.append(tr.gen_opt.arena.epoch())
+        post(0)
+        post(1)
+        post(2)
+        A.gen_update(tr, b, hp, (cases.noise(cases.latent_shape(hp, 16), 95), cases.noise(lat1, 96), cases.noise(lat1, 97)))
+        post(3)
+        post(4)
+        tr.gen.load_state_dict({k: torch.as_tensor(v) for k, v in sds2['gen'].items()})
+        post(5)
+        post(6)
+        assert epochs[0] == epochs[1] == epochs[2] and epochs[3] == epochs[4] and epochs[5] == epochs[6]
+        assert len(set(epochs)) == 3, epochs                      # every way of changing the weights moved the counter
+        if graphs:
+            assert sum(1 for k in tr._graphs if k[0] == 'post_update') == 1      # graphs of older generator epochs are dropped
+        outs.append((trace, A.params(tr, 'dis'), A.params(tr, 'gen')))
+    assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+    for net in (1, 2):
+        for k in outs[0][net]:
+            assert np.array_equal(outs[0][net][k], outs[1][net][k]), k
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 5])
 def test_ragged_batches_against_oracle(n):
     """Edge cases the reference's code paths have: batch smaller than the [0:4] slice of post_update
