@@ -459,7 +459,7 @@ def main():
         roofline = None
         traffic = None
         traffic_file = None
-        tfiles = ('r2t_traffic.json', 'r2_traffic.json', 'r1_traffic.json') if args.dtype == 'f32' else ('r3l_traffic_bf16.json',)
+        tfiles = ('r4_traffic.json', 'r2t_traffic.json') if args.dtype == 'f32' else ('r4_traffic_bf16.json', 'r3l_traffic_bf16.json')
         for tf in tfiles:               # PMC traffic is collected offline (rocprofv3 --pmc cannot run inside the timed bench)
             try:
                 with open(os.path.join(REPO, 'profiles', tf)) as f:

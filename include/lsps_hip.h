@@ -305,6 +305,17 @@ int lsps_convT2d_wgrad(const float *x, const float *dy, float *dw, float *db,
 int lsps_conv2d_in_fwd(const float *x, const float *w, const float *residual /*nullable*/, float *y, float *rstd,
                        int N, int C, int H, int W, int K, float slope, float eps,
                        void *ws, size_t ws_bytes, void *stream);
+/* The same call for a pass that NO backward follows (torch.no_grad(): the generator inside dis_update / post_update,
+ * lsps_trainer.py:145-146,238-241; evaluation).  Identical contract; the difference is dispatch freedom: the estimate modes run
+ * the generator on 4 + 4 samples (lsps_trainer.py:238), 32 - 64 workgroups of the F(4x4,3x3) kernel, so here such launches
+ * split the input channels over up to 8 workgroups per (image, k slice) and sum the partial outputs inside the norm kernel
+ * (58 -> 42 us per conv + norm at N = 8).  F(4x4,3x3) rounds at 8e-6 of abs-max where the F(2x2,3x3) / direct kernels that
+ * lsps_conv2d_in_fwd keeps for few-image launches round at 5e-7: irrelevant for an output (north_star: 1e-3), but a training
+ * step's gradient is discontinuous in its forward pass (LeakyReLU kinks, sign() of the L1 losses), and the golden step cases at
+ * N = 2 pin Adam's first sign decisions — so passes that are differentiated keep the kernels those vectors were checked with. */
+int lsps_conv2d_in_fwd_nograd(const float *x, const float *w, const float *residual /*nullable*/, float *y, float *rstd,
+                              int N, int C, int H, int W, int K, float slope, float eps,
+                              void *ws, size_t ws_bytes, void *stream);
 
 /* ---- InstanceNorm2d(affine=False) [+ LeakyReLU] [+ residual add], fused --------------------
  * call sites: common_net.py:168-171 (norm + in-place LeakyReLU), :177-181 (norm, out += residual).

@@ -31,6 +31,7 @@ _SIGNATURES = {
     'lsps_conv2d_workspace_bytes': (c_size_t, [c_int] * 9),
     'lsps_conv2d_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [c_int, c_float, _P, c_size_t, _P]),
     'lsps_conv2d_in_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [c_float, c_float, _P, c_size_t, _P]),
+    'lsps_conv2d_in_fwd_nograd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [c_float, c_float, _P, c_size_t, _P]),
     'lsps_conv2d_dgrad': (c_int, [_P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
     'lsps_conv2d_dgrad_acc': (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_size_t, _P]),
     'lsps_conv2d_dgrad_inbwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [c_float, _P, c_size_t, _P]),

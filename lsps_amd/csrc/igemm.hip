@@ -1669,13 +1669,27 @@ int lsps_conv2d_fwd(const float *x, const float *w, const float *bias, float *y,
                          slope, ws, ws_bytes, (hipStream_t)stream);
 }
 
+static int conv2d_in_fwd_impl(const float *x, const float *w, const float *residual, float *y, float *rstd, int N, int C, int H,
+                              int W, int K, float slope, float eps, void *ws, size_t ws_bytes, void *stream, bool no_backward);
+
 int lsps_conv2d_in_fwd(const float *x, const float *w, const float *residual, float *y, float *rstd, int N, int C, int H,
                        int W, int K, float slope, float eps, void *ws, size_t ws_bytes, void *stream) {
+  return conv2d_in_fwd_impl(x, w, residual, y, rstd, N, C, H, W, K, slope, eps, ws, ws_bytes, stream, false);
+}
+
+int lsps_conv2d_in_fwd_nograd(const float *x, const float *w, const float *residual, float *y, float *rstd, int N, int C, int H,
+                              int W, int K, float slope, float eps, void *ws, size_t ws_bytes, void *stream) {
+  return conv2d_in_fwd_impl(x, w, residual, y, rstd, N, C, H, W, K, slope, eps, ws, ws_bytes, stream, true);
+}
+
+static int conv2d_in_fwd_impl(const float *x, const float *w, const float *residual, float *y, float *rstd, int N, int C, int H,
+                              int W, int K, float slope, float eps, void *ws, size_t ws_bytes, void *stream, bool no_backward) {
   (void)hipGetLastError();
   LSPS_CHECK_ARG(x && w && y && rstd && ws, "conv2d_in_fwd: null pointer");
   LSPS_CHECK_ARG(conv_args_ok(N, C, H, W, K, 3, 3, 1, 1), "conv2d_in_fwd: unsupported geometry");
   LSPS_CHECK_ARG(!(residual && slope >= 0.f), "conv2d_in_fwd: residual and activation are exclusive (reference block forms)");
-  const int ksplit = (W == 32 && !wino4_ok(N, C, H, K)) ? wino4_split(N, C, H, K) : 0;
+  // few-image launches of a pass that no backward follows (the estimate modes' generator): reduction-split F(4x4,3x3)
+  const int ksplit = (no_backward && W == 32 && !wino4_ok(N, C, H, K)) ? wino4_split(N, C, H, K) : 0;
   if (W == 32 && (ksplit || wino4_ok(N, C, H, K))) {
     TapList l;
     l.T = 9;

@@ -156,6 +156,8 @@ class LSPSTrainer(nn.Module):
         self._graph_pool = None
         self._capturing = None
         self._side = None
+        self._frozen_decided = None
+        self._gen_epoch_last = None
 
     # ------------------------------------------------------------------ device / arenas
     def cuda(self, gpu=None):
@@ -198,16 +200,24 @@ class LSPSTrainer(nn.Module):
 
     def _declare_frozen(self, method):
         """post_update never steps the generator (the estimate modes train the discriminator / regressor only,
-        lsps_trainer.py:220-262): its packed weight panels are kept from step to step until the generator's weights change
-        (FlatArena.epoch).  The other update methods declare nothing frozen.  Returns the epoch in force (or None)."""
+        lsps_trainer.py:220-262): its packed weight panels are kept from step to step (ops.weight_cache_frozen) — once the
+        generator's weights have been seen UNCHANGED by two consecutive post_update calls (FlatArena.epoch), i.e. in an
+        estimate loop; a workflow that alternates gen_update and post_update keeps packing per step.  The other update
+        methods declare nothing frozen.  Returns the epoch in force (or None).  Once per call: `_graphed` decides before it
+        looks a graph up, the eager body then finds the decision made."""
+        if self._frozen_decided is not None:
+            ep, self._frozen_decided = self._frozen_decided[0], None
+            return ep
         arena = self.gen_opt.arena
+        ep = None
         if method == 'post_update' and arena is not None:
-            ep = arena.epoch()
-            if ops.weight_cache_frozen(arena.flat_p, ep):
-                return ep
-            return None
-        ops.weight_cache_frozen(None)
-        return None
+            now = arena.epoch()
+            stable, self._gen_epoch_last = (now == self._gen_epoch_last), now
+            if stable and ops.weight_cache_frozen(arena.flat_p, now):
+                ep = now
+        if ep is None:
+            ops.weight_cache_frozen(None)
+        return ep
 
     def _side_stream(self, device):
         """Second HIP stream for the independent branch of the estimate modes (LSPS_NO_OVERLAP=1: none).  Also under data
@@ -247,14 +257,17 @@ class LSPSTrainer(nn.Module):
                tuple(os.environ.get(k) for k in ('LSPS_CHWN', 'LSPS_CHWN_MIN_N', 'LSPS_NO_OVERLAP', 'LSPS_NO_PACK_CACHE', 'LSPS_EST_SPLIT_BACKWARD', 'LSPS_EST_ORDER')),
                tuple(int(o.arena.flat_p.data_ptr()) for o in (self.dis_opt, self.gen_opt, self.vae_opt) if o.arena is not None))
         if name == 'post_update':
-            # a captured post_update holds no pack launches for the frozen generator (they were cache hits at capture): it is
-            # only valid while that cache is — same generator epoch — and graphs of older epochs can never be replayed again
+            # a post_update captured while the generator's panels are frozen holds no pack launches for them (they were cache
+            # hits): it is only valid while that cache is — same generator epoch — and such graphs of older epochs can never be
+            # replayed again.  (ep None: nothing frozen, the graph packs for itself and is valid for any weights.)
             ep = self._declare_frozen(name)
+            self._frozen_decided = (ep,)
             sig = sig + (('gen_epoch', ep),)
-            for old in [k for k in self._graphs if k[0] == 'post_update' and k[-1] != ('gen_epoch', ep)]:
+            for old in [k for k in self._graphs if k[0] == 'post_update' and k[-1][1] not in (None, ep)]:
                 del self._graphs[old]
         g = self._graphs.get(sig)
         if g is not None:
+            self._frozen_decided = None
             return g.replay(self, args, kwargs)
         if sig not in self._graph_seen:                  # warm-up call: eager
             self._graph_seen.add(sig)
@@ -295,9 +308,13 @@ class LSPSTrainer(nn.Module):
         else:
             red.begin(sig, scalars=scal if lsps_dist.active() else None)
         try:
+            if not begun and not lsps_dist.active():
+                ops.grad_defer_begin()      # weight gradients go into the arena in a few multi-tensor launches (ops._arena_grads)
             loss.backward()
+            ops.grad_defer_flush()
             red.finish()
         finally:
+            ops._stash.active = False
             ops.weight_cache_end()          # the optimizer is about to change the weights
         if self._capturing is not None:
             self._capturing.pending = (key, opt, list(names), scal)
@@ -307,6 +324,8 @@ class LSPSTrainer(nn.Module):
     def _begin_backward(self, key, sig):
         """Opens the gradient exchange of a step whose loss terms are differentiated one by one (post_update)."""
         self._reducers[key].begin(sig)
+        if not lsps_dist.active():
+            ops.grad_defer_begin()
 
     def _finish_step(self, opt, names, scal, mean):
         opt.step()
@@ -470,17 +489,13 @@ class LSPSTrainer(nn.Module):
             # the stream of its forward).  Same kernels, same arithmetic; per-stream workspaces and pack-cache entries.
             side = self._side_stream(images_a.device)
             main = torch.cuda.current_stream(images_a.device)
-            # Schedule (profiles/r4c_estimate3_timeline_*.txt).  The two branches share nothing but the discriminator's
-            # weights, and the loss is their weighted SUM, so d loss = reg_w d reg + feature_w_reg d feat can be taken one term
-            # at a time: the regression term is differentiated as soon as its forward has been launched, i.e. its whole
-            # forward + backward (~110 launches that each fill the chip) runs beside the generator pass of the feature
-            # branch (~200 launches that fill a quarter of it) instead of waiting for that pass to end — with ONE backward
-            # over the summed loss nothing of either backward could start before the generator pass had finished.
-            # The two partial gradients meet in the parameters' AccumulateGrad nodes: each discriminator weight gets one
-            # contribution per term, and a + b = b + a in floating point, so the result is bit-identical to the single
-            # backward (tests/test_parity_gpu.py: overlapped == serial, bitwise).  Launch order: regression first — its few
-            # big kernels are in flight while the host (or hipGraphLaunch, which submits nodes in capture order) is still
-            # submitting the feature branch's small ones.
+            # Schedule (profiles/r4*_estimate3_timeline_*.txt).  The two branches share nothing but the discriminator's weights,
+            # and the loss is their weighted SUM, so d loss = reg_w d reg + feature_w_reg d feat is taken one term at a time:
+            # the regression term is differentiated right behind its own forward instead of waiting for the generator pass
+            # of the other branch (with ONE backward over the summed loss nothing of either backward can start before both
+            # forwards have ended).  The two partial gradients meet in the parameters' AccumulateGrad nodes: each
+            # discriminator weight gets one contribution per term, and a + b = b + a in floating point, so the result is
+            # bit-identical to the single backward (tests/test_parity_gpu.py: overlapped == serial, bitwise).
             split = side is not None and os.environ.get('LSPS_EST_SPLIT_BACKWARD', '1') != '0'
             sig = ('post_update', int(mode))
 
@@ -502,13 +517,12 @@ class LSPSTrainer(nn.Module):
                     terms_feat.append(self._compute_ll_loss(f_x_ab, f_x_aa))
                     terms_feat.append(self._compute_ll_loss(f_x_ba, f_x_bb))
                 return outs
-            # hipGraphLaunch executes the FIRST-captured branch behind a fork while it is still submitting the step's
-            # ~300 nodes; the other branch only starts once everything is submitted (~2.5 ms in; profiles/r4e_*).  Orders:
-            #   'chain'      regression forward, THEN fork: [generator pass, feature forward | regression backward], feature
-            #                backward: the late branch is the regression backward alone (default)
-            #   'feat_first' fork at once: [generator pass, feature forward | regression forward + backward]
-            #   'reg_first'  fork at once: [regression forward + backward | generator pass, feature forward]
-            order = os.environ.get('LSPS_EST_ORDER', 'chain') if split else 'serial'
+            # Launch / capture order of the branches (measured, profiles/r4f_estimate3_orders.txt; whichever branch is launched
+            # first runs almost alone for its first ~2.5 ms — its kernels fill the chip — so the order decides what the tail is):
+            #   'feat_first' [generator pass, feature forward | regression forward + backward], feature backward   6.88 ms (default)
+            #   'reg_first'  [regression forward + backward | generator pass, feature forward], feature backward   7.18 ms
+            #   'chain'      regression forward, THEN [generator pass, feature forward | regression backward], ...  7.17 ms
+            order = os.environ.get('LSPS_EST_ORDER', 'feat_first') if split else 'serial'
             if order == 'chain':
                 regression_branch()
                 side.wait_stream(main)

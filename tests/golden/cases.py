@@ -91,9 +91,11 @@ def dead_bias_keys(golden):
 #     reference on identical torch kernels: 1.8e-4, 1.1e-6);
 #   * the quantiles bound the ISOLATED flips (LeakyReLU kinks, sign() of the L1 losses: a forward difference of 1e-6 flips a
 #     different set of them).  They are noise, not accuracy: the restatement itself has q90 5.2e-4 / q99 1.65e-3, the product
-#     between q90 8.9e-4 / q99 1.8e-3 (direct kernels) and q90 1.4e-3 / q99 6.6e-3 (F(4x4,3x3) Winograd forward on 4 samples,
-#     forward error 8e-6) depending on which conv algorithm rounds the forward pass; hence q90 <= 2e-3, q99 <= 1e-2.
-GRAD_ROBUST = {'l2': 1e-3, 'mean': 1e-3, 'cosine': 1e-3, 'q99': 1e-2, 'q90': 2e-3}
+#     between q90 8.9e-4 / q99 1.8e-3 (direct and F(2x2,3x3) kernels: what a differentiated pass at these batch sizes runs)
+#     and q90 1.1e-3 / q99 3.2e-3 with the F(4x4,3x3) kernels forced (forward error 8e-6 instead of 5e-7; a reduction-split
+#     F(4x4,3x3) forward at N = 2 measured q90 1.4e-3 / q99 6.6e-3 and is therefore kept to passes without a backward:
+#     include/lsps_hip.h, lsps_conv2d_in_fwd_nograd); hence q90 <= 2e-3, q99 <= 5e-3.
+GRAD_ROBUST = {'l2': 1e-3, 'mean': 1e-3, 'cosine': 1e-3, 'q99': 5e-3, 'q90': 2e-3}
 # ResNeXt generator at 8-64 channels: three LeakyReLU / InstanceNorm stages per block, restatement-vs-reference quantiles 1.4e-2 (99 %) and 1.25e-2 (90 %)
 GRAD_ROBUST_RESX = {'l2': 2e-3, 'mean': 1e-3, 'cosine': 1e-3, 'q99': 3e-2, 'q90': 2e-2}
 
@@ -108,7 +110,7 @@ def compare(results, golden, rtol, atol_scale=1.0, skip=(), grad_rtol=None, grad
     Isolated flips cannot hide a systematically wrong gradient, though, so every gradient tensor must
     ALSO pass the robust criteria of ``grad_robust`` (GRAD_ROBUST): its L2 norm within 1e-3 relative, its mean within 1e-3
     of abs-max, the cosine between its stored elements (full tensor or the 256 seeded samples) and the reference's within
-    1e-3 of 1, 90 % of those elements within 2e-3 and 99 % within 1e-2 of abs-max (isolated kink flips; the restatement of
+    1e-3 of 1, 90 % of those elements within 2e-3 and 99 % within 5e-3 of abs-max (isolated kink flips; the restatement of
     the reference on identical kernels already has a 99th percentile of 1.65e-3).  ``report`` (a dict) receives the worst value per criterion."""
     bad = []
     worst = 0.0

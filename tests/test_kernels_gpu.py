@@ -819,11 +819,11 @@ def test_conv3x3_instance_norm_small_batch_reduction_split(case, form, monkeypat
     rd = res.cuda() if res is not None else None
     ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, C, 32, 32, K, 3, 3, 1, 1), xd.device)
 
-    def run():
+    def run(entry=L.lsps_conv2d_in_fwd_nograd):
         y = torch.full((N, K, 32, 32), float('nan'), device='cuda')
         rstd = torch.empty(N * K, device='cuda')
-        _lib.check(L.lsps_conv2d_in_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(rd), _lib.ptr(y), _lib.ptr(rstd), N, C, 32, 32, K,
-                                        slope, 1e-5, ws, wsb, _lib.stream()), 'conv2d_in_fwd')
+        _lib.check(entry(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(rd), _lib.ptr(y), _lib.ptr(rstd), N, C, 32, 32, K,
+                         slope, 1e-5, ws, wsb, _lib.stream()), 'conv2d_in_fwd')
         return y, rstd, [L.lsps_last_kernel(None).decode()]
     y, rstd, names = run()
     split = ks > 0
@@ -838,6 +838,10 @@ def test_conv3x3_instance_norm_small_batch_reduction_split(case, form, monkeypat
         ops.set_winograd('auto')
     assert 'wino4_f3x3_kernel' not in names0
     assert _rel(y, y0.cpu()) < W4_TOL
+    # the entry a differentiated pass calls never takes the split (the golden step cases at N = 2 pin its kernels)
+    y1, rstd1, names1 = run(L.lsps_conv2d_in_fwd)
+    assert ('wino4_f3x3_kernel' in names1) == (N * (K // 32) >= 128), names1
+    assert _rel(y1, ref) < W4_TOL
 
 
 @pytest.mark.parametrize("case", [(3, 256, 32, 256), (4, 64, 32, 64), (2, 8, 32, 32), (2, 64, 16, 64), (3, 24, 8, 40), (1, 16, 32, 48)],

@@ -111,6 +111,44 @@ def timed(fn, k=100):
     return 1e3 * (time.perf_counter() - t0) / k
 
 
+def host_cost():
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); ga.replay(); t1 = time.perf_counter()
+    with torch.cuda.stream(side):
+        gb.replay()
+    t2 = time.perf_counter()
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    return 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t0)
+
+
+for _ in range(3):
+    host_cost()
+print("host time of ga.replay() %.3f ms, gb.replay() %.3f ms, both finished after %.3f ms" % host_cost())
+import threading
+
+
+def threaded_step():
+    tr.dis.zero_grad()
+    side.wait_stream(main)
+    torch.cuda.synchronize()
+
+    def run_b():
+        with torch.cuda.stream(side):
+            gb.replay()
+    th = threading.Thread(target=run_b)
+    t0 = time.perf_counter()
+    th.start()
+    ga.replay()
+    th.join()
+    main.wait_stream(side)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0)
+
+
+for _ in range(3):
+    threaded_step()
+print("two graphs replayed from two host threads: both finished after %.3f ms" % min(threaded_step() for _ in range(10)))
 print("two graphs, regression first: %.3f ms" % timed(lambda: two_graph_step('a_first')))
 print("two graphs, feature first:    %.3f ms" % timed(lambda: two_graph_step('b_first')))
 print("eager parts (same structure): %.3f ms" % timed(lambda: (eager_step(), tr.dis_opt.step())))
