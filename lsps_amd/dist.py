@@ -258,8 +258,10 @@ def drain_watchdog(timeout_s=5.0):
     Why: the watchdog polls the end events of the collectives on its work list (every ~100 ms); HIP refuses such a query
     (hipErrorCapturedEvent, which the watchdog turns into a process abort) once the process group's stream has joined a
     hipGraph capture.  Before a data-parallel step is captured the list must therefore be EMPTY, not just complete.  The
-    list itself is not visible from Python, but the flight recorder is: an entry stays 'active' until the watchdog has
-    seen its work finished and dropped it (`_dump_nccl_trace(onlyActive=True)`).  Needs the recorder ON — it is off unless
+    list itself is not visible from Python, but the flight recorder is: the watchdog marks an entry `retired` at the moment
+    it drops the finished work from its list (NOT the entry's `state`, which a dump refreshes by querying the events
+    itself: 'completed' right after a device synchronise although the watchdog has not polled yet — r4k's bench under
+    LSPS_FORCE_DP=1 aborted on exactly that).  Needs the recorder ON — it is off unless
     TORCH_FR_BUFFER_SIZE (torch < 2.9: TORCH_NCCL_TRACE_BUFFER_SIZE) is set before the process group is created
     (profiles/r4b_drain_probe.txt); bench.py and depth_train.py set it.  With it off, or on a torch without the call, the
     drain cannot be confirmed and the caller keeps the step eager."""
@@ -270,10 +272,12 @@ def drain_watchdog(timeout_s=5.0):
     seen = _fr_entries(False)
     if not seen:                           # recorder off (or no such call): an empty 'active' list would prove nothing
         return False
+    if 'retired' not in seen[-1]:          # a recorder without the field: nothing to confirm with
+        return False
     t0 = time.time()
     while time.time() - t0 < timeout_s:
-        active_ = _fr_entries(True)
-        if active_ is not None and not [e for e in active_ if _fr_id(e) not in _captured_ids]:
+        ent = _fr_entries(False)
+        if ent is not None and not [e for e in ent if not e.get('retired') and _fr_id(e) not in _captured_ids]:
             return True
         time.sleep(0.02)
     return False

@@ -54,12 +54,28 @@ def _weights_constant(fn):
         finally:
             ops.weight_cache_end()
 
-    @functools.wraps(fn)
-    def wrapped(self, images_a, *a, **k):
+    def with_modes(self, *a, **k):
+        # The library's math / Winograd modes are process-wide (include/lsps_hip.h); a trainer that was given its own
+        # (`set_modes`) installs them for the duration of its update methods, so two trainers in different modes can
+        # alternate in one process (one thread drives one device: no concurrent update methods).
+        if self.math_mode is None and self.winograd is None:
+            return dispatch(self, *a, **k)
+        prev = (ops.get_math_mode(), ops.get_winograd())
+        try:
+            if self.math_mode is not None:
+                ops.set_math_mode(self.math_mode)
+            if self.winograd is not None:
+                ops.set_winograd(self.winograd)
+            return dispatch(self, *a, **k)
+        finally:
+            ops.set_math_mode(prev[0])
+            ops.set_winograd(prev[1])
+
+    def dispatch(self, images_a, *a, **k):
         if not self._graphs_on or (lsps_dist.active() and not lsps_dist.capturable()):
             return eager(self, images_a, *a, **k)
         return self._graphed(fn.__name__, eager, (images_a,) + a, k)
-    return wrapped
+    return functools.wraps(fn)(with_modes)
 
 
 def _flatten_tensors(obj, out):
@@ -158,6 +174,8 @@ class LSPSTrainer(nn.Module):
         self._side = None
         self._frozen_decided = None
         self._gen_epoch_last = None
+        self.math_mode = None               # None: whatever the process-wide mode is (ops.set_math_mode); see set_modes
+        self.winograd = None
 
     # ------------------------------------------------------------------ device / arenas
     def cuda(self, gpu=None):
@@ -182,6 +200,12 @@ class LSPSTrainer(nn.Module):
             self._reducers[key] = lsps_dist.GradReducer(arena, segments=starts)
         self._drop_graphs()                 # captured launches point into the previous arenas
         self.sync_replicas()
+        return self
+
+    def set_modes(self, math_mode=None, winograd=None):
+        """This trainer's own math mode ('f32' | 'bf16' | 'f32_split') and conv algorithm ('auto' | 'off' | 'always' | ...),
+        installed around each of its update methods and restored afterwards; None = follow the process-wide setting."""
+        self.math_mode, self.winograd = math_mode, winograd
         return self
 
     def _drop_graphs(self):

@@ -515,6 +515,51 @@ def test_frozen_generator_packs_survive_steps_and_follow_weight_changes(graphs, 
             assert np.array_equal(outs[0][net][k], outs[1][net][k]), k
 
 
+def test_two_trainers_in_different_math_modes_alternate_in_one_process():
+    """The library's math / Winograd modes are process-wide; `LSPSTrainer.set_modes` installs a trainer's own around each of its
+    update methods (two trainers in different modes could not coexist).  An f32 and a bf16 trainer stepped
+    alternately give, bitwise, what each gives alone under the corresponding process-wide mode — and the process-wide mode is
+    what it was afterwards."""
+    A = _adapter()
+    from lsps_amd import ops
+    hp = cases.hp_for('full')
+    sds = cases.make_weights(hp, lsps_ref)
+    b = cases.make_inputs(2)
+    lat2, lat1 = cases.latent_shape(hp, 4), cases.latent_shape(hp, 2)
+
+    def steps(tr, rounds):
+        out = []
+        for r in rounds:
+            A.dis_update(tr, b, hp, cases.noise(lat2, 500 + r))
+            A.gen_update(tr, b, hp, (cases.noise(lat2, 510 + r), cases.noise(lat1, 520 + r), cases.noise(lat1, 530 + r)))
+            out.append(A.scalars(tr))
+        return out
+    alone = {}
+    for mode in ('f32', 'bf16'):
+        ops.set_math_mode(mode)
+        try:
+            tr = A.make_trainer(hp, sds)
+            A.set_train(tr, True)
+            alone[mode] = (steps(tr, (0, 1)), A.params(tr, 'gen'))
+        finally:
+            ops.set_math_mode('f32')
+    t32, t16 = A.make_trainer(hp, sds), A.make_trainer(hp, sds).set_modes(math_mode='bf16')
+    A.set_train(t32, True)
+    A.set_train(t16, True)
+    tr32, tr16 = [], []
+    for r in (0, 1):
+        tr32 += steps(t32, (r,))
+        assert ops.get_math_mode() == 'f32'
+        tr16 += steps(t16, (r,))
+        assert ops.get_math_mode() == 'f32'
+    assert alone['f32'][0] != alone['bf16'][0], "the bf16 mode did not engage"
+    for mode, trace, tr in (('f32', tr32, t32), ('bf16', tr16, t16)):
+        assert trace == alone[mode][0], mode
+        got = A.params(tr, 'gen')
+        for k, v in alone[mode][1].items():
+            assert np.array_equal(got[k], v), (mode, k)
+
+
 def test_deferred_arena_gradients_equal_autograd_accumulation(monkeypatch):
     """Single process: weight / bias gradients of arena parameters skip autograd's `p.grad +=` launches and are added with a few
     multi-tensor launches at the end of backward (ops._arena_grads, ops.grad_defer_flush).  Same sums in a different order:

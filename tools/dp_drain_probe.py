@@ -29,8 +29,8 @@ if ent:
     print("last entry:", {k: ent[-1][k] for k in ent[-1] if k in ('state', 'profiling_name', 'collective_seq_id', 'retired', 'time_discovered_completed_ns')})
 for i in range(60):
     a = pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=True)).get('entries')
-    print("t=%.3f s active entries: %s" % (time.time() - t0, None if a is None else len(a)))
-    if not a:
+    print("t=%.3f s active entries: %s, not retired: %s" % (time.time() - t0, None if a is None else len(a), len([e for e in pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=False)).get("entries") if not e.get("retired")])))
+    if not [e for e in pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=False)).get("entries") if not e.get("retired")]:
         break
     time.sleep(0.02)
 from lsps_amd import dist as ldist  # noqa: E402
