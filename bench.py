@@ -383,7 +383,7 @@ def main():
         # the loss read-out after the replay): the eager step is bound by the ~400 launches' host side, not by the GPU
         tr.use_graphs(True)
         est_step()                      # warm-up call of this signature was the eager timing above; this one captures
-        t_est = timed(est_step, 20)
+        t_est = timed(est_step, 50)
         tr.use_graphs(False)
         tr.gen.eval()
         with torch.no_grad():

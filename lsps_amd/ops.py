@@ -166,76 +166,6 @@ def convT_out_size(h, r, stride, pad, outpad):
 # ------------------------------------------------------------------------------------------
 # Conv2d (+ fused bias and LeakyReLU/Tanh epilogue)
 # ------------------------------------------------------------------------------------------
-# ------------------------------------------------------------------------------------------
-# Weight / bias gradients of parameters that live in a flat gradient arena (lsps_amd/optim.py) can skip autograd's own
-# accumulation: a training step launches one `p.grad += g` per parameter and backward pass plus one InputBuffer add per
-# extra use of a parameter in the graph (152 launches of ~7 us in the f32 pretrain step, 148 in config 5), each on a
-# tensor of at most 2.4 MB.  While a trainer has deferral on (single process only: the data-parallel reducer wants every
-# gradient the moment it exists), the backward of the functions below hands such gradients to a stash instead of
-# returning them, and `grad_defer_flush` adds them into the arena with a few multi-tensor launches
-# (`torch._foreach_add_`; contributions to the same parameter go into successive rounds, in production order).
-# ------------------------------------------------------------------------------------------
-class _GradStash(object):
-    def __init__(self):
-        self.active = False
-        self.items = []
-
-
-_stash = _GradStash()
-
-
-def grad_defer_begin():
-    import os
-    if os.environ.get('LSPS_DEFER_GRADS', '1') == '0':
-        return False
-    _stash.items = []
-    _stash.active = True
-    return True
-
-
-def grad_defer_flush():
-    """Adds the stashed gradients into their parameters' `.grad` (arena views) and switches deferral off."""
-    items, _stash.items, _stash.active = _stash.items, [], False
-    rounds, count = [], {}
-    for p, g in items:
-        r = count.get(id(p), 0)
-        count[id(p)] = r + 1
-        if r == len(rounds):
-            rounds.append(([], []))
-        rounds[r][0].append(p.grad)
-        rounds[r][1].append(g.reshape(p.grad.shape))
-    for dsts, srcs in rounds:
-        torch._foreach_add_(dsts, srcs)
-    return len(items)
-
-
-def _arena_grads(*positions):
-    """Class decorator: the inputs at `positions` of forward() are parameters (weight, bias, ...)."""
-    def deco(cls):
-        fwd, bwd = cls.forward, cls.backward
-
-        def forward(ctx, *args):
-            ctx._lsps_params = tuple(args[i] if i < len(args) else None for i in positions)
-            return fwd(ctx, *args)
-
-        def backward(ctx, *gs):
-            outs = bwd(ctx, *gs)
-            if _stash.active and isinstance(outs, tuple):
-                outs = list(outs)
-                for i, p in zip(positions, ctx._lsps_params):
-                    slot = getattr(p, '_lsps_slot', None) if p is not None else None
-                    if slot is not None and i < len(outs) and outs[i] is not None and p.grad is not None:
-                        _stash.items.append((p, outs[i]))
-                        slot[0].touched[slot[1]] = True
-                        outs[i] = None
-                outs = tuple(outs)
-            return outs
-        cls.forward = staticmethod(forward)
-        cls.backward = staticmethod(backward)
-        return cls
-    return deco
-
-
 class _EmptyBatchFn(torch.autograd.Function):
     """Empty batch in -> empty batch out, as torch.nn does (the kernels are never launched on zero samples); the
     parameter gradients of an empty batch are zeros."""
@@ -294,7 +224,6 @@ def _act_backward(L, dy, y, act, slope, want_db, channels, ws, wsb, st):
     return dpre, None
 
 
-@_arena_grads(1, 2)
 class _Conv2dFn(torch.autograd.Function):
     """nn.Conv2d [+ nn.LeakyReLU(inplace)] — common_net.py:250-252, 162-163; lsps_nets.py:123-124."""
 
@@ -361,7 +290,6 @@ def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, slope=LRELU_SLOPE):
     return _Conv2dFn.apply(x, w, b, int(stride), int(pad), int(act), float(slope))
 
 
-@_arena_grads(1, 2)
 class _Conv2dGroupedFn(torch.autograd.Function):
     """nn.Conv2d(..., groups=G) — the 3x3 conv of LeakyINSResNeXtBlock (common_net.py:116).  One launch per group on the
     channel slices of the full tensors (lsps_conv2d_grouped_*): no slice copies, no concatenation."""
@@ -421,7 +349,6 @@ def conv2d_grouped(x, w, b=None, stride=1, pad=0, groups=1):
 # ------------------------------------------------------------------------------------------
 # ConvTranspose2d
 # ------------------------------------------------------------------------------------------
-@_arena_grads(1, 2)
 class _ConvT2dFn(torch.autograd.Function):
     """nn.ConvTranspose2d [+ LeakyReLU / Tanh] — common_net.py:262-264; lsps_nets.py:17-23, 226-229."""
 
@@ -534,7 +461,6 @@ def conv3x3s2_chwn_ok(N, C, H, W, K):
     return _lib.lib().lsps_conv3x3s2_chwn_workspace_bytes(N, C, H, W, K) > 0 and get_math_mode() == 'f32'
 
 
-@_arena_grads(1, 2)
 class _ConvS2CHWNFn(torch.autograd.Function):
     """LeakyReLUConv2d(C, K, 3, 2, 1) (common_net.py:250-252) on x [C][H][W][N] -> [K][H/2][W/2][N]."""
 
@@ -631,7 +557,6 @@ class _InormFn(torch.autograd.Function):
         return dy, (dout if ctx.has_res and ctx.needs_input_grad[1] else None), None
 
 
-@_arena_grads(1, 2)
 class _ResBlockFn(torch.autograd.Function):
     """LeakyINSResBlock as ONE autograd node: x + IN(conv3x3(LReLU(IN(conv3x3(x))))) (common_net.py:160-181, stride 1).
     Same kernels as the composed form; what the fusion buys is the backward: the gradient arriving over the skip
@@ -639,7 +564,7 @@ class _ResBlockFn(torch.autograd.Function):
     3-pass add by autograd, and five saved-tensor / node hand-offs disappear."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2):
+    def forward(ctx, x, w1, w2, nograd=False):
         L = _lib.lib()
         x, w1, w2 = _c(x), _c(w1), _c(w2)
         N, C, H, W = x.shape
@@ -654,9 +579,10 @@ class _ResBlockFn(torch.autograd.Function):
         r2 = torch.empty_like(r1)
         # conv + InstanceNorm (+ LeakyReLU | + skip) in ONE call each: on 32x32 maps the Winograd F(4x4,3x3) kernel owns
         # whole (n, k) planes and normalises in its epilogue; other shapes run conv + the in-place norm pass in the library
-        # a pass nobody differentiates (torch.no_grad(): needs_input_grad is all False) may take the few-image dispatch of
+        # a pass nobody differentiates (the caller saw torch.no_grad(): inside forward() grad mode is always off, and
+        # needs_input_grad follows the weights' requires_grad whatever the mode) may take the few-image dispatch of
         # lsps_conv2d_in_fwd_nograd (include/lsps_hip.h)
-        in_fwd = L.lsps_conv2d_in_fwd if any(ctx.needs_input_grad) else L.lsps_conv2d_in_fwd_nograd
+        in_fwd = L.lsps_conv2d_in_fwd_nograd if nograd else L.lsps_conv2d_in_fwd
         with profiler.span(flops):
             _lib.check(in_fwd(_lib.ptr(x), _lib.ptr(w1), None, _lib.ptr(a1), _lib.ptr(r1), N, C, H, W, K,
                               LRELU_SLOPE, IN_EPS, ws, wsb, st), 'conv2d_in_fwd')
@@ -702,7 +628,7 @@ class _ResBlockFn(torch.autograd.Function):
             with profiler.span(flops):
                 _lib.check(L.lsps_conv2d_dgrad_acc(_lib.ptr(dh1), _lib.ptr(w1), _lib.ptr(g), _lib.ptr(dx), N, C, H, W, K, 3, 3,
                                                    1, 1, ws, wsb, st), 'conv2d_dgrad_acc')
-        return dx, dw1, dw2
+        return dx, dw1, dw2, None
 
 
 # ------------------------------------------------------------------------------------------
@@ -853,7 +779,6 @@ def _c8_act_backward(L, dy, y, slope, want_db, channels, st):
     return g, db
 
 
-@_arena_grads(1, 2)
 class _ConvS2C8Fn(torch.autograd.Function):
     """LeakyReLUConv2d(C, K, 3, 2, 1) (common_net.py:246-256) on a C8 tensor: x [N][C/8][H][W][8] -> [N][K/8][H/2][W/2][8]."""
 
@@ -914,7 +839,6 @@ def conv3x3s2_c8(x, w, b=None, slope=LRELU_SLOPE, prev=None, own=None):
     return _ConvS2C8Fn.apply(x, w, b, float(slope), prev, own)
 
 
-@_arena_grads(1, 2)
 class _ConvTS2C8Fn(torch.autograd.Function):
     """LeakyReLUConvTranspose2d(Ci, Co, 3, 2, 1, 1) (common_net.py:258-268) on a C8 tensor:
     x [N][Ci/8][H][W][8] -> [N][Co/8][2H][2W][8]."""
@@ -984,7 +908,6 @@ def c8_stem_ok(x, w, stride, pad):
     return N > 0 and _lib.lib().lsps_c8_stem_ok(N, H, W, w.shape[0], w.shape[2], w.shape[3], stride, pad) == 1
 
 
-@_arena_grads(1, 2)
 class _StemC8Fn(torch.autograd.Function):
     """LeakyReLUConv2d(1, K, 7, stride, 3) (lsps_nets.py:117,184): f32 image in, C8 bf16 activation out.  Backward: weight and
     bias gradient in ONE kernel from (x, dy, saved y) — the LeakyReLU backward is applied while dy is staged."""
@@ -1049,7 +972,6 @@ def c8_pw1_ok(x, w, stride, pad, outpad):
     return _c8_enabled() and is_c8(x) and tuple(w.shape) == (x.shape[1] * 8, 1, 1, 1) and stride == 1 and pad == 0 and outpad == 0
 
 
-@_arena_grads(1, 2)
 class _Pw1C8Fn(torch.autograd.Function):
     """ConvTranspose2d(C, 1, kernel 1) [+ Tanh] on a C8 tensor (lsps_nets.py:226-229): x [N][C/8][H][W][8] -> y f32 [N,1,H,W]."""
 
@@ -1116,7 +1038,6 @@ def pw1_c8(x, w, b=None, act=ACT_NONE, slope=LRELU_SLOPE, prev=None):
     return _Pw1C8Fn.apply(x, w, b, int(act), float(slope), prev)
 
 
-@_arena_grads(1, 2)
 class _ResBlockC8Fn(torch.autograd.Function):
     """LeakyINSResBlock on C8 tensors as ONE autograd node (common_net.py:160-181): both convs run c8_conv3x3_kernel with
     the InstanceNorm (+ LeakyReLU | + skip) in the epilogue; backward = norm-2 backward, two transposing-read weight
@@ -1197,7 +1118,7 @@ def res_block(x, w1, w2):
     """x + IN(conv3x3(LReLU(IN(conv3x3(x, w1))), w2)) — LeakyINSResBlock (common_net.py:160-181), one autograd node."""
     if x.shape[0] == 0:
         return _empty(x, x.shape, w1, w2)
-    return _ResBlockFn.apply(x, w1, w2)
+    return _ResBlockFn.apply(x, w1, w2, not torch.is_grad_enabled())
 
 
 def instance_norm_(y, residual=None, slope=-1.0):
@@ -1292,7 +1213,6 @@ def bce_sigmoid(logits, target):
 # ------------------------------------------------------------------------------------------
 # pose-MLP linear
 # ------------------------------------------------------------------------------------------
-@_arena_grads(1, 2)
 class _LinearFn(torch.autograd.Function):
     """nn.Linear (+ LeakyReLU | Softplus) — lsps_nets.py:44-50, 73-83; common_net.py:221-231."""
 
@@ -1384,7 +1304,6 @@ def mul_add(x, t, m):
     return _MulAddFn.apply(x, t, m)
 
 
-@_arena_grads(1, 2)
 class _BnormFn(torch.autograd.Function):
     """nn.BatchNorm2d / nn.BatchNorm1d [+ nn.LeakyReLU] of the BN block variants (common_net.py:183-322).  `x`: [N, C, ...]."""
 

@@ -46,7 +46,6 @@ class FlatArena(object):
             view.copy_(p.data)
             p.data = view
             p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
-            p._lsps_slot = (self, i)                        # ops._arena_grads: this parameter's gradient lives in an arena
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.on_grad_ready = None                       # set by dist.GradReducer
         # (bias index, weight index) of convs whose bias is mathematically dead (trainers/common_net.py:_mark_dead_bias)

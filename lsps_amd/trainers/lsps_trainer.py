@@ -332,13 +332,9 @@ class LSPSTrainer(nn.Module):
         else:
             red.begin(sig, scalars=scal if lsps_dist.active() else None)
         try:
-            if not begun and not lsps_dist.active():
-                ops.grad_defer_begin()      # weight gradients go into the arena in a few multi-tensor launches (ops._arena_grads)
             loss.backward()
-            ops.grad_defer_flush()
             red.finish()
         finally:
-            ops._stash.active = False
             ops.weight_cache_end()          # the optimizer is about to change the weights
         if self._capturing is not None:
             self._capturing.pending = (key, opt, list(names), scal)
@@ -348,8 +344,6 @@ class LSPSTrainer(nn.Module):
     def _begin_backward(self, key, sig):
         """Opens the gradient exchange of a step whose loss terms are differentiated one by one (post_update)."""
         self._reducers[key].begin(sig)
-        if not lsps_dist.active():
-            ops.grad_defer_begin()
 
     def _finish_step(self, opt, names, scal, mean):
         opt.step()
