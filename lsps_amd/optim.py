@@ -24,6 +24,7 @@ from . import _lib
 
 class FlatArena(object):
     """Re-homes `params` (already on the target device) into flat p/g buffers."""
+    _uids = 0
 
     def __init__(self, params):
         self.params = [p for p in params]
@@ -41,6 +42,8 @@ class FlatArena(object):
         self.touched = [False] * len(self.params)
         self.generation = 0                             # bumped whenever flat_p is written behind torch's back (Adam kernel,
         self._hooks = []                                # replica broadcast): see epoch()
+        FlatArena._uids += 1                            # process-unique: a later arena may be handed the SAME device addresses
+        self.uid = FlatArena._uids                      # by the caching allocator, with equal generation and version counts
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             view = self.flat_p[o:o + p.numel()].view(p.shape)
             view.copy_(p.data)
@@ -64,8 +67,9 @@ class FlatArena(object):
         """Change counter of the parameter VALUES: the arena's own writers bump `generation`; writers that go through the
         Parameter objects (load_state_dict, an in-place op under no_grad) bump torch's per-tensor version counters.  Used to
         keep packed weight panels across steps while a net is frozen (ops.weight_cache_frozen).  (A write through `p.data`
-        is invisible to both: call `arena.generation += 1` after one.)"""
-        return (self.generation << 32) + (sum(p._version for p in self.params) & 0xffffffff)
+        is invisible to both: call `arena.generation += 1` after one.)  The arena's process-unique id is part of the value:
+        two arenas never share an epoch, even when the allocator gives the second one the first one's addresses."""
+        return ((self.uid & 0xffff) << 48) | ((self.generation & 0xffffff) << 24) | (sum(p._version for p in self.params) & 0xffffff)
 
     def zero_grad(self):
         self.flat_g.zero_()

@@ -53,6 +53,7 @@ def _weights_constant(fn):
             return fn(self, images_a, *a, **k)
         finally:
             ops.weight_cache_end()
+            ops.weight_cache_frozen(None)   # the promise ends with the method: scopes opened elsewhere see no frozen weights
 
     def with_modes(self, *a, **k):
         # The library's math / Winograd modes are process-wide (include/lsps_hip.h); a trainer that was given its own

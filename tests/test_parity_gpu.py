@@ -479,7 +479,19 @@ def test_frozen_generator_packs_survive_steps_and_follow_weight_changes(graphs, 
             monkeypatch.delenv('LSPS_NO_FROZEN_PACKS', raising=False)
         else:
             monkeypatch.setenv('LSPS_NO_FROZEN_PACKS', '1')
+        if frozen:
+            # a DECOY first: another trainer with other generator weights fills the frozen table, then goes away — the caching
+            # allocator hands its arena's addresses to the next trainer, whose generation / version counts are the same
+            decoy = A.make_trainer(hp, sds2)
+            A.set_train(decoy, True)
+            for rnd in range(3):
+                A.post_update(decoy, b, 3, hp, cases.noise(lat, 70 + rnd), cases.noise((8, zd), 71 + rnd, 0.05),
+                              cases.noise((8, zd), 72 + rnd, 0.05))
+            decoy_ptr = decoy.gen_opt.arena.flat_p.data_ptr()
+            del decoy
         tr = A.make_trainer(hp, sds)
+        if frozen and not graphs:
+            print("arena address reused by the next trainer:", tr.gen_opt.arena.flat_p.data_ptr() == decoy_ptr)
         tr.use_graphs(graphs)
         A.set_train(tr, True)
         trace, epochs = [], []
