@@ -98,15 +98,43 @@ struct CGParams {
   int act;
   float slope;
   int splits;
+  int grouped;                   // mode 1 only: blockIdx.z / splits indexes a GROUP of output positions with ~4 taps in total
 };
 
+// dgrad (mode 1) computes one tile per INPUT position of the conv, and a position receives 1, 2, 2 or 4 taps by its (row, column)
+// parity: one workgroup per position means workgroups of 1x ... 4x the work, and whenever the grid is about one round of the
+// chip's resident slots (N = 128: 1024 workgroups) the kernel lasts as long as its 4-tap workgroups while the 1-tap ones leave
+// their slots idle (tools/bench_chwn.py 128: dgrad 69 TFLOP/s next to forward's 96 - 111).  Grouped, a workgroup walks
+//   type A: the odd-odd position of one 2x2 block (4 taps) | type B: its two mixed positions (2 + 2) | type C: the even-even
+//   positions of four consecutive blocks (1 + 1 + 1 + 1)
+// one after the other: every workgroup does ~4 taps (border positions lose the taps that fall outside).
+__device__ __forceinline__ int chwn_group_size(int g, int Ho, int Wo) {
+  const int NB = (Ho >> 1) * (Wo >> 1);
+  return g < NB ? 1 : (g < 2 * NB ? 2 : 4);
+}
+__device__ __forceinline__ int chwn_group_pos(int g, int i, int Ho, int Wo) {       // i-th position of group g (all uniform)
+  const int bw = Wo >> 1, NB = (Ho >> 1) * bw;
+  if (g < NB) return (2 * (g / bw) + 1) * Wo + 2 * (g % bw) + 1;
+  if (g < 2 * NB) {
+    const int b = g - NB, y = 2 * (b / bw), x = 2 * (b % bw);
+    return i == 0 ? y * Wo + x + 1 : (y + 1) * Wo + x;
+  }
+  const int b = 4 * (g - 2 * NB) + i;
+  return (2 * (b / bw)) * Wo + 2 * (b % bw);
+}
+
+template <bool GROUPED>
 __global__ __launch_bounds__(256, 4) void chwn_gemm_kernel(CGParams p) {
   __shared__ __attribute__((aligned(16))) float As[2][CG_BK][128], Bs[2][CG_BK][128];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1, l31 = lane & 31, half = lane >> 5;
   const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
-  const int pos = blockIdx.z / p.splits, sp = blockIdx.z - pos * p.splits;
+  const int zi = blockIdx.z / p.splits, sp = blockIdx.z - zi * p.splits;
+  const int npos = GROUPED ? chwn_group_size(zi, p.Ho, p.Wo) : 1;
+#pragma clang loop unroll(disable)
+  for (int gi = 0; gi < npos; ++gi) {
+  const int pos = GROUPED ? __builtin_amdgcn_readfirstlane(chwn_group_pos(zi, gi, p.Ho, p.Wo)) : zi;
   const int oh = pos / p.Wo, ow = pos - oh * p.Wo;
 
   // valid taps of this position, packed 4 bits each (uniform)
@@ -214,7 +242,10 @@ __global__ __launch_bounds__(256, 4) void chwn_gemm_kernel(CGParams p) {
   }
 
   // epilogue: register r of acc[i][j] = row m0 + wm*64 + i*32 + (r & 3) + 8 (r >> 2) + 4 half, column n0 + wn*64 + j*32 + l31
-  const long plane = (long)p.Ho * p.Wo * p.N;
+  long plane = (long)p.Ho * p.Wo * p.N;
+  // (inside the position loop the per-lane output addresses are loop-invariant up to `pos`; hoisted, their 32 64-bit values
+  // live through the main loop and spill — keep them a post-loop computation, as in the one-position kernel)
+  if (GROUPED) asm volatile("" : "+s"(plane));
   float *out = p.splits > 1 ? p.part + (long)sp * p.Md * plane : p.Y;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -230,6 +261,7 @@ __global__ __launch_bounds__(256, 4) void chwn_gemm_kernel(CGParams p) {
         out[(long)m * plane + (long)pos * p.N + n] = v;
       }
     }
+  }                                                    // next position of the group (the loop above ended on a barrier)
 }
 
 // Y = act(bias + sum of the reduction splits)
@@ -456,7 +488,9 @@ size_t lsps_conv3x3s2_chwn_workspace_bytes(int N, int C, int H, int W, int K) {
   if (!chwn_geom_ok(N, C, H, W, K)) return 0;
   const int P = H / 2, Q = W / 2;
   const size_t pack = (size_t)9 * C * K * sizeof(float);
-  const size_t fs = (size_t)chwn_gemm_splits(K, C, N, P * Q), ds = (size_t)chwn_gemm_splits(C, K, N, H * W);
+  size_t fs = (size_t)chwn_gemm_splits(K, C, N, P * Q), ds = (size_t)chwn_gemm_splits(C, K, N, H * W);
+  const size_t dsg = (size_t)chwn_gemm_splits(C, K, N, H * W >= 64 ? 9 * (H / 2) * (W / 2) / 4 : H * W);   // dgrad, grouped positions
+  if (dsg > ds) ds = dsg;
   const size_t fpart = fs > 1 ? fs * K * P * Q * N * sizeof(float) : 0, dpart = ds > 1 ? ds * C * H * W * N * sizeof(float) : 0;
   const size_t wpart = (size_t)chwn_wgrad_splits(K, C, N, P, Q) * 9 * K * C * sizeof(float);
   size_t m = pack + (fpart > dpart ? fpart : dpart);
@@ -482,12 +516,25 @@ static int chwn_run_gemm(const float *A, const float *B, const float *bias, floa
   p.mode = mode;
   p.act = act;
   p.slope = slope;
-  p.splits = chwn_gemm_splits(Md, Rd, N, Ho * Wo);
-  if ((long)Ho * Wo * p.splits > 65535) {
+  static int group_env = -1;
+  if (group_env < 0) {
+    const char *e = getenv("LSPS_CHWN_GROUP");
+    group_env = (e && e[0] == '0') ? 0 : 1;
+  }
+  // dgrad: positions grouped by tap count (see chwn_group_positions); maps of at least 4 x 4 positions (NB % 4 == 0)
+  // (measured, tools/bench_chwn.py, profiles/r4s_chwn_grouped_dgrad.txt: 8x8 ... 32x32 input maps gain 8 - 15 % at N = 128 and 768;
+  // on the 4x4 map — 9 groups — the lower occupancy costs more than the balance gives: per-position workgroups stay)
+  p.grouped = (mode == 1 && group_env && (Ho % 2) == 0 && (Wo % 2) == 0 && Ho * Wo >= 64) ? 1 : 0;
+  const int nz = p.grouped ? 9 * (Ho / 2) * (Wo / 2) / 4 : Ho * Wo;
+  p.splits = chwn_gemm_splits(Md, Rd, N, nz);
+  if ((long)nz * p.splits > 65535) {
     set_error("conv3x3s2_chwn: %d x %d output positions x %d splits exceed the grid", Ho, Wo, p.splits);
     return LSPS_E_ARG;
   }
-  hipLaunchKernelGGL(chwn_gemm_kernel, dim3(ceil_div(N, 128), Md / 128, Ho * Wo * p.splits), dim3(256), 0, st, p);
+  if (p.grouped)
+    hipLaunchKernelGGL(chwn_gemm_kernel<true>, dim3(ceil_div(N, 128), Md / 128, nz * p.splits), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(chwn_gemm_kernel<false>, dim3(ceil_div(N, 128), Md / 128, nz * p.splits), dim3(256), 0, st, p);
   LSPS_CHECK_LAUNCH("chwn_gemm");
   if (p.splits > 1) {
     const long plane = (long)Ho * Wo * N, total = (long)Md * plane;
