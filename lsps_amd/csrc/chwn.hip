@@ -106,7 +106,7 @@ struct CGParams {
 // chip's resident slots (N = 128: 1024 workgroups) the kernel lasts as long as its 4-tap workgroups while the 1-tap ones leave
 // their slots idle (tools/bench_chwn.py 128: dgrad 69 TFLOP/s next to forward's 96 - 111).  Grouped, a workgroup walks
 //   type A: the odd-odd position of one 2x2 block (4 taps) | type B: its two mixed positions (2 + 2) | type C: the even-even
-//   positions of four consecutive blocks (1 + 1 + 1 + 1)
+//   positions of four consecutive blocks (1 + 1 + 1 + 1; hence maps whose block count is a multiple of 4)
 // one after the other: every workgroup does ~4 taps (border positions lose the taps that fall outside).
 __device__ __forceinline__ int chwn_group_size(int g, int Ho, int Wo) {
   const int NB = (Ho >> 1) * (Wo >> 1);
@@ -489,7 +489,7 @@ size_t lsps_conv3x3s2_chwn_workspace_bytes(int N, int C, int H, int W, int K) {
   const int P = H / 2, Q = W / 2;
   const size_t pack = (size_t)9 * C * K * sizeof(float);
   size_t fs = (size_t)chwn_gemm_splits(K, C, N, P * Q), ds = (size_t)chwn_gemm_splits(C, K, N, H * W);
-  const size_t dsg = (size_t)chwn_gemm_splits(C, K, N, H * W >= 64 ? 9 * (H / 2) * (W / 2) / 4 : H * W);   // dgrad, grouped positions
+  const size_t dsg = (size_t)chwn_gemm_splits(C, K, N, (H * W >= 64 && ((H / 2) * (W / 2)) % 4 == 0) ? 9 * (H / 2) * (W / 2) / 4 : H * W);   // dgrad, grouped positions
   if (dsg > ds) ds = dsg;
   const size_t fpart = fs > 1 ? fs * K * P * Q * N * sizeof(float) : 0, dpart = ds > 1 ? ds * C * H * W * N * sizeof(float) : 0;
   const size_t wpart = (size_t)chwn_wgrad_splits(K, C, N, P, Q) * 9 * K * C * sizeof(float);
@@ -524,7 +524,7 @@ static int chwn_run_gemm(const float *A, const float *B, const float *bias, floa
   // dgrad: positions grouped by tap count (see chwn_group_positions); maps of at least 4 x 4 positions (NB % 4 == 0)
   // (measured, tools/bench_chwn.py, profiles/r4s_chwn_grouped_dgrad.txt: 8x8 ... 32x32 input maps gain 8 - 15 % at N = 128 and 768;
   // on the 4x4 map — 9 groups — the lower occupancy costs more than the balance gives: per-position workgroups stay)
-  p.grouped = (mode == 1 && group_env && (Ho % 2) == 0 && (Wo % 2) == 0 && Ho * Wo >= 64) ? 1 : 0;
+  p.grouped = (mode == 1 && group_env && (Ho % 2) == 0 && (Wo % 2) == 0 && Ho * Wo >= 64 && (((Ho / 2) * (Wo / 2)) % 4) == 0) ? 1 : 0;
   const int nz = p.grouped ? 9 * (Ho / 2) * (Wo / 2) / 4 : Ho * Wo;
   p.splits = chwn_gemm_splits(Md, Rd, N, nz);
   if ((long)nz * p.splits > 65535) {

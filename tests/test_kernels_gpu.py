@@ -911,6 +911,8 @@ CHWN_CASES = [
     (20, 512, 8, 8, 1024),      # dis_s2: forward / dgrad reduction splits
     (36, 1024, 4, 4, 2048),     # dis_s3: 2x2 outputs, 25 of 36 taps real
     (132, 128, 4, 6, 128),      # two n tiles (128 + 4), non-square map
+    (8, 128, 12, 6, 128),       # 18 blocks of 2x2 input positions: not a multiple of 4 -> the dgrad keeps per-position workgroups
+    (8, 128, 16, 8, 256),       # non-square map WITH grouped dgrad positions (32 blocks)
     (4, 128, 2, 2, 128),        # one output position, 4 of 9 taps real
 ]
 
