@@ -396,7 +396,7 @@ def main():
             ops.set_math_mode('f32')
         # BASELINE config 5 itself (exps/nicvl.yaml nets, bf16 activations in the channel-group layout, bs=256): its own
         # trainer, same seeded-weight recipe; the standalone line is `bench.py --exp nicvl --dtype bf16 --batch 256`
-        t_c5 = None
+        t_c5 = t_c5_graph = None
         if args.dtype == 'f32' and args.exp == 'nnyu' and os.environ.get('LSPS_BENCH_CONFIG5', '1') != '0':
             hp5 = load_hp('nicvl')
             tr5 = trainers.LSPSTrainer(hp5)
@@ -414,6 +414,10 @@ def main():
             ops.set_math_mode('bf16')
             step5()
             t_c5 = timed(step5, 5)
+            tr5.use_graphs(True)            # the same step replayed from hipGraphs (single stream: no forked branches)
+            step5()
+            t_c5_graph = timed(step5, 5)
+            tr5.use_graphs(False)
             ops.set_math_mode('f32')
             del tr5, b5
             torch.cuda.empty_cache()
@@ -446,6 +450,7 @@ def main():
         if t_c5:
             extra['config5_pretrain_step_nicvl_bf16_bs256'] = {
                 'steps_per_s': 1.0 / t_c5, 'ms_per_step': 1e3 * t_c5, 'samples_per_s_per_domain': 256.0 / t_c5,
+                'hip_graph_ms_per_step': 1e3 * t_c5_graph,
                 'note': 'BASELINE config 5 on one GPU: exps/nicvl.yaml nets, batch 256 per domain, bf16 activations / MFMA operands '
                         '(f32 accumulate, statistics, losses, Adam); NOT the headline value'}
         if t_bf16:
