@@ -555,58 +555,69 @@ __global__ __launch_bounds__(256) void pw1_dgrad_kernel(const float *__restrict_
 // (C <= 64; grid = 2 blocks per image: 512 pixel quads each for a 128x128 map ... the quads of a block are strided by 256).
 // wpart (nullable): partial sums of the head's OWN gradients from the same pass, wpart[block][c] = sum y[c][pix] * dy[pix] (y is its
 // input) and wpart[block][C] = sum dy.
+// blockIdx.y = slice of PW1_CS channels: with all 64 channels per thread the two running sums per channel are 128 registers
+// (two waves per SIMD, 3.4 TB/s on the two 1 GB streams of a bs = 128 step); 16 channels per thread leave room for eight waves
+#define PW1_CS 16
 __global__ __launch_bounds__(256) void pw1_dgrad_act_kernel(const float *__restrict__ dy, const float *__restrict__ w,
                                                             const float *__restrict__ y, float *__restrict__ dx, float *__restrict__ part,
                                                             float *__restrict__ wpart, int C, int HW4, float slope) {
-  __shared__ float red[4][64];
+  __shared__ float red[4][PW1_CS];
   const int n = blockIdx.x >> 1, hb = blockIdx.x & 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.y * PW1_CS, nc = min(PW1_CS, C - c0);       // uniform
   const int q0 = hb * ((HW4 + 1) / 2), q1 = hb ? HW4 : (HW4 + 1) / 2;
-  const f32x4 *yp = reinterpret_cast<const f32x4 *>(y) + (long)n * C * HW4;
-  f32x4 *xp = reinterpret_cast<f32x4 *>(dx) + (long)n * C * HW4;
+  const f32x4 *yp = reinterpret_cast<const f32x4 *>(y) + ((long)n * C + c0) * HW4;
+  f32x4 *xp = reinterpret_cast<f32x4 *>(dx) + ((long)n * C + c0) * HW4;
   const f32x4 *gp = reinterpret_cast<const f32x4 *>(dy) + (long)n * HW4;
-  float s[64], sw[64], sd = 0.f;
+  float s[PW1_CS], sw[PW1_CS], wv[PW1_CS], sd = 0.f;
 #pragma unroll
-  for (int c = 0; c < 64; ++c) s[c] = sw[c] = 0.f;
+  for (int c = 0; c < PW1_CS; ++c) {
+    s[c] = sw[c] = 0.f;
+    wv[c] = c0 + c < C ? w[c0 + c] : 0.f;
+  }
   for (int q = q0 + tid; q < q1; q += 256) {
     const f32x4 g = gp[q];
     sd += (g[0] + g[1]) + (g[2] + g[3]);
-#pragma unroll 8
-    for (int c = 0; c < 64; ++c) {
-      if (c >= C) break;
-      const f32x4 yv = yp[(long)c * HW4 + q];
-      const float wc = w[c];
+    f32x4 yv[PW1_CS];
+#pragma unroll
+    for (int c = 0; c < PW1_CS; ++c)                   // all loads of the slice in flight before the first store
+      yv[c] = yp[(long)(c < nc ? c : 0) * HW4 + q];    // (channels beyond C: a duplicate load, never stored)
+#pragma unroll
+    for (int c = 0; c < PW1_CS; ++c) {
+      if (c < nc) {
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float v = wc * g[e];
-        o[e] = yv[e] > 0.f ? v : v * slope;
+        const float v = wv[c] * g[e];
+        o[e] = yv[c][e] > 0.f ? v : v * slope;
       }
       xp[(long)c * HW4 + q] = o;
       s[c] += (o[0] + o[1]) + (o[2] + o[3]);
-      sw[c] += (yv[0] * g[0] + yv[1] * g[1]) + (yv[2] * g[2] + yv[3] * g[3]);
+      sw[c] += (yv[c][0] * g[0] + yv[c][1] * g[1]) + (yv[c][2] * g[2] + yv[c][3] * g[3]);
+      }
     }
   }
 #pragma unroll
-  for (int c = 0; c < 64; ++c) {
+  for (int c = 0; c < PW1_CS; ++c) {
     const float t = wave_sum(s[c]);
     if (lane == 0) red[wave][c] = t;
   }
   __syncthreads();
-  if (tid < C) part[(long)blockIdx.x * C + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  if (tid < PW1_CS && c0 + tid < C) part[(long)blockIdx.x * C + c0 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
   if (wpart) {                                                  // uniform
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 64; ++c) {
+    for (int c = 0; c < PW1_CS; ++c) {
       const float t = wave_sum(sw[c]);
       if (lane == 0) red[wave][c] = t;
     }
     sd = wave_sum(sd);
     __syncthreads();
-    if (tid < C) wpart[(long)blockIdx.x * (C + 1) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < PW1_CS && c0 + tid < C)
+      wpart[(long)blockIdx.x * (C + 1) + c0 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
     __syncthreads();
     if (lane == 0) red[wave][0] = sd;
     __syncthreads();
-    if (tid == 0) wpart[(long)blockIdx.x * (C + 1) + C] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    if (tid == 0 && blockIdx.y == 0) wpart[(long)blockIdx.x * (C + 1) + C] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
   }
 }
 

@@ -2011,7 +2011,7 @@ int lsps_pw1_dgrad_act(const float *dpre, const float *w, const float *act_y, fl
   LSPS_CHECK_ARG(ws && ws_bytes >= (size_t)2 * N * (2 * C + 1) * sizeof(float), "pw1_dgrad_act: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float *part = (float *)ws, *wpart = dw ? part + (size_t)2 * N * C : nullptr;
-  hipLaunchKernelGGL(pw1_dgrad_act_kernel, dim3(2 * N), dim3(256), 0, st, dpre, w, act_y, dx, part, wpart, C, HW / 4, act_slope);
+  hipLaunchKernelGGL(pw1_dgrad_act_kernel, dim3(2 * N, ceil_div(C, PW1_CS)), dim3(256), 0, st, dpre, w, act_y, dx, part, wpart, C, HW / 4, act_slope);
   LSPS_CHECK_LAUNCH("pw1_dgrad_act");
   note_kernel("pw1_dgrad_kernel");
   if (db_prev) {
