@@ -58,13 +58,27 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(hp, pretrain_batch=16, timed=3, full_bs128=False):
+def _mem_available_gb():
+    try:
+        with open('/proc/meminfo') as f:
+            for line in f:
+                if line.startswith('MemAvailable'):
+                    return int(line.split()[1]) / 1e6
+    except (OSError, ValueError):
+        pass
+    return 0.0
+
+
+def cpu_baseline(hp, pretrain_batch=16, timed=3, full_bs128=False, direct_budget_s=0.0):
     """The oracle (CPU restatement of the reference, literal backward scope: it back-propagates into the generator in
     dis_update / post_update and computes the discriminator weight gradients in gen_update exactly like the reference)
     timed on this host's physical cores, as BASELINE.md section 3 prescribes: 1 warm-up + `timed` steps, min and median;
       * pretrain step (dis_update + gen_update, the headline workload) at a reduced batch, scaled linearly to bs=128
         (flagged as an extrapolation: bs=128 needs ~50 GB and ~3 min per step on 8 cores);
-      * the literal estimate3 step, post_update(mode=3), at bs=128 DIRECTLY (no extrapolation)."""
+      * the literal estimate3 step, post_update(mode=3), at bs=128 DIRECTLY (no extrapolation);
+      * `direct_budget_s` > 0 (the default line: --cpu-baseline-budget-s 600): ONE literal bs=128 pretrain step timed in THIS run
+        when the reduced-batch timing predicts that it fits the budget and the host has the ~60 GB it needs (a second one if
+        the budget still allows); the per-host-type cache of profiles/ is only the fallback."""
     import statistics
     import torch
     from oracle import lsps_ref
@@ -138,6 +152,18 @@ def cpu_baseline(hp, pretrain_batch=16, timed=3, full_bs128=False):
                 json.dump({cache_key: full}, f, indent=1)
         except OSError:
             pass
+    elif direct_budget_s > 0 and min(tp) * (128.0 / n) * 1.3 <= direct_budget_s and _mem_available_gb() >= 90.0:
+        bf = batch(128)
+        runs, t_leg = [], time.time()
+        runs.append(pretrain(bf))                           # no warm-up at the shape: an earlier lease measured 218 s cold, 244 s warm
+        if (time.time() - t_leg) + 1.15 * runs[0] <= direct_budget_s:
+            runs.append(pretrain(bf))
+        del bf
+        full = {'batch_per_domain': 128, 's_per_step': min(runs), 's_per_step_runs': runs, 'extrapolated': False,
+                'steps_per_s': 1.0 / min(runs), 'source': 'timed in this run (%d literal bs=128 step%s inside --cpu-baseline-budget-s %d)'
+                                                       % (len(runs), 's' if len(runs) > 1 else '', int(direct_budget_s)),
+                'torch': torch.__version__,
+                'max_rss_gb': __import__('resource').getrusage(__import__('resource').RUSAGE_SELF).ru_maxrss / 1e6}
     else:
         try:
             with open(cache_path) as f:
@@ -200,6 +226,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-bs128', action='store_true',
                     help='additionally time ONE literal bs=128 pretrain step of the CPU oracle (minutes, ~50 GB of host memory)')
+    ap.add_argument('--cpu-baseline-budget-s', type=float, default=600.0,
+                    help='seconds of host time the default line may spend on literal bs=128 oracle steps (0: quote the cached '
+                         'measurement of profiles/cpu_baseline_bs128.json, or the extrapolation)')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary workloads (estimate3, fwd-only)')
     ap.add_argument('--graphs', action='store_true',
                     help='replay the pretrain step from hipGraphs (LSPSTrainer.use_graphs); the per-kernel HIP events cannot be '
@@ -241,7 +270,8 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     n_ranks = 1
-    if world > 1 or os.environ.get('LSPS_FORCE_DP') == '1':
+    from lsps_amd import options as lsps_options
+    if world > 1 or lsps_options.get().force_dp:
         if args.backend == 'nccl':
             # flight recorder on (torch's default is off): lsps_amd.dist.drain_watchdog confirms through it that RCCL's
             # watchdog holds no eager work before the data-parallel estimate3 step is captured (else that step stays eager)
@@ -337,7 +367,7 @@ def main():
         for r_ in tr._reducers.values():
             r_.take_stats()             # drop what the profiled pass added
         dp_stats = {'backend': 'rccl' if args.backend == 'nccl' else 'gloo',
-                    'bucket_mib': int(os.environ.get('LSPS_BUCKET_BYTES', ldist_default_bucket())) / float(1 << 20),
+                    'bucket_mib': lsps_options.get().bucket_bytes / float(1 << 20),
                     'allreduce_exposed_ms_per_step': sum(r['exposed_ms'] for r in rs.values()) / args.steps,
                     'allreduce_mb_per_step': sum(r['bytes'] for r in rs.values()) / args.steps / 1e6,
                     'per_update': {('dis_update' if k == 'dis' else 'gen_update'): {
@@ -534,9 +564,11 @@ def main():
             'step_mfma_issued_frac': step_issued_frac,
             'global_iterations_per_s': args.steps / elapsed,
             'roofline': roofline, 'data_parallel': dp_stats, 'other_workloads': extra,
+            # the process options this rank ran with (lsps_amd/options.py: every LSPS_* switch, read once at import)
+            'options': lsps_options.get().as_dict(),
         }
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cb = cpu_baseline(hp, full_bs128=args.cpu_baseline_bs128)
+            out['cpu_baseline'] = cb = cpu_baseline(hp, full_bs128=args.cpu_baseline_bs128, direct_budget_s=args.cpu_baseline_budget_s)
             out['speedup_vs_cpu_baseline'] = out['value'] / cb['value']
             est = extra.get('estimate3_step_bs%d' % args.batch)
             if est and args.batch == 128:      # the one comparison with no extrapolation on either side

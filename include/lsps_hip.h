@@ -406,6 +406,23 @@ int lsps_axpy(const float *x, const float *y, float alpha, float *out, long n, v
  * followed by `out += residual` (:180); with x == NULL it is the branch's backward (dt = dy*m). */
 int lsps_mul_add(const float *x, const float *t, const float *m, float *out, long n, void *stream);
 
+/* ---- f32-class stride-2 conv on the bf16 matrix pipe: three-limb "X3" tensors (round 5 prototype, csrc/x3s2.h) -------------
+ * An X3 tensor carries an f32 activation as three bf16 limbs per element, x = hi + mid + lo EXACTLY (8 + 8 + 8 significand
+ * bits), as three C8 planes per image: [N][limb 3][C/8][H][W][8] bf16.  A product of two such operands is formed by six
+ * v_mfma_f32_32x32x16_bf16 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the dropped terms are < 2^-24 relative), f32
+ * accumulation: f32-class arithmetic at 192 instead of 512 matrix-pipe cycles per 32x32x16 MACs.
+ *   lsps_x3_split_nchw      f32 [N,C,HW] -> X3 (C % 8 == 0);  lsps_x3_join_nchw the inverse (exact)
+ *   lsps_x3_conv3x3s2_fwd   LeakyReLUConv2d(C, K, 3, 2, 1) (reference: src/trainers/common_net.py:246-256; lsps_nets.py:119-123,
+ *                           186-192): y = LeakyReLU_slope(conv(x, w) + bias) from an X3 input; w f32 (K,C,3,3), split into limbs by
+ *                           the pack kernel (cached in the pack-cache scope); output f32 NCHW `y` or, when `yl` is given, X3 `yl`
+ *                           (the next stride-2 layer's input).  C % 16 == 0, K % 128 == 0, H, W powers of two (_ok). */
+int lsps_x3_split_nchw(const float *x, void *xl, int N, int C, int HW, void *stream);
+int lsps_x3_join_nchw(const void *xl, float *y, int N, int C, int HW, void *stream);
+int lsps_x3_conv3x3s2_ok(int N, int C, int H, int W, int K);
+size_t lsps_x3_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K);
+int lsps_x3_conv3x3s2_fwd(const void *xl, const float *w, const float *bias /*nullable*/, float *y /*nullable*/, void *yl /*nullable*/,
+                          int N, int C, int H, int W, int K, float slope, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- data step either side of the path -------------------------------------------------
  * lsps_crop_normalize: reference src/data/dataset_hand2.py:27-31 `normalize(img, com, cube)` for a batch:
  *   out = (dpt == 0 ? com_z + half : dpt) - com_z) / half, with half = cube_z / 2.  dpt/out: [N][HW] device floats

@@ -108,6 +108,11 @@ _SIGNATURES = {
     'lsps_conv2d_stem_wgrad_act': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 8 + [c_float, _P, c_size_t, _P]),
     'lsps_pw1_dgrad_act_workspace_bytes': (c_size_t, [c_int] * 2),
     'lsps_pw1_dgrad_act': (c_int, [_P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    'lsps_x3_split_nchw': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'lsps_x3_join_nchw': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'lsps_x3_conv3x3s2_ok': (c_int, [c_int] * 5),
+    'lsps_x3_conv3x3s2_workspace_bytes': (c_size_t, [c_int] * 5),
+    'lsps_x3_conv3x3s2_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [c_float, _P, c_size_t, _P]),
     'lsps_crop_normalize': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     'lsps_crop_augment': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
 }

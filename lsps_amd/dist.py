@@ -22,7 +22,8 @@ import torch.distributed as dist
 # 16 MiB: few, large messages (an 8-rank ring moves 2 MiB pieces per step: per-link-bound, not latency-bound), yet small
 # enough that what is still un-sent when backward ends — the last bucket, i.e. the FIRST layers — stays a few MB: on the
 # discriminator that is 6.5 MB (a 32 MiB cut leaves model_S.2's 19 MB weight in it: 25 MB exposed per estimate step)
-DEFAULT_BUCKET_BYTES = 16 << 20
+from . import options
+from .options import DEFAULT_BUCKET_BYTES  # noqa: F401
 
 
 def world():
@@ -32,17 +33,15 @@ def world():
 def active():
     """True when gradients must be exchanged.  LSPS_FORCE_DP=1 also runs the exchange in a 1-rank process
     group (used to smoke-test the RCCL call pattern on a single-GPU box)."""
-    import os
     if not (dist.is_available() and dist.is_initialized()):
         return False
-    return dist.get_world_size() > 1 or os.environ.get('LSPS_FORCE_DP') == '1'
+    return dist.get_world_size() > 1 or options.get().force_dp
 
 
 def capturable():
     """Can this process group's collectives be recorded into a hipGraph?  RCCL kernels can (they are stream work); gloo
     moves data through the host.  LSPS_DP_GRAPHS=0 keeps data-parallel steps eager."""
-    import os
-    if not (dist.is_available() and dist.is_initialized()) or os.environ.get('LSPS_DP_GRAPHS') == '0':
+    if not (dist.is_available() and dist.is_initialized()) or not options.get().dp_graphs:
         return False
     return dist.get_backend() == 'nccl'
 
@@ -88,9 +87,8 @@ class GradReducer(object):
     def __init__(self, arena, bucket_bytes=None, group=None, segments=None):
         """`segments`: start indices of the parameter groups that must never share a bucket (the generator arena holds
         `gen` then `map`: a step with train_map=False would otherwise all-reduce the idle Mapping's zeros)."""
-        import os
         if bucket_bytes is None:
-            bucket_bytes = int(os.environ.get("LSPS_BUCKET_BYTES", DEFAULT_BUCKET_BYTES))
+            bucket_bytes = options.get().bucket_bytes
         self.arena = arena
         self.group = group
         self.world = world()

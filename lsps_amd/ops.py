@@ -9,6 +9,7 @@ import ctypes as _ctypes
 import torch
 
 from . import _lib
+from . import options  # noqa: F401  (`ops.options.get()`: the process options in force)
 from ._lib import ACT_LRELU, ACT_NONE, ACT_SOFTPLUS, ACT_TANH, LOSS_KLSD, LOSS_L1, LOSS_L2, LOSS_SQ  # noqa: F401
 
 LRELU_SLOPE = 0.01     # nn.LeakyReLU() default (src/trainers/common_net.py:169,252,264)
@@ -200,13 +201,12 @@ class ActHolder(object):
 
 
 def _fuse_enabled():
-    import os
-    return os.environ.get('LSPS_FUSE_ACT', '1') != '0'
+    return options.get().fuse_act
 
 
 def _fusable(prev):
-    import os
-    return prev is not None and prev.slope >= 0 and os.environ.get('LSPS_C8_FUSE_ACT', '1') != '0' and os.environ.get('LSPS_FUSE_ACT', '1') != '0'
+    o = options.get()
+    return prev is not None and prev.slope >= 0 and o.c8_fuse_act and o.fuse_act
 
 
 def _act_backward(L, dy, y, act, slope, want_db, channels, ws, wsb, st):
@@ -644,8 +644,7 @@ def is_c8(t):
 def c8_block_ok(x, channels, dropout=0.0):
     """Can a LeakyINSResBlock(channels -> channels) on `x` (f32 NCHW or already C8) run on the C8 kernels?  bf16 math mode,
     32x32 maps, channels % 128 == 0 (k tiles of the weight-gradient kernel), no dropout; LSPS_C8=0 switches the path off."""
-    import os
-    if get_math_mode() != 'bf16' or dropout > 0 or os.environ.get('LSPS_C8', '1') == '0':
+    if get_math_mode() != 'bf16' or dropout > 0 or not options.get().c8:
         return False
     if is_c8(x):
         N, G, H, W, _ = x.shape
@@ -730,15 +729,13 @@ def add_c8(a, b):
 
 
 def _c8_enabled():
-    import os
-    return get_math_mode() == 'bf16' and os.environ.get('LSPS_C8', '1') != '0'
+    return get_math_mode() == 'bf16' and options.get().c8
 
 
 def c8_conv_s2_ok(x, w, stride, pad):
     """Can LeakyReLUConv2d(C, K, 3, stride 2, pad 1) on `x` (f32 NCHW or C8) run on the C8 stride-2 kernels (csrc/c8s2.h)?
     bf16 math mode only; LSPS_C8=0 / LSPS_C8S2=0 switch it off."""
-    import os
-    if not _c8_enabled() or os.environ.get('LSPS_C8S2', '1') == '0' or stride != 2 or pad != 1 or tuple(w.shape[2:]) != (3, 3):
+    if not _c8_enabled() or not options.get().c8s2 or stride != 2 or pad != 1 or tuple(w.shape[2:]) != (3, 3):
         return False
     if is_c8(x):
         N, G, H, W, _ = x.shape
@@ -751,8 +748,7 @@ def c8_conv_s2_ok(x, w, stride, pad):
 
 
 def c8_convT_s2_ok(x, w, stride, pad, outpad):
-    import os
-    if not _c8_enabled() or os.environ.get('LSPS_C8S2', '1') == '0' or stride != 2 or pad != 1 or outpad != 1 or \
+    if not _c8_enabled() or not options.get().c8s2 or stride != 2 or pad != 1 or outpad != 1 or \
             tuple(w.shape[2:]) != (3, 3):
         return False
     if is_c8(x):
@@ -1389,8 +1385,7 @@ PACK_CACHE_BYTES = 1 << 30          # gen + dis panels in both directions are ~0
 def weight_cache_begin(device):
     """From here until `weight_cache_end()` the conv weights are promised not to change (one update method of the
     trainer up to its optimizer step): packed weight panels are built once and reused."""
-    import os
-    if os.environ.get('LSPS_NO_PACK_CACHE') == '1':
+    if not options.get().pack_cache:
         return
     key = (device.type, device.index)
     buf = _pack_arenas.get(key)
@@ -1410,9 +1405,8 @@ FROZEN_CACHE_BYTES = 1 << 29        # the generator's panels for the forward dir
 def weight_cache_frozen(flat_params=None, epoch=0):
     """Declares the weights inside `flat_params` (a flat parameter arena) unchanged ACROSS the scopes that follow, until
     `epoch` changes (lsps_pack_cache_frozen): their packed panels survive `weight_cache_end()`.  None: no frozen weights."""
-    import os
     L = _lib.lib()
-    if flat_params is None or os.environ.get('LSPS_NO_PACK_CACHE') == '1' or os.environ.get('LSPS_NO_FROZEN_PACKS') == '1':
+    if flat_params is None or not options.get().pack_cache or not options.get().frozen_packs:
         _lib.check(L.lsps_pack_cache_frozen(None, None, None, 0, 0), 'pack_cache_frozen')
         return False
     key = (flat_params.device.type, flat_params.device.index)

@@ -141,13 +141,13 @@ class SharedDis(_Net):
         channel-group layout (csrc/c8s2.h, common_net.run_layers).  f32: where the geometry allows (N % 4 == 0, channels
         % 128 == 0, even maps) in batch-innermost layout on the plain-GEMM kernels of csrc/chwn.hip (one transpose in, one
         out); otherwise layer by layer in NCHW."""
-        import os
         layers = list(self.model_S)
         if ops.is_c8(f) or ops.get_math_mode() == 'bf16':
             return ops.from_c8(run_layers(layers, f))
         N, C, H, W = f.shape
         # below ~96 samples the 128-wide batch tile of the GEMM is mostly padding (dis.feats on 16 samples: slower than NCHW)
-        ok = len(layers) > 0 and N >= int(os.environ.get('LSPS_CHWN_MIN_N', '96')) and os.environ.get('LSPS_CHWN', '1') != '0'
+        opt = ops.options.get()
+        ok = len(layers) > 0 and N >= opt.chwn_min_n and opt.chwn
         c, h, w = C, H, W
         for l in layers:
             conv = l.model[0] if isinstance(l, LeakyReLUConv2d) else None

@@ -245,14 +245,14 @@ class LSPSTrainer(nn.Module):
         return ep
 
     def _side_stream(self, device):
-        """Second HIP stream for the independent branch of the estimate modes (LSPS_NO_OVERLAP=1: none).  Also under data
+        """Second HIP stream for the independent branch of the estimate modes (options.overlap = False: none).  Also under data
         parallelism: the gradient hooks run in the AccumulateGrad nodes, which the engine executes on the launch stream after
         it has joined the side stream's producers, so a bucket's all-reduce is ordered behind both branches."""
-        if os.environ.get('LSPS_NO_OVERLAP') == '1':
+        if not ops.options.get().overlap:
             return None
         if self._side is None:
-            # LSPS_SIDE_PRIO=-1: a high-priority stream (its quarter-chip launches are the step's critical chain)
-            self._side = torch.cuda.Stream(device=device, priority=int(os.environ.get('LSPS_SIDE_PRIO', '0')))
+            # side_prio = -1: a high-priority stream (its quarter-chip launches are the step's critical chain)
+            self._side = torch.cuda.Stream(device=device, priority=ops.options.get().side_prio)
             # the discriminator's AccumulateGrad nodes live on the main stream while part of their gradients now arrive from
             # the side stream: intended (the engine synchronises them), so the advisory warning is switched off
             fn = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
@@ -276,10 +276,10 @@ class LSPSTrainer(nn.Module):
         tensors = []
         # everything that decides WHICH launches a step makes or WHERE they read / write: argument shapes and values, every
         # sub-net's train / eval flag (poseVAE.encode draws noise, GaussianNoiseLayer is off in eval), the algorithm /
-        # math switches of the library, the layout / overlap environment and the arenas' addresses
+        # math switches of the library, the process options as a whole (lsps_amd/options.py: a frozen, hashable object — a
+        # switch added there is part of the signature by construction) and the arenas' addresses
         sig = (name, _flatten_tensors((args, kwargs), tensors), self.gen.training, self.dis.training, self.vae.training,
-               self.map.training, ops.get_winograd(), ops.get_math_mode(),
-               tuple(os.environ.get(k) for k in ('LSPS_CHWN', 'LSPS_CHWN_MIN_N', 'LSPS_NO_OVERLAP', 'LSPS_NO_PACK_CACHE', 'LSPS_EST_SPLIT_BACKWARD', 'LSPS_EST_ORDER')),
+               self.map.training, ops.get_winograd(), ops.get_math_mode(), ops.options.get(),
                tuple(int(o.arena.flat_p.data_ptr()) for o in (self.dis_opt, self.gen_opt, self.vae_opt) if o.arena is not None))
         if name == 'post_update':
             # a post_update captured while the generator's panels are frozen holds no pack launches for them (they were cache
@@ -515,7 +515,7 @@ class LSPSTrainer(nn.Module):
             # forwards have ended).  The two partial gradients meet in the parameters' AccumulateGrad nodes: each
             # discriminator weight gets one contribution per term, and a + b = b + a in floating point, so the result is
             # bit-identical to the single backward (tests/test_parity_gpu.py: overlapped == serial, bitwise).
-            split = side is not None and os.environ.get('LSPS_EST_SPLIT_BACKWARD', '1') != '0'
+            split = side is not None and ops.options.get().est_split_backward
             sig = ('post_update', int(mode))
 
             def regression_branch():
@@ -541,7 +541,7 @@ class LSPSTrainer(nn.Module):
             #   'feat_first' [generator pass, feature forward | regression forward + backward], feature backward   6.88 ms (default)
             #   'reg_first'  [regression forward + backward | generator pass, feature forward], feature backward   7.18 ms
             #   'chain'      regression forward, THEN [generator pass, feature forward | regression backward], ...  7.17 ms
-            order = os.environ.get('LSPS_EST_ORDER', 'feat_first') if split else 'serial'
+            order = ops.options.get().est_order if split else 'serial'
             if order == 'chain':
                 regression_branch()
                 side.wait_stream(main)

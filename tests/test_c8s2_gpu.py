@@ -294,7 +294,7 @@ def test_fused_activation_backward_equals_the_separate_pass(monkeypatch):
     try:
         res = []
         for fuse in ('1', '0'):
-            monkeypatch.setenv('LSPS_C8_FUSE_ACT', fuse)
+            monkeypatch.setattr(ops.options, '_current', ops.options.from_env({'LSPS_C8_FUSE_ACT': fuse}))
             for m in dec + enc:
                 for p in m.parameters():
                     p.grad = None

@@ -134,6 +134,8 @@ def _product_step_worker(rank, world, port, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['LSPS_BUCKET_BYTES'] = str(1 << 14)
+    from lsps_amd import options
+    options.reload_env()                    # the switches are read once per process, at import (lsps_amd/options.py)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(2)
     try:
@@ -300,7 +302,8 @@ def _full_width_reducer(tr, params, segments, monkey_log):
 
 def test_full_width_default_buckets_launch_in_readiness_order_and_skip_the_idle_mapping(monkeypatch):
     import yaml
-    monkeypatch.delenv('LSPS_BUCKET_BYTES', raising=False)
+    from lsps_amd import options
+    monkeypatch.setattr(options, '_current', options.from_env({}))      # the DEFAULT bucket size
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(repo, 'exps', 'nnyu.yaml')) as f:
         hp = yaml.safe_load(f)['train']['hyperparameters']

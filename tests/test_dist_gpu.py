@@ -129,6 +129,8 @@ def _golden_worker(rank, world, port, out, config='tiny'):
         os.environ['LSPS_BUCKET_BYTES'] = str(1 << 16)      # tiny nets: several buckets per arena
     else:
         os.environ.pop('LSPS_BUCKET_BYTES', None)           # full width: the DEFAULT bucket layout
+    from lsps_amd import options
+    options.reload_env()                    # the switches are read once per process, at import (lsps_amd/options.py)
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -265,6 +267,8 @@ def _dp_graph_worker(port, out, trace_buf='2000'):
     os.environ['LSPS_FORCE_DP'] = '1'
     os.environ['LSPS_BUCKET_BYTES'] = str(1 << 16)
     os.environ['TORCH_NCCL_TRACE_BUFFER_SIZE'] = os.environ['TORCH_FR_BUFFER_SIZE'] = trace_buf   # dist.drain_watchdog ('0': off)
+    from lsps_amd import options
+    options.reload_env()
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', device_id=torch.device('cuda', 0), rank=0, world_size=1)
     try:

@@ -1046,7 +1046,7 @@ def test_output_head_dgrad_with_fused_activation_backward(monkeypatch):
     z = torch.randn(3, 128, 64, 64, device=dev)
     res = []
     for fuse in ('1', '0'):
-        monkeypatch.setenv('LSPS_FUSE_ACT', fuse)
+        monkeypatch.setattr(ops.options, '_current', ops.options.from_env({'LSPS_FUSE_ACT': fuse}))
         for m in layers:
             for p in m.parameters():
                 p.grad = None

@@ -53,7 +53,7 @@ def test_full_steps_match_reference_golden_per_conv_algorithm(mode, golden, monk
     from lsps_amd import ops
     prev = ops.get_winograd()
     ops.set_winograd(mode)
-    monkeypatch.setenv('LSPS_CHWN_MIN_N', '1' if mode == 'always' else '1000000')
+    monkeypatch.setattr(ops.options, '_current', ops.options.from_env({'LSPS_CHWN_MIN_N': '1' if mode == 'always' else '1000000'}))
     ops.kernel_log_begin()
     try:
         R = cases.run_step_cases(A, 'full', lsps_ref)
@@ -439,10 +439,8 @@ def test_post_update_overlapped_branches_match_serial_bitwise(mode, monkeypatch)
     lat, zd = cases.latent_shape(hp, 8), hp['vae']['z_dim']
     outs = []
     for variant in ('overlap', 'serial', 'graph'):
-        if variant == 'serial':
-            monkeypatch.setenv('LSPS_NO_OVERLAP', '1')
-        else:
-            monkeypatch.delenv('LSPS_NO_OVERLAP', raising=False)
+        from lsps_amd import options
+        monkeypatch.setattr(options, '_current', options.from_env({'LSPS_NO_OVERLAP': '1'} if variant == 'serial' else {}))
         tr = A.make_trainer(hp, sds)
         tr.use_graphs(variant == 'graph')
         A.set_train(tr, True)
@@ -475,10 +473,8 @@ def test_frozen_generator_packs_survive_steps_and_follow_weight_changes(graphs, 
     lat, lat1, zd = cases.latent_shape(hp, 8), cases.latent_shape(hp, 8), hp['vae']['z_dim']
     outs = []
     for frozen in (True, False):
-        if frozen:
-            monkeypatch.delenv('LSPS_NO_FROZEN_PACKS', raising=False)
-        else:
-            monkeypatch.setenv('LSPS_NO_FROZEN_PACKS', '1')
+        from lsps_amd import options
+        monkeypatch.setattr(options, '_current', options.from_env({} if frozen else {'LSPS_NO_FROZEN_PACKS': '1'}))
         if frozen:
             # a DECOY first: another trainer with other generator weights fills the frozen table, then goes away — the caching
             # allocator hands its arena's addresses to the next trainer, whose generation / version counts are the same
