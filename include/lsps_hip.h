@@ -422,6 +422,30 @@ int lsps_x3_conv3x3s2_ok(int N, int C, int H, int W, int K);
 size_t lsps_x3_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K);
 int lsps_x3_conv3x3s2_fwd(const void *xl, const float *w, const float *bias /*nullable*/, float *y /*nullable*/, void *yl /*nullable*/,
                           int N, int C, int H, int W, int K, float slope, void *ws, size_t ws_bytes, void *stream);
+/* dx [N,C,H,W] (f32 NCHW `dx` or X3 `dxl`) from the X3 gradient dyl [N,K,H/2,W/2] w.r.t. the conv's OUTPUT (its own activation
+ * already undone).  act_yl != NULL: dx is the gradient w.r.t. the OUTPUT of the layer in front (X3 saved output act_yl, dx's shape):
+ * the epilogue multiplies by LeakyReLU'(act_yl) (slope act_slope) and db_prev [C] (nullable) receives that layer's bias gradient.
+ * lsps_x3_conv3x3s2_wgrad: dw [K,C,3,3] f32 (OVERWRITTEN) from X3 x and X3 dy (autograd of common_net.py:250). */
+int lsps_x3_conv3x3s2_dgrad(const void *dyl, const float *w, float *dx /*nullable*/, void *dxl /*nullable*/, const void *act_yl /*nullable*/,
+                            float act_slope, float *db_prev /*nullable*/, int N, int C, int H, int W, int K,
+                            void *ws, size_t ws_bytes, void *stream);
+int lsps_x3_conv3x3s2_wgrad(const void *xl, const void *dyl, float *dw, int N, int C, int H, int W, int K,
+                            void *ws, size_t ws_bytes, void *stream);
+/* LeakyReLUConvTranspose2d(Ci, Co, 3, 2, 1, 1) (common_net.py:258-268, lsps_nets.py:222-225): x [N,Ci,H,W] X3 -> y [N,Co,2H,2W]
+ * (f32 NCHW `y` or X3 `yl`); w (Ci,Co,3,3); dgrad: dx [N,Ci,H,W] from the X3 gradient w.r.t. the layer's output (activation
+ * undone); wgrad: dw (Ci,Co,3,3) OVERWRITTEN.  Ci % 128 == 0, Co % 64 == 0.  Workspace: lsps_x3_conv3x3s2_workspace_bytes(N, Co, 2H, 2W, Ci). */
+int lsps_x3_convT3x3s2_ok(int N, int Ci, int H, int W, int Co);
+int lsps_x3_convT3x3s2_fwd(const void *xl, const float *w, const float *bias /*nullable*/, float *y /*nullable*/, void *yl /*nullable*/,
+                           int N, int Ci, int H, int W, int Co, float slope, void *ws, size_t ws_bytes, void *stream);
+int lsps_x3_convT3x3s2_dgrad(const void *dyl, const float *w, float *dx /*nullable*/, void *dxl /*nullable*/, int N, int Ci, int H, int W,
+                             int Co, void *ws, size_t ws_bytes, void *stream);
+int lsps_x3_convT3x3s2_wgrad(const void *xl, const void *dyl, float *dw, int N, int Ci, int H, int W, int Co,
+                             void *ws, size_t ws_bytes, void *stream);
+/* g (X3) = dy * LeakyReLU'(y) from f32 NCHW dy and the layer's f32 NCHW output y (slope < 0: g = dy), db [C] (nullable) = sum of g:
+ * the X3-emitting form of lsps_act_bwd_bias for a layer whose output left the X3 family as f32 (common_net.py:252). */
+size_t lsps_x3_act_bwd_bias_workspace_bytes(int N, int C);
+int lsps_x3_act_bwd_bias(const float *dy, const float *y /*nullable*/, void *gl, float *db /*nullable*/, int N, int C, int HW, float slope,
+                         void *ws, size_t ws_bytes, void *stream);
 
 /* ---- data step either side of the path -------------------------------------------------
  * lsps_crop_normalize: reference src/data/dataset_hand2.py:27-31 `normalize(img, com, cube)` for a batch:

@@ -4,6 +4,7 @@
 #ifndef LSPS_C8CONV_H
 #define LSPS_C8CONV_H
 #include "conv_types.h"
+#include "c8util.h"
 
 namespace lsps {
 
@@ -38,44 +39,6 @@ namespace lsps {
 #define C8_SCRATCH (C8_RBYTES)                       // epilogue reduction scratch behind it (5 KB)
 #define C8_LDS_BYTES (C8_RBYTES + 5120)              // 136192 bytes (stages: 112640): one workgroup per CU
 #define C8_ACHUNK (C8_AUNITS * 8)                    // bf16 elements of packed weights per (k tile, chunk)
-
-typedef __attribute__((address_space(3))) void *c8_lds_ptr;
-
-// LDS-DMA issued from inline asm, for the kernels that read their operands with ds_read_b64_tr_b16.  hipcc cannot tell that a
-// transposing read does not alias the DMA target and puts `s_waitcnt vmcnt(0)` in front of the first such read after a
-// buffer_load ... lds — the next chunk's requests would be waited for before the current chunk's MFMAs start, i.e. no overlap at
-// all (profiles/r3g_c8_ablations.txt: 22 % / 40 % of the two weight-gradient kernels).  Issued this way the compiler sees no LDS
-// write; the kernels' own `s_waitcnt vmcnt(0)` + barrier at the end of a chunk is the only synchronisation, as designed.
-// Untracked VMEM requests only make the compiler's own vmcnt waits more conservative (the counter retires in order).
-typedef int c8_i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ c8_i32x4 c8_rsrc_words(const void *base, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)base;
-  c8_i32x4 r;
-  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-  r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));      // stride 0
-  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-  r.w = 0x00020000;                                                                // raw buffer, out-of-range reads return 0
-  return r;
-}
-__device__ __forceinline__ unsigned c8_lds_addr(const void *ptr) {
-  return (unsigned)(__UINTPTR_TYPE__)(c8_lds_ptr)ptr;
-}
-// 64 lanes x 16 bytes -> LDS [lds_addr + 16 lane ..); lds_addr and soff wave-uniform
-__device__ __forceinline__ void c8_dma16_asm(c8_i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :
-               : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rsrc),
-                 "s"(__builtin_amdgcn_readfirstlane((int)soff))
-               : "memory", "m0");
-}
-
-// x > 0 ? b : a  (x <= 0, either zero included: LeakyReLU'(0) = slope like torch's `out > 0` test) without a compare mask:
-// 64 such masks held live in SGPR pairs spill.  ((bits - 1) | bits) is negative exactly for +0, -0 and negative x.
-__device__ __forceinline__ float c8_sel_nonpos(float x, float a, float b) {
-  const int xb = __builtin_bit_cast(int, x);
-  const int m = ((xb - 1) | xb) >> 31;
-  return __builtin_bit_cast(float, (__builtin_bit_cast(int, a) & m) | (__builtin_bit_cast(int, b) & ~m));
-}
 
 struct C8Pack {
   const float *W;
@@ -227,21 +190,6 @@ struct C8ConvParams {
                                  // 3: y = backward of IN + LeakyReLU(slope) applied to conv, from the saved output R and rstd
   float slope, eps;
 };
-
-// butterfly reduce-scatter inside the 32-lane half: on return lane l31 holds in v[0] the sum over the half's lanes of v[l31].
-// Step CNT (16, 8, .. 1): partners l31 ^ CNT keep one half of their CNT*2 values each and exchange the other half.
-// (Template recursion: with a run-time trip count the register array is indexed dynamically = select chains.)
-template <int CNT>
-__device__ __forceinline__ void c8_reduce_scatter32(float (&v)[32], int l31) {
-  const bool up = (l31 & CNT) != 0;
-#pragma unroll
-  for (int k = 0; k < CNT; ++k) {
-    const float send = up ? v[k] : v[k + CNT];
-    const float keep = up ? v[k + CNT] : v[k];
-    v[k] = keep + __shfl_xor(send, CNT, 64);
-  }
-  if constexpr (CNT > 1) c8_reduce_scatter32<CNT / 2>(v, l31);
-}
 
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void c8_conv3x3_kernel(C8ConvParams p) {

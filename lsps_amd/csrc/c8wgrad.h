@@ -41,16 +41,6 @@ struct C8WgradParams {
   int splits, imgs_per_split;
 };
 
-typedef short c8_s16x4 __attribute__((ext_vector_type(4)));
-typedef short c8_s16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ bf16x8 c8_tr_frag(const unsigned char *p0, const unsigned char *p1) {
-  const c8_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c8_s16x4 __attribute__((address_space(3))) *)(p0));
-  const c8_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c8_s16x4 __attribute__((address_space(3))) *)(p1));
-  const c8_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-
 __global__ __launch_bounds__(512, 1) void c8_wgrad_kernel(C8WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char c8w_lds[];
   const int tid = threadIdx.x, lane = tid & 63;

@@ -27,6 +27,93 @@ static bool x3s2_fwd_geom(int N, int Cx, int H, int W, int M, X3S2Params *p) {
   return true;
 }
 
+
+static bool x3s2_tr_geom(int N, int Cx, int H, int W, int M, X3S2TParams *p) {      // H x W = the BIG (output) map
+  if (N <= 0 || H < 2 || W < 2 || !x3_pow2(H) || !x3_pow2(W) || (Cx & 15) || (M & 63)) return false;
+  const int P = H / 2, Q = W / 2, PQ = P * Q;
+  int TI, TR, tpi, nt;
+  if (PQ >= 256) {
+    if (Q > 256) return false;
+    TI = 1; TR = 256 / Q; tpi = P / TR; nt = N * tpi;
+  } else {
+    TI = 256 / PQ; TR = P; tpi = 1; nt = (N + TI - 1) / TI;
+  }
+  if (2l * TI * TR * (Q + 1) > X3T_BP * 64 || (long)TI * 3 * (Cx >> 3) * P * Q * 16 >= (1l << 31)) return false;
+  if ((long)(Cx >> 4) * 3 * X3T_ASTAGE >= (1l << 31)) return false;
+  if (p) {
+    p->H = H; p->W = W; p->P = P; p->Q = Q;
+    p->TI = TI; p->TR = TR; p->tiles_per_img = tpi; p->ntiles = nt;
+  }
+  return true;
+}
+
+static bool x3s2_wgrad_geom(int N, int K, int C, int H, int W, X3S2WParams *p) {   // small [N][K][H/2][W/2], big [N][C][H][W]
+  if (N <= 0 || H < 2 || W < 2 || !x3_pow2(H) || !x3_pow2(W) || (K & 127) || (C & 63)) return false;
+  const int P = H / 2, Q = W / 2, PQ = P * Q;
+  int TIW, TRW, QW, cb, cpi, nc;
+  if (PQ >= 16) {
+    TIW = 1;
+    QW = Q >= 16 ? 16 : Q;
+    TRW = 16 / QW;
+    cb = Q / QW;
+    cpi = (P / TRW) * cb;
+    nc = N * cpi;
+  } else {
+    TIW = 16 / PQ; TRW = P; QW = Q; cb = 1; cpi = 1;
+    nc = (N + TIW - 1) / TIW;
+  }
+  const int blk = (2 * TRW + 1) * (2 * QW + 1);
+  int bplane = TIW * blk;
+  while ((bplane & 7) != 4) ++bplane;                            // plane stride = 64 (mod 128) bytes: bank quarter rotation
+  if (8 * bplane > X3W_BP * 64) return false;
+  if ((long)TIW * 3 * (C >> 3) * H * W * 16 >= (1l << 31) || (long)TIW * 3 * (K >> 3) * P * Q * 16 >= (1l << 31)) return false;
+  const int tiles = (K >> 7) * (C >> 6);
+  int s = (256 + tiles - 1) / tiles;
+  if (s > 1) s = (s + 7) / 8 * 8;                                // a split lives on ONE XCD (workgroup -> tile mapping): use all 8
+  if (s > nc) s = nc;
+  const int cps = (nc + s - 1) / s;
+  s = (nc + cps - 1) / cps;
+  if (p) {
+    p->N = N; p->K = K; p->C = C; p->H = H; p->W = W; p->P = P; p->Q = Q;
+    p->TIW = TIW; p->TRW = TRW; p->QW = QW; p->colblocks = cb; p->chunks_per_img = cpi; p->nchunks = nc;
+    p->splits = s; p->chunks_per_split = cps; p->bplane = bplane;
+  }
+  return true;
+}
+
+// packed three-limb weight panel (forward-direction layout: BM = 128, transposed-direction layout: BM = 64) in the pack-cache
+// scope or at the start of `ws`
+static int x3s2_pack(const float *w, int M, int C, long sm, long sc, int BM, void *ws, size_t ws_bytes, hipStream_t st,
+                     const unsigned short **out) {
+  const size_t need = (size_t)M * C * 9 * 3 * sizeof(unsigned short);
+  bool hit = false;
+  void *slot = pack_cache_slot(w, /*tag: X3 stride-2 layout*/ (1 << 24) + BM, M, C, sm, sc, need, &hit, st);
+  if (!slot) {
+    if (!ws || ws_bytes < need) {
+      set_error("x3 stride-2 conv: workspace too small (%zu < %zu)", ws_bytes, need);
+      return LSPS_E_ARG;
+    }
+    slot = ws;
+  }
+  *out = (const unsigned short *)slot;
+  if (hit) return 0;
+  X3S2Pack pp;
+  pp.W = w; pp.Wq = (unsigned short *)slot; pp.M = M; pp.C = C; pp.sm = sm; pp.sc = sc;
+  if (BM == 128)
+    hipLaunchKernelGGL(x3s2_pack_kernel, dim3(ceil_div((long)M * C * 9, 256)), dim3(256), 0, st, pp);
+  else
+    hipLaunchKernelGGL(x3s2_pack_tr_kernel, dim3(ceil_div((long)M * C * 9, 256)), dim3(256), 0, st, pp);
+  LSPS_CHECK_LAUNCH("x3s2_pack");
+  return 0;
+}
+
+// bias-gradient partial sums of a MASKED transposed launch: [ntiles][M] floats at the END of the workspace
+static float *x3s2_dbpart(void *ws, size_t ws_bytes, int ntiles, int M, size_t pack_bytes) {
+  const size_t need = (size_t)ntiles * M * sizeof(float);
+  if (!ws || ws_bytes < align_up(pack_bytes, 256) + need + 256) return nullptr;
+  return reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + ((ws_bytes - need) & ~(size_t)255));
+}
+
 static int x3_device_cus() {
   static int cus = 0;
   if (!cus) {
@@ -36,6 +123,116 @@ static int x3_device_cus() {
     cus = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount : 256;
   }
   return cus;
+}
+
+
+// small[n][m] = act(bias + sum Wt[m][kk][r][s] big[n][kk][2p+r-1][2q+s-1]);  W element (m, kk, t) at m*sm + kk*sc + t
+static int x3s2_run_fwd(const void *big, const float *w, long sm, long sc, const float *bias, float *y, void *yl, int N, int Cx, int H, int W,
+                        int M, float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+  X3S2Params p;
+  if (!x3s2_fwd_geom(N, Cx, H, W, M, &p)) {
+    set_error("x3 stride-2 conv (forward direction): unsupported geometry N=%d C=%d %dx%d M=%d", N, Cx, H, W, M);
+    return LSPS_E_ARG;
+  }
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) {
+    set_error("x3 stride-2 conv: the bias must be 16-byte aligned");
+    return LSPS_E_ARG;
+  }
+  const unsigned short *wq = nullptr;
+  if (int rc = x3s2_pack(w, M, Cx, sm, sc, 128, ws, ws_bytes, st, &wq)) return rc;
+  p.X = (const unsigned short *)big;
+  p.Wq = wq;
+  p.bias = bias;
+  p.Y = y;
+  p.YL = (unsigned short *)yl;
+  p.N = N; p.Cx = Cx; p.M = M;
+  p.lrelu = slope >= 0.f ? slope : 1.f;
+  const dim3 grid(std::min((p.ntiles + 7) / 8 * 8 * (M >> 7), x3_device_cus() / 8 * 8));
+  if (yl) {
+    if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_fwd_kernel<true>), X3F_LDS_BYTES, "x3s2_fwd")) return rc;
+    hipLaunchKernelGGL(x3s2_fwd_kernel<true>, grid, dim3(512), X3F_LDS_BYTES, st, p);
+  } else {
+    if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_fwd_kernel<false>), X3F_LDS_BYTES, "x3s2_fwd")) return rc;
+    hipLaunchKernelGGL(x3s2_fwd_kernel<false>, grid, dim3(512), X3F_LDS_BYTES, st, p);
+  }
+  LSPS_CHECK_LAUNCH("x3s2_fwd");
+  return 0;
+}
+
+// big[n][m][2p+r-1][2q+s-1] += Wt[m][kk][r][s] small[n][kk][p][q] (+ bias, activation); H x W = the big map
+static int x3s2_run_tr(const void *small, const float *w, long sm, long sc, const float *bias, float *y, void *yl, int N, int Cx, int H,
+                       int W, int M, float slope, void *ws, size_t ws_bytes, hipStream_t st, const void *act_y = nullptr,
+                       float act_slope = 0.f, float *db_prev = nullptr) {
+  X3S2TParams p;
+  if (!x3s2_tr_geom(N, Cx, H, W, M, &p)) {
+    set_error("x3 stride-2 conv (transposed direction): unsupported geometry N=%d C=%d -> %dx%d M=%d", N, Cx, H, W, M);
+    return LSPS_E_ARG;
+  }
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) {
+    set_error("x3 stride-2 conv: the bias must be 16-byte aligned");
+    return LSPS_E_ARG;
+  }
+  const unsigned short *wq = nullptr;
+  if (int rc = x3s2_pack(w, M, Cx, sm, sc, 64, ws, ws_bytes, st, &wq)) return rc;
+  p.X = (const unsigned short *)small;
+  p.Wq = wq;
+  p.bias = bias;
+  p.Y = y;
+  p.YL = (unsigned short *)yl;
+  p.N = N; p.Cx = Cx; p.M = M;
+  p.lrelu = slope >= 0.f ? slope : 1.f;
+  p.ActY = (const unsigned short *)act_y;
+  p.act_slope = act_slope;
+  p.dbpart = nullptr;
+  if (act_y) {
+    p.dbpart = x3s2_dbpart(ws, ws_bytes, p.ntiles, M, (size_t)M * Cx * 9 * 3 * sizeof(unsigned short));
+    if (!p.dbpart) {
+      set_error("x3 stride-2 conv: workspace too small for the bias-gradient partial sums");
+      return LSPS_E_ARG;
+    }
+  }
+  const dim3 grid(std::min((p.ntiles + 7) / 8 * 8 * (M >> 6), x3_device_cus() / 8 * 8));
+#define X3T_LAUNCH(O3, MK)                                                                                                \
+  do {                                                                                                                    \
+    if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_tr_kernel<O3, MK>), X3T_LDS_BYTES, "x3s2_tr")) return rc;  \
+    hipLaunchKernelGGL((x3s2_tr_kernel<O3, MK>), grid, dim3(512), X3T_LDS_BYTES, st, p);                                  \
+  } while (0)
+  if (yl) {
+    if (act_y) X3T_LAUNCH(true, true); else X3T_LAUNCH(true, false);
+  } else {
+    if (act_y) X3T_LAUNCH(false, true); else X3T_LAUNCH(false, false);
+  }
+#undef X3T_LAUNCH
+  LSPS_CHECK_LAUNCH("x3s2_tr");
+  if (act_y && db_prev) {
+    hipLaunchKernelGGL(x3_colsum_kernel, dim3(ceil_div(M, 64)), dim3(256), 0, st, (const float *)p.dbpart, db_prev, M, p.ntiles);
+    LSPS_CHECK_LAUNCH("x3_colsum");
+  }
+  return 0;
+}
+
+static int x3s2_run_wgrad(const void *small, const void *big, float *dw, int N, int K, int C, int H, int W, void *ws, size_t ws_bytes,
+                          hipStream_t st) {
+  X3S2WParams p;
+  if (!x3s2_wgrad_geom(N, K, C, H, W, &p)) {
+    set_error("x3 stride-2 weight gradient: unsupported geometry N=%d K=%d C=%d %dx%d", N, K, C, H, W);
+    return LSPS_E_ARG;
+  }
+  const size_t need = (size_t)p.splits * 9 * K * C * sizeof(float);
+  if (!ws || ws_bytes < need) {
+    set_error("x3 stride-2 weight gradient: workspace too small (%zu < %zu)", ws_bytes, need);
+    return LSPS_E_ARG;
+  }
+  p.S = (const unsigned short *)small;
+  p.B = (const unsigned short *)big;
+  p.part = (float *)ws;
+  if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_wgrad_kernel), X3W_LDS_BYTES, "x3s2_wgrad")) return rc;
+  const int tiles = (K >> 7) * (C >> 6);
+  hipLaunchKernelGGL(x3s2_wgrad_kernel, dim3(p.splits == 1 ? tiles : (p.splits + 7) / 8 * 8 * tiles), dim3(512), X3W_LDS_BYTES, st, p);
+  LSPS_CHECK_LAUNCH("x3s2_wgrad");
+  hipLaunchKernelGGL(x3_wgrad_reduce_kernel, dim3(ceil_div((long)K * C, 64)), dim3(256), 0, st, (const float *)p.part, dw, K * C, p.splits);
+  LSPS_CHECK_LAUNCH("x3s2_wgrad_reduce");
+  return 0;
 }
 
 }  // namespace lsps
@@ -64,49 +261,96 @@ int lsps_x3_join_nchw(const void *xl, float *y, int N, int C, int HW, void *stre
   return 0;
 }
 
-int lsps_x3_conv3x3s2_ok(int N, int C, int H, int W, int K) { return x3s2_fwd_geom(N, C, H, W, K, nullptr) ? 1 : 0; }
+int lsps_x3_conv3x3s2_ok(int N, int C, int H, int W, int K) {
+  return x3s2_fwd_geom(N, C, H, W, K, nullptr) && x3s2_tr_geom(N, K, H, W, C, nullptr) && x3s2_wgrad_geom(N, K, C, H, W, nullptr) ? 1 : 0;
+}
 
 size_t lsps_x3_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K) {
-  if (!x3s2_fwd_geom(N, C, H, W, K, nullptr)) return 0;
-  return align_up((size_t)K * C * 9 * 3 * sizeof(unsigned short), 256);
+  if (!lsps_x3_conv3x3s2_ok(N, C, H, W, K)) return 0;
+  const size_t pack = align_up((size_t)K * C * 9 * 3 * sizeof(unsigned short), 256);
+  X3S2TParams q;
+  x3s2_tr_geom(N, K, H, W, C, &q);
+  size_t need = pack + align_up((size_t)q.ntiles * C * sizeof(float), 256) + 512;     // packed weights + dgrad's bias-gradient partials
+  X3S2WParams wp;
+  x3s2_wgrad_geom(N, K, C, H, W, &wp);
+  need = std::max(need, (size_t)wp.splits * 9 * K * C * sizeof(float));
+  return need;
 }
 
 int lsps_x3_conv3x3s2_fwd(const void *xl, const float *w, const float *bias, float *y, void *yl, int N, int C, int H, int W, int K,
                           float slope, void *ws, size_t ws_bytes, void *stream) {
-  hipStream_t st = (hipStream_t)stream;
   LSPS_CHECK_ARG(xl && w && (y || yl), "x3 conv: null pointer");
-  X3S2Params p;
-  LSPS_CHECK_ARG(x3s2_fwd_geom(N, C, H, W, K, &p), "x3 stride-2 conv: unsupported geometry N=%d C=%d %dx%d K=%d", N, C, H, W, K);
-  LSPS_CHECK_ARG(!bias || !(reinterpret_cast<uintptr_t>(bias) & 15), "x3 stride-2 conv: the bias must be 16-byte aligned");
-  const size_t need = (size_t)K * C * 9 * 3 * sizeof(unsigned short);
-  bool hit = false;
-  void *slot = pack_cache_slot(w, /*tag: X3 stride-2 layout*/ (1 << 24) + 128, K, C, (long)C * 9, 9, need, &hit, st);
-  if (!slot) {
-    LSPS_CHECK_ARG(ws && ws_bytes >= need, "x3 stride-2 conv: workspace too small (%zu < %zu)", ws_bytes, need);
-    slot = ws;
+  return x3s2_run_fwd(xl, w, (long)C * 9, 9, bias, y, yl, N, C, H, W, K, slope, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_x3_conv3x3s2_dgrad(const void *dyl, const float *w, float *dx, void *dxl, const void *act_yl, float act_slope, float *db_prev,
+                            int N, int C, int H, int W, int K, void *ws, size_t ws_bytes, void *stream) {
+  LSPS_CHECK_ARG(dyl && w && (dx || dxl), "x3 conv dgrad: null pointer");
+  return x3s2_run_tr(dyl, w, 9, (long)C * 9, nullptr, dx, dxl, N, K, H, W, C, -1.f, ws, ws_bytes, (hipStream_t)stream, act_yl, act_slope,
+                     db_prev);
+}
+
+int lsps_x3_conv3x3s2_wgrad(const void *xl, const void *dyl, float *dw, int N, int C, int H, int W, int K, void *ws, size_t ws_bytes,
+                            void *stream) {
+  LSPS_CHECK_ARG(xl && dyl && dw, "x3 conv wgrad: null pointer");
+  return x3s2_run_wgrad(dyl, xl, dw, N, K, C, H, W, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_x3_convT3x3s2_ok(int N, int Ci, int H, int W, int Co) {
+  return x3s2_tr_geom(N, Ci, 2 * H, 2 * W, Co, nullptr) && x3s2_fwd_geom(N, Co, 2 * H, 2 * W, Ci, nullptr) &&
+                 x3s2_wgrad_geom(N, Ci, Co, 2 * H, 2 * W, nullptr)
+             ? 1 : 0;
+}
+
+/* ConvTranspose2d(Ci, Co, 3, 2, 1, 1): x [N,Ci,H,W] -> y [N,Co,2H,2W]; w (Ci,Co,3,3).  Workspace: lsps_x3_conv3x3s2_workspace_bytes
+ * (N, Co, 2H, 2W, Ci). */
+int lsps_x3_convT3x3s2_fwd(const void *xl, const float *w, const float *bias, float *y, void *yl, int N, int Ci, int H, int W, int Co,
+                           float slope, void *ws, size_t ws_bytes, void *stream) {
+  LSPS_CHECK_ARG(xl && w && (y || yl), "x3 convT: null pointer");
+  return x3s2_run_tr(xl, w, 9, (long)Co * 9, bias, y, yl, N, Ci, 2 * H, 2 * W, Co, slope, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_x3_convT3x3s2_dgrad(const void *dyl, const float *w, float *dx, void *dxl, int N, int Ci, int H, int W, int Co, void *ws,
+                             size_t ws_bytes, void *stream) {
+  LSPS_CHECK_ARG(dyl && w && (dx || dxl), "x3 convT dgrad: null pointer");
+  return x3s2_run_fwd(dyl, w, (long)Co * 9, 9, nullptr, dx, dxl, N, Co, 2 * H, 2 * W, Ci, -1.f, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int lsps_x3_convT3x3s2_wgrad(const void *xl, const void *dyl, float *dw, int N, int Ci, int H, int W, int Co, void *ws, size_t ws_bytes,
+                             void *stream) {
+  LSPS_CHECK_ARG(xl && dyl && dw, "x3 convT wgrad: null pointer");
+  return x3s2_run_wgrad(xl, dyl, dw, N, Ci, Co, 2 * H, 2 * W, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t lsps_x3_act_bwd_bias_workspace_bytes(int N, int C) {
+  if (N <= 0 || C <= 0) return 0;
+  return ((size_t)256 + 8) * C * sizeof(float);
+}
+
+/* g (X3) = dy * LeakyReLU'(y) from f32 NCHW dy and the layer's f32 NCHW OUTPUT y (slope < 0: g = dy, y may be NULL);
+ * db [C] (nullable) = sum of g over n and pixels. */
+int lsps_x3_act_bwd_bias(const float *dy, const float *y, void *gl, float *db, int N, int C, int HW, float slope, void *ws,
+                         size_t ws_bytes, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  LSPS_CHECK_ARG(dy && gl && (y || slope < 0.f), "x3 act_bwd_bias: null pointer");
+  LSPS_CHECK_ARG(N > 0 && C > 0 && (C & 7) == 0 && HW > 0, "x3 act_bwd_bias: C must be a multiple of 8");
+  // enough workgroups to fill the chip: (C / 8) x splits >= ~1024
+  int splits = std::max(1, std::min(N, (int)((1024 + (C >> 3) - 1) / (C >> 3))));
+  if (splits > 256) splits = 256;
+  const int ips = (N + splits - 1) / splits;
+  splits = (N + ips - 1) / ips;
+  float *part = nullptr;
+  if (db) {
+    LSPS_CHECK_ARG(ws && ws_bytes >= (size_t)splits * C * sizeof(float), "x3 act_bwd_bias: workspace too small");
+    part = (float *)ws;
   }
-  if (!hit) {
-    X3S2Pack pp;
-    pp.W = w; pp.Wq = (unsigned short *)slot; pp.M = K; pp.C = C; pp.sm = (long)C * 9; pp.sc = 9;
-    hipLaunchKernelGGL(x3s2_pack_kernel, dim3(ceil_div((long)K * C * 9, 256)), dim3(256), 0, st, pp);
-    LSPS_CHECK_LAUNCH("x3s2_pack");
+  hipLaunchKernelGGL(x3_act_bwd_bias_nchw_kernel, dim3(C >> 3, splits), dim3(256), 0, st, dy, y, (unsigned short *)gl, part, N, C, HW, ips,
+                     slope);
+  LSPS_CHECK_LAUNCH("x3_act_bwd_bias");
+  if (db) {
+    hipLaunchKernelGGL(x3_colsum_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, (const float *)part, db, C, splits);
+    LSPS_CHECK_LAUNCH("x3_colsum");
   }
-  p.X = (const unsigned short *)xl;
-  p.Wq = (const unsigned short *)slot;
-  p.bias = bias;
-  p.Y = y;
-  p.YL = (unsigned short *)yl;
-  p.N = N; p.Cx = C; p.M = K;
-  p.lrelu = slope >= 0.f ? slope : 1.f;
-  const dim3 grid(std::min((p.ntiles + 7) / 8 * 8 * (K >> 7), x3_device_cus() / 8 * 8));
-  if (yl) {
-    if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_fwd_kernel<true>), X3F_LDS_BYTES, "x3s2_fwd")) return rc;
-    hipLaunchKernelGGL(x3s2_fwd_kernel<true>, grid, dim3(512), X3F_LDS_BYTES, st, p);
-  } else {
-    if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_fwd_kernel<false>), X3F_LDS_BYTES, "x3s2_fwd")) return rc;
-    hipLaunchKernelGGL(x3s2_fwd_kernel<false>, grid, dim3(512), X3F_LDS_BYTES, st, p);
-  }
-  LSPS_CHECK_LAUNCH("x3s2_fwd");
   return 0;
 }
 

@@ -19,11 +19,11 @@
 // kernel: each fragment feeds three or two products).
 #ifndef LSPS_X3S2_H
 #define LSPS_X3S2_H
-#include "conv_types.h"
+#include "c8util.h"
 
 namespace lsps {
 
-typedef __attribute__((address_space(3))) void *x3_lds_ptr;
+typedef c8_lds_ptr x3_lds_ptr;
 
 #define X3_OOB 0x80000000u
 
@@ -109,7 +109,7 @@ struct X3S2Params {
   float lrelu;                   // epilogue: v = max(v, v * lrelu) (1 = no activation)
 };
 
-#define X3F_BP 9                                           // image pieces (64 units) per limb and stage: <= 576 units
+#define X3F_BP 10                                          // image pieces (64 units) per limb and stage: <= 640 units
 #define X3F_AP 12                                          // weight pieces per limb and stage: 3 taps x 2 k-halves x 128 m
 #define X3F_APIECES (3 * X3F_AP)
 #define X3F_BPIECES (3 * X3F_BP)
@@ -309,6 +309,571 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
     if (!more) return;
     lin += G;
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// transposed direction (Conv2d dgrad, ConvTranspose2d forward): big[n][m][2p+r-1][2q+s-1] += Wt[m][kk][r][s] small[n][kk][p][q].
+// Workgroup = 64 m x 256 SMALL pixels x the four output parity classes of a 2x2 block (c8s2_tr_kernel's tiling: tap (r, s)
+// feeds class (r != 1, s != 1) from the small pixel shifted by (r == 0, s == 0): no multiply-by-zero work); 8 waves = 2 (m)
+// x 4 (pixels), wave tile 32 m x 64 small pixels x 4 classes = 8 accumulator tiles.  A STAGE is (16-channel k-step, tap row
+// r): three limbs of the TR small rows p + (r == 0) (one halo column of zeros per row) + three limbs of the 3 taps' weights.
+// Epilogue: bias + LeakyReLU; optionally (MASKED) the LeakyReLU BACKWARD of the layer whose output gradient this is (from the hi
+// limb of that layer's saved X3 output: sign(x) = sign(hi)) and that layer's bias-gradient partial sums; output f32 NCHW or X3.
+// ------------------------------------------------------------------------------------------------------------------
+struct X3S2TParams {
+  const unsigned short *X;       // small [N][3][Cx/8][P][Q][8]
+  const unsigned short *Wq;      // x3s2_pack_tr_kernel's layout
+  const float *bias;             // [M] or null
+  float *Y;                      // f32 [N][M][H][W] (OUT3 = false)
+  unsigned short *YL;            // [N][3][M/8][H][W][8] (OUT3 = true)
+  int N, Cx, M;
+  int H, W, P, Q;                // big (output) map H x W, small map P x Q
+  int TI, TR;                    // pixel tile of the SMALL map: TI images x TR rows x Q columns = 256 pixels
+  int tiles_per_img, ntiles;
+  float lrelu;
+  const unsigned short *ActY;    // MASKED: X3 saved output of the previous layer (Y's shape); only its hi limb is read
+  float act_slope;
+  float *dbpart;                 // MASKED: [ntiles][M]
+};
+
+// Wq[m tile of 64][k-step of 16 c][tap row r][limb][tap column s][k-half][64 m][8 c]
+__global__ __launch_bounds__(256) void x3s2_pack_tr_kernel(X3S2Pack p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // over [mt][ks][r][s][kh][64][8]
+  const long total = (long)p.M * p.C * 9;
+  if (idx >= total) return;
+  const int e = (int)(idx & 7), ml = (int)((idx >> 3) & 63), kh = (int)((idx >> 9) & 1);
+  long rest = idx >> 10;
+  const int s = (int)(rest % 3);
+  rest /= 3;
+  const int r = (int)(rest % 3);
+  rest /= 3;
+  const int chunks = p.C >> 4;
+  const int chunk = (int)(rest % chunks), mt = (int)(rest / chunks);
+  const int m = mt * 64 + ml, c = chunk * 16 + kh * 8 + e;
+  const float x = p.W[(long)m * p.sm + (long)c * p.sc + 3 * r + s];
+  const __bf16 h = (__bf16)x;
+  const float r1 = x - (float)h;
+  const __bf16 mi = (__bf16)r1;
+  const __bf16 lo = (__bf16)(r1 - (float)mi);
+  const long stage = ((long)mt * chunks + chunk) * 3 + r;
+  const long o = (stage * 9 + s) * 1024 + kh * 512 + ml * 8 + e;    // limb 0; limb l at + l * 3 * 1024
+  p.Wq[o] = __builtin_bit_cast(unsigned short, h);
+  p.Wq[o + 3 * 1024] = __builtin_bit_cast(unsigned short, mi);
+  p.Wq[o + 6 * 1024] = __builtin_bit_cast(unsigned short, lo);
+}
+
+#define X3T_BP 12                                          // image pieces per limb and stage: <= 768 units (2 k-halves)
+#define X3T_AP 6                                           // weight pieces per limb and stage: 3 taps x 2 k-halves x 64 m
+#define X3T_BPIECES (3 * X3T_BP)
+#define X3T_APIECES (3 * X3T_AP)
+#define X3T_ASTAGE (X3T_APIECES * 1024)
+#define X3T_STAGE ((X3T_BPIECES + X3T_APIECES) * 1024)     // 55296
+#define X3T_LDS_BYTES (2 * X3T_STAGE)                      // 110592
+
+template <bool OUT3, bool MASKED>
+__global__ __launch_bounds__(512, 1) void x3s2_tr_kernel(X3S2TParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char x3_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave & 1, wp = wave >> 1;
+  typedef unsigned long long u64;
+
+  const int MT = p.M >> 6, G = gridDim.x, nlin = ((p.ntiles + 7) >> 3) * 8 * MT;
+  const int TI = p.TI, TR = p.TR, Q = p.Q;
+  const int CB = Q + 1, blk = TR * CB, plane = TI * blk, bunits = 2 * plane;
+  const int Q16 = Q * 16, PQ16 = p.P * Q16, img_bytes = (p.Cx >> 3) * PQ16, nks = p.Cx >> 4;
+  const long HWl = (long)p.H * p.W;
+
+  int mt, ptile, n0, p0, nimg;
+  __amdgpu_buffer_rsrc_t xrs, wrs;
+  constexpr int NB = (X3T_BPIECES + 7) / 8, NA = (X3T_APIECES + 7) / 8;      // 5, 3
+  unsigned voffb[NB];                                           // source offset for the un-shifted rows (r = 1, 2), or X3_OOB
+  unsigned lastrow = 0;                                         // bit i: piece i's unit is in small row P - 1 (dead under r = 0)
+  const unsigned voffa = (unsigned)((wave * 64 + lane) * 16);
+
+  auto decode = [&](int lin, int &mt_, int &ptile_) {
+    const int xcd = lin & 7, qq = lin >> 3;
+    mt_ = qq % MT;
+    ptile_ = xcd + 8 * (qq / MT);
+    return lin < nlin && ptile_ < p.ntiles;
+  };
+  auto setup = [&](int mt_, int ptile_) {
+    mt = mt_; ptile = ptile_;
+    if (TI == 1) {
+      n0 = ptile / p.tiles_per_img;
+      p0 = (ptile - n0 * p.tiles_per_img) * TR;
+    } else {
+      n0 = ptile * TI;
+      p0 = 0;
+    }
+    nimg = min(TI, p.N - n0);
+    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.X) + (long)n0 * 3 * (img_bytes >> 1), 0, nimg * 3 * img_bytes,
+                                            0x00020000);
+    wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.Wq) + (long)mt * nks * 3 * (X3T_ASTAGE >> 1), 0,
+                                            nks * 3 * X3T_ASTAGE, 0x00020000);
+    lastrow = 0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int j = wave + 8 * i, limb = min(j / X3T_BP, 2), pc = j % X3T_BP;
+      const int u = pc * 64 + lane;
+      unsigned v = X3_OOB;
+      if (j < X3T_BPIECES && u < bunits) {
+        const int kh = u >= plane ? 1 : 0, rem = u - kh * plane;
+        const int img = rem / blk, rem2 = rem - img * blk;
+        const int ri = rem2 / CB, ci = rem2 - ri * CB;
+        const int row = p0 + ri;
+        if (row < p.P && ci < Q && img < nimg) {
+          v = (unsigned)((img * 3 + limb) * img_bytes + kh * PQ16 + (row * Q + ci) * 16);
+          if (row == p.P - 1) lastrow |= 1u << i;
+        }
+      }
+      voffb[i] = v;
+    }
+  };
+  auto issue = [&](int ks, int r, int buf) {
+    unsigned char *base = x3_lds + buf * X3T_STAGE;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int piece = wave + 8 * i;
+      if (piece < X3T_BPIECES) {
+        unsigned v = voffb[i];
+        if (r == 0) v = ((lastrow >> i) & 1u) || v == X3_OOB ? X3_OOB : v + (unsigned)Q16;      // rows p + 1
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (x3_lds_ptr)(base + piece * 1024), 16, v, ks * 2 * PQ16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int piece = wave + 8 * i;
+      if (piece < X3T_APIECES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (x3_lds_ptr)(base + (X3T_BPIECES + piece) * 1024), 16, voffa,
+                                                 (ks * 3 + r) * X3T_ASTAGE + i * 8192, 0, 0);
+    }
+  };
+
+  unsigned bbase[2];
+  int ygeo[2];                                                  // image << 20 | row << 10 | column of this lane's two tile pixels
+  const int tpi = TR * Q;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int t = wp * 64 + 32 * j + l31;
+    const int il = t / tpi, rem = t - il * tpi;
+    const int pl = rem / Q, ql = rem - pl * Q;
+    bbase[j] = (unsigned)((half * plane + il * blk + pl * CB + ql) * 16);
+    ygeo[j] = il << 20 | pl << 10 | ql;
+  }
+  const unsigned a_base = (unsigned)(X3T_BPIECES * 1024 + (half * 64 + wm * 32 + l31) * 16);
+
+  int lin = blockIdx.x, buf = 0;
+  {
+    int m_, t_;
+    if (!decode(lin, m_, t_)) return;
+    setup(m_, t_);
+  }
+  issue(0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  while (true) {
+    const int mt_c = mt, ptile_c = ptile;
+    long ypix[2];                                                // pixel index of (n, row 2p, column 2q) in an H x W plane set, or -1
+    int yn[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int il = ygeo[j] >> 20, pl = (ygeo[j] >> 10) & 1023, ql = ygeo[j] & 1023;
+      yn[j] = n0 + il;
+      ypix[j] = il < nimg ? (long)(2 * (p0 + pl)) * p.W + 2 * ql : -1;
+    }
+    int mt_n, ptile_n;
+    const bool more = decode(lin + G, mt_n, ptile_n);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
+
+    for (int ks = 0; ks < nks; ++ks) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if (r < 2) {
+          issue(ks, r + 1, buf ^ 1);
+        } else if (ks + 1 < nks) {
+          issue(ks + 1, 0, buf ^ 1);
+        } else if (more) {
+          setup(mt_n, ptile_n);
+          issue(0, 0, buf ^ 1);
+        }
+        const unsigned char *S = x3_lds + buf * X3T_STAGE;
+        bf16x8 bf[2][2][3];                                      // [column shift][j][limb]
+#pragma unroll
+        for (int sc = 0; sc < 2; ++sc)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+              bf[sc][j][l] = *reinterpret_cast<const bf16x8 *>(S + l * (X3T_BP * 1024) + bbase[j] + sc * 16);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int cls = (r != 1 ? 2 : 0) + (s != 1 ? 1 : 0), sc = s == 0 ? 1 : 0;
+          bf16x8 af[3];
+#pragma unroll
+          for (int l = 0; l < 3; ++l) af[l] = *reinterpret_cast<const bf16x8 *>(S + a_base + ((l * 3 + s) * 128) * 16);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[cls][j] = mfma_split6(af[0], af[1], af[2], bf[sc][j][0], bf[sc][j][1], bf[sc][j][2], acc[cls][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        buf ^= 1;
+      }
+    }
+
+    // epilogue.  acc[cls = 2a + b][j][r]: channel mt*64 + wm*32 + (r&3) + 8 (r>>2) + 4 half at output (2p + a, 2q + b)
+    float sdb[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sdb[e] = 0.f;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int m8 = mt_c * 64 + wm * 32 + 8 * rq;                // channel group's first channel
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) b4 = *reinterpret_cast<const f32x4 *>(p.bias + m8 + 4 * half);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (ypix[j] < 0) continue;
+          float v[2][4];                                          // [b][e]
+          u64 am[2] = {0ull, 0ull};
+          if (MASKED) {
+            // hi limb of the saved output: unit (n, limb 0, group, row 2p + a, column 2q + b), this lane's 8 bytes
+            const long u0 = ((long)yn[j] * 3 * (p.M >> 3) + (m8 >> 3)) * HWl + ypix[j] + (long)a * p.W;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) am[b] = reinterpret_cast<const u64 *>(p.ActY)[((u0 + b) << 1) + half];
+          }
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const bf16x4 mk = __builtin_bit_cast(bf16x4, am[b]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = acc[a * 2 + b][j][rq * 4 + e] + b4[e];
+              x = fmaxf(x, x * p.lrelu);
+              if (MASKED) {
+                x = c8_sel_nonpos((float)mk[e], x * p.act_slope, x);
+                sdb[rq * 4 + e] += x;
+              }
+              v[b][e] = x;
+            }
+          }
+          if (!OUT3) {
+            // f32 NCHW: a lane's (b = 0, 1) pair of one channel is 8 contiguous bytes; 32 lanes = 256 contiguous bytes
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float *dst = p.Y + ((long)yn[j] * p.M + m8 + 4 * half + e) * HWl + ypix[j] + (long)a * p.W;
+              *reinterpret_cast<f32x2 *>(dst) = f32x2{v[0][e], v[1][e]};
+            }
+          } else {
+            unsigned w[3][2][2];                                  // [limb][b][dword]
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              bf16x4 h, mi, lo;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                h[e] = (__bf16)v[b][e];
+                const float r1 = v[b][e] - (float)h[e];
+                mi[e] = (__bf16)r1;
+                lo[e] = (__bf16)(r1 - (float)mi[e]);
+              }
+              const uint2 uh = __builtin_bit_cast(uint2, h), um = __builtin_bit_cast(uint2, mi), ul = __builtin_bit_cast(uint2, lo);
+              w[0][b][0] = uh.x; w[0][b][1] = uh.y;
+              w[1][b][0] = um.x; w[1][b][1] = um.y;
+              w[2][b][0] = ul.x; w[2][b][1] = ul.y;
+            }
+            // exchange the two column classes across the half-waves (c8s2_tr_kernel): lanes 0-31 store the whole 16-byte unit of
+            // column 2q, lanes 32-63 that of column 2q + 1
+            const long unit0 = ((long)yn[j] * 3 * (p.M >> 3) + (m8 >> 3)) * HWl + ypix[j] + (long)a * p.W + half;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+#pragma unroll
+              for (int d = 0; d < 2; ++d) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(w[l][0][d], w[l][1][d], false, false);
+                w[l][0][d] = sw[0];
+                w[l][1][d] = sw[1];
+              }
+              reinterpret_cast<u32x4 *>(p.YL)[unit0 + (long)l * (p.M >> 3) * HWl] = u32x4{w[l][0][0], w[l][0][1], w[l][1][0], w[l][1][1]};
+            }
+          }
+        }
+    }
+    if (MASKED) {
+      // 16 channel slots per lane: add the two 16-lane halves of the 32 pixel lanes, butterfly over the remaining four bits,
+      // then sum the 4 pixel waves through LDS (the buffer that is dead until the next tile's second stage is requested)
+      float sd32[32];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sd32[e] = sdb[e] + __shfl_xor(sdb[e], 16, 64);
+#pragma unroll
+      for (int e = 16; e < 32; ++e) sd32[e] = 0.f;
+      c8_reduce_scatter32<8>(sd32, l31);                           // lane: slot (l31 & 15) = r of its half
+      float *red = reinterpret_cast<float *>(x3_lds + (buf ^ 1) * X3T_STAGE);   // [wave 8][half 2][16]
+      if ((l31 & 16) == 0) red[(wave * 2 + half) * 16 + l31] = sd32[0];
+      __syncthreads();
+      if (tid < 64) {                                              // (wm, half, slot)
+        const int w_m = tid >> 5, hf = (tid >> 4) & 1, qs = tid & 15;
+        float t = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) t += red[((w4 * 2 + w_m) * 2 + hf) * 16 + qs];
+        const int m = mt_c * 64 + w_m * 32 + (qs & 3) + 8 * (qs >> 2) + 4 * hf;
+        p.dbpart[(long)ptile_c * p.M + m] = t;
+      }
+      __syncthreads();                                             // before the next tile's DMA lands on `red`
+    }
+    if (!more) return;
+    lin += G;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient: dW[k][c][r][s] = sum_{n,p,q} small[n][k][p][q] big[n][c][2p+r-1][2q+s-1], both operands X3, the reduction
+// runs over pixels: fragments by transposing LDS reads (c8wgrad.h, c8s2.h).  Workgroup = 128 k x 64 c x 9 taps for a range of
+// pixel chunks; chunk = 16 small pixels (one k-step: TRW rows x QW columns of one image, or TIW whole images) whose big-tensor
+// patch ((2 TRW + 1) x (2 QW + 1) input pixels, columns de-interleaved by parity) is staged per channel group; a stage holds the
+// three limbs of both operands (<= 55 KB), double buffered.  8 waves = 4 (k) x 2 (c), 9 accumulator tiles each.
+// ------------------------------------------------------------------------------------------------------------------
+#define X3W_SBYTES 4096                                     // small tensor per limb: 16 k-groups x 16 pixels = 4 DMA pieces
+#define X3W_BP 14                                           // big tensor pieces per limb: 8 planes of <= 108 units = 864 units
+#define X3W_LIMB (X3W_SBYTES + X3W_BP * 1024)               // 18432
+#define X3W_STAGE (3 * X3W_LIMB)                            // 55296
+#define X3W_LDS_BYTES (2 * X3W_STAGE)                       // 110592
+
+struct X3S2WParams {
+  const unsigned short *S;       // small [N][3][K/8][P][Q][8]
+  const unsigned short *B;       // big [N][3][C/8][H][W][8]
+  float *part;                   // [splits][9][K][C]
+  int N, K, C;
+  int H, W, P, Q;
+  int TIW, TRW, QW;              // chunk: TIW images x TRW rows x QW columns = 16 small pixels
+  int colblocks;                 // Q / QW
+  int chunks_per_img, nchunks;   // nchunks = N * chunks_per_img, or ceil(N / TIW)
+  int splits, chunks_per_split;
+  int bplane;                    // units per channel-group plane of the big tensor's LDS image (4 mod 8)
+};
+
+__global__ __launch_bounds__(512, 1) void x3s2_wgrad_kernel(X3S2WParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char x3_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave >> 1, wc = wave & 1;
+
+  const int CT = p.C >> 6, KT = p.K >> 7, tiles = CT * KT;
+  const int lin = blockIdx.x, xcd = lin & 7, qq = lin >> 3;
+  const int tile = p.splits == 1 ? lin : qq % tiles, split = p.splits == 1 ? 0 : xcd + 8 * (qq / tiles);
+  if (split >= p.splits || tile >= tiles) return;
+  const int kt = tile / CT, ct = tile - kt * CT;
+  const int c0 = split * p.chunks_per_split, c1 = min(p.nchunks, c0 + p.chunks_per_split);
+
+  const int Q = p.Q, TIW = p.TIW, TRW = p.TRW, QW = p.QW;
+  const int CB = 2 * QW + 1, blk = (2 * TRW + 1) * CB;          // units per image of a plane
+  const int PQ16 = p.P * Q * 16, HW16 = p.H * p.W * 16;
+  const int s_img = (p.K >> 3) * PQ16, b_img = (p.C >> 3) * HW16;  // bytes per image and limb
+  const int tpi = TRW * QW;                                     // chunk pixels per image
+
+  // DMA pieces: small tensor 4 per limb (piece q = k-groups 4 q .. 4 q + 3 x 16 pixels), big tensor <= 14 per limb; a wave's
+  // list covers all three limbs: small pieces j = wave + 8 i (i < 2, j < 12: limb j / 4, q = j % 4), big pieces j = wave + 8 i
+  // (i < 6, j < 42: limb j / 14).  LDS-DMA lands lane-linear (slot = lane), the SOURCE address is free: slot sigma of a small piece
+  // holds (pixel quad sigma / 16, k-group (sigma / 4) % 4, pixel sigma % 4 of the quad), i.e. byte quad * 256 + group * 64 +
+  // pixel * 16: the four k-groups a transposing read phase touches (same quad) fill one 256-byte row = all 64 banks once.
+  int voffs[2], voffb[6];
+  unsigned topm = 0, leftm = 0;                                 // bit i: big piece i's unit lies in the patch's first row / first column
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = wave + 8 * i, limb = min(j >> 2, 2), q4 = j & 3;
+    const int t = (lane >> 4) * 4 + (lane & 3), kg = q4 * 4 + ((lane >> 2) & 3);
+    const int il = t / tpi, rem = t - il * tpi, pl = rem / QW, ql = rem - pl * QW;
+    voffs[i] = (il * 3 + limb) * s_img + (kt * 16 + kg) * PQ16 + (pl * Q + ql) * 16;
+  }
+  const int bunits = 8 * p.bplane;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int j = wave + 8 * i, limb = min(j / X3W_BP, 2), pc = j % X3W_BP;
+    const int u = pc * 64 + lane;
+    int v = (int)X3_OOB;
+    if (j < 3 * X3W_BP && u < bunits) {
+      const int cg = u / p.bplane, rem = u - cg * p.bplane;
+      if (rem < TIW * blk) {
+        const int il = rem / blk, rem2 = rem - il * blk;
+        const int ri = rem2 / CB, ci = rem2 - ri * CB;
+        const int col = ci <= QW ? 2 * ci - 1 : 2 * (ci - QW - 1);    // relative to 2 q0; -1 = the left neighbour column
+        v = (il * 3 + limb) * b_img + (ct * 8 + cg) * HW16 + (ri * p.W + col) * 16;   // row = 2 p0 - 1 + ri, column = 2 q0 + col:
+        if (ri == 0) topm |= 1u << i;                                                  // the chunk's origin is added per chunk
+        if (ci == 0) leftm |= 1u << i;
+      }
+    }
+    voffb[i] = v;
+  }
+  auto issue = [&](int chunk, int stage) {
+    int n, p0, q0;
+    if (TIW == 1) {
+      n = chunk / p.chunks_per_img;
+      const int rem = chunk - n * p.chunks_per_img;
+      const int rb = rem / p.colblocks;
+      p0 = rb * TRW;
+      q0 = (rem - rb * p.colblocks) * QW;
+    } else {
+      n = chunk * TIW;
+      p0 = 0;
+      q0 = 0;
+    }
+    const int nimg = min(TIW, p.N - n);
+    const c8_i32x4 srs = c8_rsrc_words(p.S + (long)n * 3 * (s_img >> 1), (unsigned)(nimg * 3 * s_img));
+    const c8_i32x4 brs = c8_rsrc_words(p.B + (long)n * 3 * (b_img >> 1), (unsigned)(nimg * 3 * b_img));
+    const unsigned base = c8_lds_addr(x3_lds) + stage * X3W_STAGE;
+    const int sdelta = (p0 * Q + q0) * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = wave + 8 * i;
+      if (j < 12) c8_dma16_asm(srs, base + (j >> 2) * X3W_LIMB + (j & 3) * 1024, (unsigned)(voffs[i] + sdelta), 0);
+    }
+    const int bdelta = ((2 * p0 - 1) * p.W + 2 * q0) * 16;      // first staged row is 2 p0 - 1, column origin 2 q0
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int j = wave + 8 * i;
+      if (j < 3 * X3W_BP) {
+        const bool dead = voffb[i] == (int)X3_OOB || (p0 == 0 && ((topm >> i) & 1u)) || (q0 == 0 && ((leftm >> i) & 1u));
+        c8_dma16_asm(brs, base + (j / X3W_BP) * X3W_LIMB + X3W_SBYTES + (j % X3W_BP) * 1024, dead ? X3_OOB : (unsigned)(voffb[i] + bdelta),
+                     0);
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transposing-read addresses (c8wgrad.h): 16-lane group g: channels 16 (g & 1) .., pixels 8 (g >> 1) ..; lane i16 points at
+  // pixel + i16 / 4 (second read: + 4 = the next pixel quad = + 256 bytes), channel group 2 (g & 1) + (i16 % 4) / 2, byte 8 (i16 & 1)
+  const int g = lane >> 4, i16 = lane & 15;
+  const int cgl = 2 * (g & 1) + ((i16 & 3) >> 1), px = 8 * (g >> 1) + (i16 >> 2), byte = 8 * (i16 & 1);
+  const unsigned a_base = (unsigned)(wk * 1024 + 2 * (g >> 1) * 256 + cgl * 64 + (i16 >> 2) * 16 + byte);
+  auto bunit = [&](int t) -> int {                              // chunk pixel t -> unit of its (2p - 1, 2q - 1) corner in a plane
+    const int il = t / tpi, rem = t - il * tpi;
+    const int pl = rem / QW, ql = rem - pl * QW;
+    return il * blk + 2 * pl * CB + ql;
+  };
+  const unsigned b_base0 = (unsigned)(X3W_SBYTES + ((wc * 4 + cgl) * p.bplane + bunit(px)) * 16 + byte);
+  const unsigned b_base1 = (unsigned)(X3W_SBYTES + ((wc * 4 + cgl) * p.bplane + bunit(px + 4)) * 16 + byte);
+
+  if (c1 > c0) {
+    issue(c0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  for (int it = c0; it < c1; ++it) {
+    const int stage = (it - c0) & 1;
+    if (it + 1 < c1) issue(it + 1, stage ^ 1);
+    const unsigned char *St = x3_lds + stage * X3W_STAGE;
+    bf16x8 af[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) af[l] = c8_tr_frag(St + l * X3W_LIMB + a_base, St + l * X3W_LIMB + a_base + 256);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int r = t / 3, s = t % 3;
+      const int o = (r * CB + (s == 0 ? 0 : (s == 1 ? QW + 1 : 1))) * 16;
+      bf16x8 bf[3];
+#pragma unroll
+      for (int l = 0; l < 3; ++l) bf[l] = c8_tr_frag(St + l * X3W_LIMB + b_base0 + o, St + l * X3W_LIMB + b_base1 + o);
+      acc[t] = mfma_split6(af[0], af[1], af[2], bf[0], bf[1], bf[2], acc[t]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  const int l31 = lane & 31, half = lane >> 5;
+  float *out = p.part + ((long)split * 9) * p.K * p.C + (long)(kt * 128 + wk * 32 + 4 * half) * p.C + ct * 64 + wc * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(long)t * p.K * p.C + (long)((r & 3) + 8 * (r >> 2)) * p.C] = acc[t][r];
+}
+
+// dW[k][c][t] = sum_s part[s][t][k][c]   (c8_wgrad_reduce_kernel's twin in this translation unit)
+__global__ __launch_bounds__(256) void x3_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, int KC, int splits) {
+  __shared__ float red[4][9][64];
+  const int tid = threadIdx.x, l = tid & 63, sl = tid >> 6, kc = blockIdx.x * 64 + l;
+  float s[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s[t] = 0.f;
+  if (kc < KC)
+    for (int sp = sl; sp < splits; sp += 4)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) s[t] += part[((long)sp * 9 + t) * KC + kc];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) red[sl][t][l] = s[t];
+  __syncthreads();
+  for (int e = tid; e < 576; e += 256) {
+    const int ll = e / 9, t = e - ll * 9;
+    if (blockIdx.x * 64 + ll < KC)
+      dW[(long)blockIdx.x * 576 + e] = (red[0][t][ll] + red[1][t][ll]) + (red[2][t][ll] + red[3][t][ll]);
+  }
+}
+
+// out[c] = sum over rows of part[rows][C] (bias-gradient partial sums of the MASKED transposed kernel): one thread per channel,
+// four interleaved row slices
+__global__ __launch_bounds__(256) void x3_colsum_kernel(const float *__restrict__ part, float *__restrict__ out, int C, int rows) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (int r = rl; r < rows; r += 4) s += part[(long)r * C + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LeakyReLU backward from the OUTPUT + the layer's bias gradient, f32 NCHW in, X3 out: g = dy * (y > 0 ? 1 : slope) written as
+// three limbs (the operand of the X3 weight-gradient / dgrad kernels), dbpart[split][c] = sum over the split's images and pixels
+// of g.  The X3 twin of act_bwd_bias_kernel (norm_act.hip) for a layer whose output left the X3 family as f32 NCHW.
+// grid = (C / 8, splits); slope < 0: no activation (g = dy).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void x3_act_bwd_bias_nchw_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                                   unsigned short *__restrict__ g, float *__restrict__ dbpart, int N, int C,
+                                                                   int HW, int imgs_per_split, float slope) {
+  __shared__ float red[4][8];
+  const int cg = blockIdx.x, split = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = split * imgs_per_split, n1 = min(N, n0 + imgs_per_split);
+  const long cgs = C >> 3, ls = cgs * HW * 8;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  for (int n = n0; n < n1; ++n) {
+    const float *dyp = dy + ((long)n * C + cg * 8) * HW, *yp = y + ((long)n * C + cg * 8) * HW;
+    unsigned short *gp = g + ((long)n * 3 * cgs + cg) * HW * 8;
+    for (int u = tid; u < HW; u += 256) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = dyp[(long)e * HW + u];
+        v[e] = slope < 0.f ? d : c8_sel_nonpos(yp[(long)e * HW + u], d * slope, d);
+        s[e] += v[e];
+      }
+      bf16x8 h, m, l;
+      split3(v, h, m, l);
+      *reinterpret_cast<bf16x8 *>(gp + (long)u * 8) = h;
+      *reinterpret_cast<bf16x8 *>(gp + ls + (long)u * 8) = m;
+      *reinterpret_cast<bf16x8 *>(gp + 2 * ls + (long)u * 8) = l;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    s[e] = wave_sum(s[e]);
+    if (lane == 0) red[wave][e] = s[e];
+  }
+  __syncthreads();
+  if (tid < 8 && dbpart) dbpart[(long)split * C + cg * 8 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
 }  // namespace lsps

@@ -325,6 +325,39 @@ def agree_all(flag, device=None):
     return bool(int(t.item()))
 
 
+_oob_round = [0]
+
+
+def agree_all_oob(flag, timeout_s=60.0):
+    """True only if `flag` is true on EVERY rank, agreed through the process group's rendezvous STORE (TCPStore counters): no
+    collective of the backend is issued, so nothing is added to RCCL's stream or its watchdog's work list.  This is what the
+    capture decision of a data-parallel step needs: the ranks must take the same branch — a rank that stays eager
+    while the others capture would, one call later, issue collectives the replaying ranks do not — and the agreement itself
+    must not be an eager RCCL collective (it would have to be drained again).  Every rank calls this the same number of times
+    in the same order (one call per capture attempt), which makes the per-process round counter a common key.  Identity in a
+    single process; a store error or time-out answers False on this rank AND poisons the round for the others."""
+    import time
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bool(flag)
+    _oob_round[0] += 1
+    key = 'lsps_agree_%d' % _oob_round[0]
+    n = dist.get_world_size()
+    try:
+        from torch.distributed.distributed_c10d import _get_default_store
+        store = _get_default_store()
+        store.add(key + '_ok', 1 if flag else 0)
+        store.add(key + '_n', 1)
+        t0 = time.time()
+        while store.add(key + '_n', 0) < n:
+            if time.time() - t0 > timeout_s:
+                store.add(key + '_ok', -n)           # poison: whoever reads later sees < n
+                return False
+            time.sleep(0.002)
+        return store.add(key + '_ok', 0) == n
+    except Exception:                              # noqa: BLE001  (no store: nothing can be agreed => never capture)
+        return False
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -699,7 +699,12 @@ def to_c8(x):
 
 
 def from_c8(x):
-    return _FromC8Fn.apply(x) if is_c8(x) else x
+    """f32 NCHW from whatever layout a run_layers chain left `x` in (C8 bf16, three-limb X3, or already f32 NCHW)."""
+    if is_c8(x):
+        return _FromC8Fn.apply(x)
+    if is_x3(x):
+        return _FromX3Fn.apply(x)
+    return x
 
 
 class _AddC8Fn(torch.autograd.Function):
@@ -894,6 +899,228 @@ class _ConvTS2C8Fn(torch.autograd.Function):
 
 def convT3x3s2_c8(x, w, b=None, slope=LRELU_SLOPE, prev=None, own=None):
     return _ConvTS2C8Fn.apply(x, w, b, float(slope), prev, own)
+
+
+# ------------------------------------------------------------------------------------------
+# f32 math mode: the 3x3 / stride-2 convs and transposed convs on the bf16 matrix pipe with THREE-LIMB operands ("X3",
+# csrc/x3s2.h): an X3 tensor is an f32 activation carried as x = hi + mid + lo exactly (bf16 limbs), [N][3][C/8][H][W][8];
+# six bf16 MFMAs per product, f32 accumulation: f32-class arithmetic (per-kernel error vs f64 at the level of the exact-f32
+# kernels, tests/test_x3_gpu.py) at 0.5 - 0.7 of their time (profiles/r5b_x3s2_family_prototype.txt).
+# ------------------------------------------------------------------------------------------
+def is_x3(t):
+    return torch.is_tensor(t) and t.dtype == BF16 and t.dim() == 6 and t.shape[1] == 3 and t.shape[-1] == 8
+
+
+def x3_split(x):
+    """f32 [N][C][H][W] -> X3 (no tape: the callers are autograd Functions)."""
+    x = _c(x)
+    N, C, H, W = x.shape
+    y = torch.empty((N, 3, C // 8, H, W, 8), dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().lsps_x3_split_nchw(_lib.ptr(x), _lib.ptr(y, BF16), N, C, H * W, _lib.stream()), 'x3_split_nchw')
+    return y
+
+
+def x3_join(xl):
+    xl = _c(xl)
+    N, _, G, H, W, _ = xl.shape
+    y = torch.empty((N, G * 8, H, W), dtype=torch.float32, device=xl.device)
+    _lib.check(_lib.lib().lsps_x3_join_nchw(_lib.ptr(xl, BF16), _lib.ptr(y), N, G * 8, H * W, _lib.stream()), 'x3_join_nchw')
+    return y
+
+
+class _FromX3Fn(torch.autograd.Function):
+    """X3 -> f32 NCHW (exact); backward: the f32 gradient split into limbs.  A safety net: run_layers only lets an X3 tensor out
+    of a layer whose successor consumes X3."""
+
+    @staticmethod
+    def forward(ctx, xl):
+        return x3_join(xl)
+
+    @staticmethod
+    def backward(ctx, g):
+        return x3_split(g)
+
+
+def _x3_shape(x):
+    if is_x3(x):
+        N, _, G, H, W, _ = x.shape
+        return N, G * 8, H, W
+    if torch.is_tensor(x) and x.dim() == 4 and x.dtype == torch.float32:
+        return tuple(x.shape)
+    return None
+
+
+def _x3_enabled(macs):
+    o = options.get()
+    return get_math_mode() == 'f32' and o.x3 and macs >= o.x3_min_gmac * 1e9
+
+
+def x3_conv_s2_ok(x, w, stride, pad):
+    """LeakyReLUConv2d(C, K, 3, 2, 1) on `x` (f32 NCHW or X3) on the three-limb kernels?  f32 math mode, options.x3, the geometry the
+    kernels cover (lsps_x3_conv3x3s2_ok) and at least options.x3_min_gmac x 10^9 multiply-adds (persistent 256-workgroup kernels)."""
+    sh = _x3_shape(x)
+    if sh is None or stride != 2 or pad != 1 or tuple(w.shape[2:]) != (3, 3):
+        return False
+    N, C, H, W = sh
+    return N > 0 and C == w.shape[1] and _x3_enabled(9.0 * N * (H // 2) * (W // 2) * C * w.shape[0]) and \
+        _lib.lib().lsps_x3_conv3x3s2_ok(N, C, H, W, w.shape[0]) == 1
+
+
+def x3_convT_s2_ok(x, w, stride, pad, outpad):
+    sh = _x3_shape(x)
+    if sh is None or stride != 2 or pad != 1 or outpad != 1 or tuple(w.shape[2:]) != (3, 3):
+        return False
+    N, C, H, W = sh
+    return N > 0 and C == w.shape[0] and _x3_enabled(9.0 * N * H * W * C * w.shape[1]) and _lib.lib().lsps_x3_convT3x3s2_ok(N, C, H, W, w.shape[1]) == 1
+
+
+def _x3_grad_operand(L, dy, y, slope, own, want_db, channels, out_f32, st):
+    """The X3 gradient w.r.t. a layer's PRE-activation output (what its wgrad / dgrad kernels read) and its bias gradient, from
+    the gradient autograd hands the layer: f32 NCHW (the layer's output left the X3 family as f32: one pass applies LeakyReLU'(y)
+    and splits) or X3 already multiplied by LeakyReLU' in the consumer's dgrad epilogue (`own.fused`)."""
+    if own is not None and own.fused:
+        db = own.db if want_db else None
+        own.fused, own.db = False, None
+        if not out_f32:
+            return dy, db                                # X3, masked by the consumer
+        slope, want_db_here = -1.0, False                # f32, masked by the consumer (1x1 head): split only
+    else:
+        want_db_here = want_db
+        db = None
+        if not out_f32:                                  # an X3 output nobody masked (fusion switched off): via f32
+            dy, y = x3_join(dy), (x3_join(y) if y is not None else None)
+    dy = _c(dy)
+    N, C, H, W = dy.shape
+    g = torch.empty((N, 3, C // 8, H, W, 8), dtype=BF16, device=dy.device)
+    dbh = torch.empty(channels, dtype=torch.float32, device=dy.device) if want_db_here else None
+    ws, wsb = _lib.workspace(L.lsps_x3_act_bwd_bias_workspace_bytes(N, C), dy.device)
+    _lib.check(L.lsps_x3_act_bwd_bias(_lib.ptr(dy), _lib.ptr(y) if slope >= 0 else None, _lib.ptr(g, BF16), _lib.ptr(dbh), N, C, H * W,
+                                      slope, ws, wsb, st), 'x3_act_bwd_bias')
+    return g, (dbh if want_db_here else db)
+
+
+class _ConvS2X3Fn(torch.autograd.Function):
+    """LeakyReLUConv2d(C, K, 3, 2, 1) (common_net.py:246-256) on the three-limb kernels: x f32 NCHW (split here) or X3 (the
+    output of the X3 layer in front: `prev`) -> y f32 NCHW (`out_f32`) or X3 (for the X3 layer behind: `own`)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope, prev, own, out_f32):
+        L = _lib.lib()
+        w = _c(w)
+        ctx.x_is_x3 = is_x3(x)
+        xl = _c(x) if ctx.x_is_x3 else x3_split(x)
+        N, _, G, H, W, _ = xl.shape
+        C, K = G * 8, w.shape[0]
+        ctx.prev, ctx.own, ctx.out_f32 = prev, own, bool(out_f32)
+        P, Q = H // 2, W // 2
+        y = torch.empty((N, K, P, Q), dtype=torch.float32, device=xl.device) if out_f32 else \
+            torch.empty((N, 3, K // 8, P, Q, 8), dtype=BF16, device=xl.device)
+        ws, wsb = _lib.workspace(L.lsps_x3_conv3x3s2_workspace_bytes(N, C, H, W, K), xl.device)
+        with profiler.span(2.0 * N * K * P * Q * C * 9, 'x3s2_fwd_kernel'):
+            _lib.check(L.lsps_x3_conv3x3s2_fwd(_lib.ptr(xl, BF16), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y) if out_f32 else None,
+                                               None if out_f32 else _lib.ptr(y, BF16), N, C, H, W, K, slope, ws, wsb, _lib.stream()),
+                       'x3_conv3x3s2_fwd')
+        ctx.geom = (N, C, H, W, K, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(xl, w, y if slope >= 0 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        xl, w, y = ctx.saved_tensors
+        N, C, H, W, K, slope = ctx.geom
+        st = _lib.stream()
+        flops = 2.0 * N * K * (H // 2) * (W // 2) * C * 9
+        dx = dw = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        g, db = _x3_grad_operand(L, dy, y, slope, ctx.own, want_db, K, ctx.out_f32, st)
+        ws, wsb = _lib.workspace(L.lsps_x3_conv3x3s2_workspace_bytes(N, C, H, W, K), xl.device)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            with profiler.span(flops, 'x3s2_wgrad_kernel'):
+                _lib.check(L.lsps_x3_conv3x3s2_wgrad(_lib.ptr(xl, BF16), _lib.ptr(g, BF16), _lib.ptr(dw), N, C, H, W, K, ws, wsb, st),
+                           'x3_conv3x3s2_wgrad')
+        if ctx.needs_input_grad[0]:
+            with profiler.span(flops, 'x3s2_tr_kernel'):
+                if not ctx.x_is_x3:                      # the producer of x is an f32 layer: hand back f32 NCHW
+                    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=xl.device)
+                    _lib.check(L.lsps_x3_conv3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(dx), None, None, 0.0, None, N, C, H, W, K,
+                                                         ws, wsb, st), 'x3_conv3x3s2_dgrad')
+                else:
+                    dx = torch.empty_like(xl)
+                    if _fusable(ctx.prev):               # x is the previous X3 layer's output: its LeakyReLU backward rides along
+                        dbp = torch.empty(C, dtype=torch.float32, device=xl.device)
+                        _lib.check(L.lsps_x3_conv3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), None, _lib.ptr(dx, BF16), _lib.ptr(xl, BF16),
+                                                             ctx.prev.slope, _lib.ptr(dbp), N, C, H, W, K, ws, wsb, st),
+                                   'x3_conv3x3s2_dgrad(masked)')
+                        ctx.prev.fused, ctx.prev.db = True, dbp
+                    else:
+                        _lib.check(L.lsps_x3_conv3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), None, _lib.ptr(dx, BF16), None, 0.0, None, N, C,
+                                                             H, W, K, ws, wsb, st), 'x3_conv3x3s2_dgrad')
+        return dx, dw, db, None, None, None, None
+
+
+def conv3x3s2_x3(x, w, b=None, slope=LRELU_SLOPE, prev=None, own=None, out_f32=True):
+    return _ConvS2X3Fn.apply(x, w, b, float(slope), prev, own, bool(out_f32))
+
+
+class _ConvTS2X3Fn(torch.autograd.Function):
+    """LeakyReLUConvTranspose2d(Ci, Co, 3, 2, 1, 1) (common_net.py:258-268) on the three-limb kernels: x [N,Ci,H,W] f32 (split
+    here) or X3 -> y [N,Co,2H,2W] f32 NCHW (`out_f32`) or X3."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope, prev, own, out_f32):
+        L = _lib.lib()
+        w = _c(w)
+        ctx.x_is_x3 = is_x3(x)
+        xl = _c(x) if ctx.x_is_x3 else x3_split(x)
+        N, _, G, H, W, _ = xl.shape
+        Ci, Co = G * 8, w.shape[1]
+        ctx.prev, ctx.own, ctx.out_f32 = prev, own, bool(out_f32)
+        y = torch.empty((N, Co, 2 * H, 2 * W), dtype=torch.float32, device=xl.device) if out_f32 else \
+            torch.empty((N, 3, Co // 8, 2 * H, 2 * W, 8), dtype=BF16, device=xl.device)
+        ws, wsb = _lib.workspace(L.lsps_x3_conv3x3s2_workspace_bytes(N, Co, 2 * H, 2 * W, Ci), xl.device)
+        with profiler.span(2.0 * N * Ci * H * W * Co * 9, 'x3s2_tr_kernel'):
+            _lib.check(L.lsps_x3_convT3x3s2_fwd(_lib.ptr(xl, BF16), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y) if out_f32 else None,
+                                                None if out_f32 else _lib.ptr(y, BF16), N, Ci, H, W, Co, slope, ws, wsb, _lib.stream()),
+                       'x3_convT3x3s2_fwd')
+        ctx.geom = (N, Ci, H, W, Co, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(xl, w, y if slope >= 0 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        xl, w, y = ctx.saved_tensors
+        N, Ci, H, W, Co, slope = ctx.geom
+        st = _lib.stream()
+        flops = 2.0 * N * Ci * H * W * Co * 9
+        dx = dw = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        g, db = _x3_grad_operand(L, dy, y, slope, ctx.own, want_db, Co, ctx.out_f32, st)
+        ws, wsb = _lib.workspace(L.lsps_x3_conv3x3s2_workspace_bytes(N, Co, 2 * H, 2 * W, Ci), xl.device)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            with profiler.span(flops, 'x3s2_wgrad_kernel'):
+                _lib.check(L.lsps_x3_convT3x3s2_wgrad(_lib.ptr(xl, BF16), _lib.ptr(g, BF16), _lib.ptr(dw), N, Ci, H, W, Co, ws, wsb, st),
+                           'x3_convT3x3s2_wgrad')
+        if ctx.needs_input_grad[0]:
+            with profiler.span(flops, 'x3s2_fwd_kernel'):
+                if not ctx.x_is_x3:
+                    dx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=xl.device)
+                    _lib.check(L.lsps_x3_convT3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(dx), None, N, Ci, H, W, Co, ws, wsb, st),
+                               'x3_convT3x3s2_dgrad')
+                else:                                    # (no fused mask in the forward-direction kernel: the producer runs its own pass)
+                    dx = torch.empty_like(xl)
+                    _lib.check(L.lsps_x3_convT3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), None, _lib.ptr(dx, BF16), N, Ci, H, W, Co, ws, wsb,
+                                                          st), 'x3_convT3x3s2_dgrad')
+        return dx, dw, db, None, None, None, None
+
+
+def convT3x3s2_x3(x, w, b=None, slope=LRELU_SLOPE, prev=None, own=None, out_f32=True):
+    return _ConvTS2X3Fn.apply(x, w, b, float(slope), prev, own, bool(out_f32))
 
 
 def c8_stem_ok(x, w, stride, pad):
@@ -1398,24 +1625,38 @@ def weight_cache_end():
     _lib.check(_lib.lib().lsps_pack_cache_end(), 'pack_cache_end')
 
 
-_frozen_arenas = {}
-FROZEN_CACHE_BYTES = 1 << 29        # the generator's panels for the forward direction: 28 x 9.4 MB of F(4x4,3x3) U + small ones
+FROZEN_CACHE_MAX_BYTES = 1 << 29    # the generator's panels for the forward direction: 28 x 9.4 MB of F(4x4,3x3) U + small ones
+_frozen_state = {'resets': 0, 'last': None}
 
 
-def weight_cache_frozen(flat_params=None, epoch=0):
-    """Declares the weights inside `flat_params` (a flat parameter arena) unchanged ACROSS the scopes that follow, until
-    `epoch` changes (lsps_pack_cache_frozen): their packed panels survive `weight_cache_end()`.  None: no frozen weights."""
+def frozen_resets():
+    """How often the library's (process-wide) frozen table has been re-targeted: another arena, another buffer or another epoch
+    (each empties the table).  A hipGraph that was captured while panels were frozen is only valid under the count it saw."""
+    return _frozen_state['resets']
+
+
+def weight_cache_frozen(arena=None, epoch=0):
+    """Declares the weights inside `arena` (an optim.FlatArena) unchanged ACROSS the scopes that follow, until `epoch` changes
+    (lsps_pack_cache_frozen): their packed panels survive `weight_cache_end()`.  None: no frozen weights.
+    The panels live in a buffer that belongs to the ARENA (`arena._frozen_buf`: sized from its parameter bytes — the F(4x4,3x3)
+    transform is 4x a 3x3 weight, the other panels ~1.1x —, capped at 512 MiB, freed with the trainer): another trainer's
+    declaration re-targets the library's table but can never overwrite panels a captured graph of this trainer reads."""
     L = _lib.lib()
-    if flat_params is None or not options.get().pack_cache or not options.get().frozen_packs:
+    if arena is None or not options.get().pack_cache or not options.get().frozen_packs:
         _lib.check(L.lsps_pack_cache_frozen(None, None, None, 0, 0), 'pack_cache_frozen')
         return False
-    key = (flat_params.device.type, flat_params.device.index)
-    buf = _frozen_arenas.get(key)
+    flat_params = arena.flat_p
+    buf = getattr(arena, '_frozen_buf', None)
     if buf is None:
-        buf = _frozen_arenas[key] = torch.empty(FROZEN_CACHE_BYTES, dtype=torch.uint8, device=flat_params.device)
+        nbytes = min(FROZEN_CACHE_MAX_BYTES, max(1 << 20, 6 * flat_params.numel() * flat_params.element_size()))
+        buf = arena._frozen_buf = torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=flat_params.device)
     lo = flat_params.data_ptr()
+    target = (lo, flat_params.numel(), buf.data_ptr(), buf.numel(), int(epoch) & 0xffffffffffffffff)
+    if target != _frozen_state['last']:             # the same comparison the library makes before it empties its table
+        _frozen_state['last'] = target
+        _frozen_state['resets'] += 1
     _lib.check(L.lsps_pack_cache_frozen(lo, lo + flat_params.numel() * flat_params.element_size(), buf.data_ptr(), buf.numel(),
-                                        int(epoch) & 0xffffffffffffffff), 'pack_cache_frozen')
+                                        target[4]), 'pack_cache_frozen')
     return True
 
 

@@ -50,6 +50,7 @@ class FlatArena(object):
             p.data = view
             p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+            p._lsps_arena = self                        # writers that go through `p.data` announce themselves: mark_dirty()
         self.on_grad_ready = None                       # set by dist.GradReducer
         # (bias index, weight index) of convs whose bias is mathematically dead (trainers/common_net.py:_mark_dead_bias)
         index = dict((id(p), i) for i, p in enumerate(self.params))
@@ -70,6 +71,11 @@ class FlatArena(object):
         is invisible to both: call `arena.generation += 1` after one.)  The arena's process-unique id is part of the value:
         two arenas never share an epoch, even when the allocator gives the second one the first one's addresses."""
         return ((self.uid & 0xffff) << 48) | ((self.generation & 0xffffff) << 24) | (sum(p._version for p in self.params) & 0xffffff)
+
+    def mark_dirty(self):
+        """To be called after a write through `p.data` (which neither `generation` nor torch's version counters see):
+        `gaussian_weights_init` does it itself; INTEGRATION.md states the contract for user code."""
+        self.generation += 1
 
     def zero_grad(self):
         self.flat_g.zero_()

@@ -113,8 +113,22 @@ def run_layers(layers, x, noise=None):
     LeakyReLUConv2d and LeakyReLUConvTranspose2d layers, GaussianNoiseLayer — run on such tensors: `x` is converted in front
     of the first of them, stays in that layout through consecutive ones and is converted back in front of any other layer
     (the caller converts what it hands out: ops.from_c8)."""
-    prev = None            # ops.ActHolder of the C8 layer whose output `x` is (consecutive layers: nobody else consumes it)
-    for l in layers:
+    prev = None            # ops.ActHolder of the C8 / X3 layer whose output `x` is (consecutive layers: nobody else consumes it)
+    layers = list(layers)
+
+    def x3_next(i, y_shape):
+        """Does layer i + 1 take the X3 output (shape as f32 NCHW: `y_shape`) of layer i?  Then layer i writes X3 and the pair
+        shares an ActHolder (layer i + 1's dgrad applies layer i's LeakyReLU backward)."""
+        if i + 1 >= len(layers) or not ops.options.get().fuse_act:
+            return False
+        n = layers[i + 1]
+        probe = torch.empty(y_shape, dtype=torch.float32, device='meta')
+        if isinstance(n, LeakyReLUConv2d):
+            c = n.model[0]
+            return ops.x3_conv_s2_ok(probe, c.weight, c.stride, c.padding)
+        return False                                               # (the X3 transposed-conv dgrad has no fused mask: f32 hand-over)
+
+    for i, l in enumerate(layers):
         if isinstance(l, LeakyINSResBlock):
             ch = l.model[0].weight.shape[0]
             drop = l.dropout if (l.training and l.dropout > 0) else 0.0
@@ -132,6 +146,12 @@ def run_layers(layers, x, noise=None):
                 own = ops.ActHolder(LRELU_SLOPE)
                 x = ops.conv3x3s2_c8(xin, c.weight, c.bias, LRELU_SLOPE, prev if xin is x else None, own)
                 prev = own
+            elif ops.x3_conv_s2_ok(x, c.weight, c.stride, c.padding):   # f32 math mode: three-limb operands on the bf16 pipe
+                N, C, H, W = ops._x3_shape(x)
+                chain = x3_next(i, (N, c.weight.shape[0], H // 2, W // 2))
+                own = ops.ActHolder(LRELU_SLOPE) if chain else None
+                x = ops.conv3x3s2_x3(x, c.weight, c.bias, LRELU_SLOPE, prev if ops.is_x3(x) else None, own, out_f32=not chain)
+                prev = own
             else:
                 x, prev = l(ops.from_c8(x)), None
         elif isinstance(l, LeakyReLUConvTranspose2d):
@@ -140,6 +160,12 @@ def run_layers(layers, x, noise=None):
                 xin = ops.to_c8(x)
                 own = ops.ActHolder(LRELU_SLOPE)
                 x = ops.convT3x3s2_c8(xin, c.weight, c.bias, LRELU_SLOPE, prev if xin is x else None, own)
+                prev = own
+            elif c.act == ACT_LRELU and ops.x3_convT_s2_ok(x, c.weight, c.stride, c.padding, c.output_padding):
+                # f32 out: the consumer is another transposed conv (splits its input) or the 1x1 head (fuses this layer's LeakyReLU
+                # backward through the ActHolder, like the f32 kernel's path below)
+                own = ops.ActHolder(LRELU_SLOPE)
+                x = ops.convT3x3s2_x3(ops.from_c8(x), c.weight, c.bias, LRELU_SLOPE, None, own, out_f32=True)
                 prev = own
             else:                                                       # f32 (or a shape without a C8 kernel)
                 own = ops.ActHolder(LRELU_SLOPE)

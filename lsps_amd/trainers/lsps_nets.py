@@ -144,6 +144,11 @@ class SharedDis(_Net):
         layers = list(self.model_S)
         if ops.is_c8(f) or ops.get_math_mode() == 'bf16':
             return ops.from_c8(run_layers(layers, f))
+        c0 = layers[0].model[0] if layers and isinstance(layers[0], LeakyReLUConv2d) else None
+        if c0 is not None and ops.x3_conv_s2_ok(f, c0.weight, c0.stride, c0.padding):
+            # three-limb operands on the bf16 matrix pipe (csrc/x3s2.h): the layers chain in the X3 layout (run_layers), the
+            # last one hands out f32 NCHW; no transposes, the LeakyReLU backward passes ride in the dgrad epilogues
+            return ops.from_c8(run_layers(layers, f))
         N, C, H, W = f.shape
         # below ~96 samples the 128-wide batch tile of the GEMM is mostly padding (dis.feats on 16 samples: slower than NCHW)
         opt = ops.options.get()

@@ -238,7 +238,7 @@ class LSPSTrainer(nn.Module):
         if method == 'post_update' and arena is not None:
             now = arena.epoch()
             stable, self._gen_epoch_last = (now == self._gen_epoch_last), now
-            if stable and ops.weight_cache_frozen(arena.flat_p, now):
+            if stable and ops.weight_cache_frozen(arena, now):
                 ep = now
         if ep is None:
             ops.weight_cache_frozen(None)
@@ -285,15 +285,23 @@ class LSPSTrainer(nn.Module):
             # a post_update captured while the generator's panels are frozen holds no pack launches for them (they were cache
             # hits): it is only valid while that cache is — same generator epoch — and such graphs of older epochs can never be
             # replayed again.  (ep None: nothing frozen, the graph packs for itself and is valid for any weights.)
+            # The frozen table is ONE per process (csrc/igemm.hip: g_fz): another trainer's post_update re-targets it, after which
+            # a later re-pack of THIS trainer's panels may lay them out differently in its buffer.  `frozen_resets` counts those
+            # re-targetings (ops.weight_cache_frozen); a frozen graph is only valid for the count it was captured under
+            # (two graphed trainers alternating in one process).
             ep = self._declare_frozen(name)
             self._frozen_decided = (ep,)
-            sig = sig + (('gen_epoch', ep),)
-            for old in [k for k in self._graphs if k[0] == 'post_update' and k[-1][1] not in (None, ep)]:
+            tag = None if ep is None else (ep, ops.frozen_resets())
+            sig = sig + (('gen_epoch', tag),)
+            for old in [k for k in self._graphs if k[0] == 'post_update' and k[-1][1] not in (None, tag)]:
                 del self._graphs[old]
         g = self._graphs.get(sig)
         if g is not None:
             self._frozen_decided = None
-            return g.replay(self, args, kwargs)
+            try:
+                return g.replay(self, args, kwargs)
+            finally:
+                ops.weight_cache_frozen(None)   # the promise ends with the method, also on the replay path
         if sig not in self._graph_seen:                  # warm-up call: eager
             self._graph_seen.add(sig)
             return eager(self, *args, **kwargs)
@@ -301,11 +309,11 @@ class LSPSTrainer(nn.Module):
         if lsps_dist.active():
             # RCCL's watchdog must have RETIRED every eager collective before its stream joins a capture (dist.drain_watchdog:
             # confirmed through the flight recorder, not a sleep).  Not confirmed (recorder off) on ANY rank => this call
-            # stays eager everywhere and the capture is tried again at the next one.  The agreement is itself an eager
-            # collective, hence the second drain (should that one fail on a single rank, that rank runs eagerly against the
-            # others' capture + replay: the same collectives in the same order, so the ranks stay aligned).
-            ok = lsps_dist.agree_all(lsps_dist.drain_watchdog())
-            if not (ok and lsps_dist.drain_watchdog()):
+            # stays eager on EVERY rank and the capture is tried again at the next one.  The decision must be the same
+            # everywhere (a rank that stayed eager alone would issue, one call later, an agreement collective the replaying
+            # ranks do not: ADVICE r4), and the agreement must not itself be RCCL work that needs draining: it goes through
+            # the rendezvous store (dist.agree_all_oob).
+            if not lsps_dist.agree_all_oob(lsps_dist.drain_watchdog()):
                 return eager(self, *args, **kwargs)
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
@@ -315,7 +323,10 @@ class LSPSTrainer(nn.Module):
         finally:
             lsps_dist.capture_end(fence)
         # the capture only recorded the launches: run them once for this call's result
-        return g.replay(self, args, kwargs)
+        try:
+            return g.replay(self, args, kwargs)
+        finally:
+            ops.weight_cache_frozen(None)
 
     def _step(self, key, opt, loss, names, tensors, sig, begun=False):
         """backward + gradient exchange + optimizer step + publication of the step's scalars (stored as numpy values like
@@ -595,15 +606,24 @@ class LSPSTrainer(nn.Module):
     def resume(self, snapshot_prefix, idx=-1, load_opt=False, est=False):
         """Under data parallelism the outcome is rank 0's: a rank that does not see the snapshot (no shared filesystem, a
         half-written file) still enters the same broadcasts as the others and ends up with rank 0's weights and count."""
+        err = None
         try:
             iterations = self._resume_local(snapshot_prefix, idx, load_opt, est)
-        except Exception:
-            # single process / rank 0: the reference's behaviour (helpers.get_model_list raises on an empty directory);
-            # another rank must not leave rank 0 alone in the broadcasts below just because ITS disk holds nothing
-            if lsps_dist.world() == 1 or lsps_dist.rank() == 0:
+        except (IndexError, FileNotFoundError, OSError, EOFError) as ex:
+            # the snapshot is not there / not readable on THIS rank.  Single process / rank 0: the reference's behaviour
+            # (helpers.get_model_list raises on an empty directory); another rank must not leave rank 0 alone in the
+            # broadcasts below just because ITS disk holds nothing.  Anything else (a state-dict key or shape mismatch, a
+            # corrupt pickle) is a configuration error and is raised on the rank that saw it (ADVICE r4).
+            if lsps_dist.world() == 1:
                 raise
-            iterations = 0
-        iterations = lsps_dist.agree_from_rank0(iterations)
+            err, iterations = ex, 0
+        if lsps_dist.world() > 1:
+            # rank 0's outcome decides, and every rank learns it BEFORE the weight broadcasts: if rank 0 failed, all raise
+            # together instead of blocking in sync_replicas() until the launcher kills them
+            ok0, iterations = lsps_dist.agree_from_rank0((err is None, iterations))
+            if not ok0:
+                raise err if (err is not None and lsps_dist.rank() == 0) else RuntimeError(
+                    "resume(): rank 0 could not load the snapshot '%s'" % snapshot_prefix)
         self.sync_replicas()
         return iterations
 

@@ -42,18 +42,21 @@ def test_steps_match_reference_golden(config, golden):
     assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
 
 
-@pytest.mark.parametrize("mode", ["always", "off"])
+@pytest.mark.parametrize("mode", ["always", "off", "x3"])
 def test_full_steps_match_reference_golden_per_conv_algorithm(mode, golden, monkeypatch):
     """The `full` config's update steps against the REAL reference's golden vectors with the residual convs forced
     onto the Winograd kernels (forward, dgrad and weight gradient, also at this small batch) and onto the direct ones:
     both sit inside the same tolerances ('auto', the default, is what the test above runs).  In the 'always' run the
     discriminator trunk is also forced onto the batch-innermost kernels the bench-size batches use (csrc/chwn.hip; their
-    batch threshold is lifted), so the whole default bs=128 dispatch is checked against the reference at trainer level."""
+    batch threshold is lifted), so the whole default bs=128 dispatch is checked against the reference at trainer level.
+    'x3' (round 5): every 3x3 / stride-2 conv and transposed conv of both nets on the three-limb kernels of csrc/x3s2.h (their
+    work threshold is lifted: at bench sizes they are the default dispatch of those layers), everything else as 'auto'."""
     A = _adapter()
     from lsps_amd import ops
     prev = ops.get_winograd()
-    ops.set_winograd(mode)
-    monkeypatch.setattr(ops.options, '_current', ops.options.from_env({'LSPS_CHWN_MIN_N': '1' if mode == 'always' else '1000000'}))
+    ops.set_winograd(mode if mode != 'x3' else 'auto')
+    env = {'LSPS_X3_MIN_GMAC': '0'} if mode == 'x3' else {'LSPS_CHWN_MIN_N': '1' if mode == 'always' else '1000000'}
+    monkeypatch.setattr(ops.options, '_current', ops.options.from_env(env))
     ops.kernel_log_begin()
     try:
         R = cases.run_step_cases(A, 'full', lsps_ref)
@@ -61,6 +64,9 @@ def test_full_steps_match_reference_golden_per_conv_algorithm(mode, golden, monk
         names = ops.kernel_log_end()
         ops.set_winograd(prev)
     assert ('chwn_gemm_kernel' in names and 'chwn_wgrad_kernel' in names) == (mode == 'always'), sorted(set(names))
+    assert all((k in names) == (mode == 'x3') for k in ('x3s2_fwd_kernel', 'x3s2_tr_kernel', 'x3s2_wgrad_kernel')), sorted(set(names))
+    if mode == 'x3':
+        assert not [k for k in names if k.startswith('igemm_') and '3x3s2' in k], sorted(set(names))
     if mode == 'always':
         assert 'wino4_f3x3_kernel' in names and 'wino4_w3x3_kernel' in names, sorted(set(names))
     g = {k: v for k, v in golden('full').items() if k.split('/')[0] in R}
