@@ -488,6 +488,35 @@ def run_extra_cases(A, shapes_mod, which=('estimate1', 'wide')):
     return R
 
 
+def run_n16_cases(A, shapes_mod, n=16):
+    """Round 5: one pretrain iteration and one estimate3 step at FULL width with 16 samples per domain —
+    the smallest batch at which the product's DEFAULT dispatch is the bench's multi-round, XCD-mapped one (32-image residual
+    convs on the F(4x4,3x3) kernels, 48-image discriminator passes).  No golden file: the test runs the CPU oracle on the same
+    seeded inputs (about half a minute on the GPU box's host) and compares the HIP trainer with it."""
+    hp = hp_for('full')
+    sds = make_weights(hp, shapes_mod)
+    R = OrderedDict()
+    lat2, lat1 = latent_shape(hp, 2 * n), latent_shape(hp, n)
+    tr = A.make_trainer(hp, sds)
+    A.set_train(tr, True)
+    b = make_inputs(n)
+    A.dis_update(tr, b, hp, noise(lat2, 1600))
+    R['n16.dis_update.scalars'] = A.scalars(tr)
+    _grad_digest(R, 'n16.dis_update.grads', A, tr, 'dis')
+    outs = A.gen_update(tr, b, hp, (noise(lat2, 2600), noise(lat1, 3600), noise(lat1, 4600)))
+    R['n16.gen_update.scalars'] = A.scalars(tr)
+    _grad_digest(R, 'n16.gen_update.grads', A, tr, 'gen')
+    R['n16.gen_update.outputs'] = OrderedDict(zip(('x_aa', 'x_ba', 'x_ab', 'x_bb', 'x_aba', 'x_bab'), outs[:6]))
+    zd = hp['vae']['z_dim']
+    tr = A.make_trainer(hp, sds)
+    A.set_train(tr, True)
+    outs = A.post_update(tr, b, 3, hp, noise(latent_shape(hp, 8), 5600), noise((n, zd), 6600, 0.05), noise((n, zd), 7600, 0.05))
+    R['n16.estimate3.scalars'] = A.scalars(tr)
+    _grad_digest(R, 'n16.estimate3.grads', A, tr, 'dis')
+    R['n16.estimate3.outputs'] = OrderedDict(zip(('x_aa', 'x_ba', 'x_ab', 'x_bb'), outs[:4]))
+    return R
+
+
 def run_expand_cases(A, shapes_mod):
     """Round 4 (golden_expand.npz): `SharedDis` with the optional `n_expand_layer` key (lsps_nets.py:93,116-118): ONE stride-1
     3x3 LeakyReLUConv2d in front of the stride-2 trunk, tiny width (front 4 -> 8 channels, expand 8 -> 16 on 32 x 32, trunk

@@ -75,6 +75,35 @@ def test_full_steps_match_reference_golden_per_conv_algorithm(mode, golden, monk
     assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
 
 
+def test_n16_full_width_default_dispatch_against_the_oracle(monkeypatch):
+    """a DIRECT oracle-vs-HIP comparison at a batch where the default dispatch is the bench's: full width,
+    16 samples per domain, `dis_update` + `gen_update` + `post_update(3)` once.  Forward tensors and loss scalars at 1e-3 of
+    abs-max, gradients through the robust criteria of cases.compare; the kernel log must show the F(4x4,3x3) forward / dgrad and
+    weight-gradient kernels, the stride-2 family (three-limb kernels where the work threshold routes to them, the exact-f32
+    ones elsewhere) and the batch-innermost trunk (its batch threshold is lowered to this batch: the 16- and 32-image passes
+    of post_update / gen_update; dis_update's 96-image pass is above the three-limb family's work threshold)."""
+    A = _adapter()
+    from lsps_amd import ops
+    import os
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    O = cases.NativeAdapter(lsps_ref, 'cpu')
+    gold = cases.flatten(cases.run_n16_cases(O, lsps_ref))
+    monkeypatch.setattr(ops.options, '_current', ops.options.from_env({'LSPS_CHWN_MIN_N': '16'}))
+    ops.kernel_log_begin()
+    try:
+        R = cases.run_n16_cases(A, lsps_ref)
+    finally:
+        names = set(ops.kernel_log_end())
+    for k in ('wino4_f3x3_kernel', 'wino4_w3x3_kernel', 'chwn_gemm_kernel', 'chwn_wgrad_kernel', 'x3s2_fwd_kernel', 'x3s2_tr_kernel',
+              'x3s2_wgrad_kernel'):
+        assert k in names, (k, sorted(names))
+    assert [k for k in names if k.startswith('igemm_') and '3x3s2' in k], sorted(names)
+    report = {}
+    bad, worst = cases.compare(R, gold, RTOL, grad_rtol=2e-2, report=report)
+    print("worst rel err", worst, report)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
+
+
 def test_extra_cases_match_reference_golden(golden):
     """`post_update(mode=1)` (lsps_trainer.py:231-234) and a full-width pretrain iteration at a batch where the DEFAULT
     dispatch ('auto') of the residual convs is the Winograd path — the dispatch the bench runs, at trainer level."""
