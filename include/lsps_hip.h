@@ -278,6 +278,10 @@ size_t lsps_pw1_dgrad_act_workspace_bytes(int N, int C);
 int lsps_pw1_dgrad_act(const float *dpre, const float *w, const float *act_y, float act_slope, float *dx, float *db_prev /*nullable*/,
                        float *dw /*nullable: the head's own weight gradient [C]*/, float *db /*nullable: its bias gradient [1]*/,
                        int N, int C, int HW, void *ws, size_t ws_bytes, void *stream);
+/* the same with dx written as a three-limb X3 tensor [N][3][C/8][HW][8] (C % 16 == 0): the operand format of the X3 transposed conv
+ * in front of the head (lsps_x3_convT3x3s2_*), whose separate split pass this saves */
+int lsps_pw1_dgrad_act_x3(const float *dpre, const float *w, const float *act_y, float act_slope, void *dxl, float *db_prev /*nullable*/,
+                          float *dw /*nullable*/, float *db /*nullable*/, int N, int C, int HW, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- ConvTranspose2d: replaces nn.ConvTranspose2d forward/backward -------------------------
  * call sites: common_net.py:262 (LeakyReLUConvTranspose2d), lsps_nets.py:226-227 (1x1 output),
@@ -417,6 +421,11 @@ int lsps_mul_add(const float *x, const float *t, const float *m, float *out, lon
  *                           the pack kernel (cached in the pack-cache scope); output f32 NCHW `y` or, when `yl` is given, X3 `yl`
  *                           (the next stride-2 layer's input).  C % 16 == 0, K % 128 == 0, H, W powers of two (_ok). */
 int lsps_x3_split_nchw(const float *x, void *xl, int N, int C, int HW, void *stream);
+/* the one-input-channel stems (LeakyReLUConv2d(1, 64, 7, s, 3), lsps_nets.py:117,184) writing their activation straight as X3
+ * (the f32 kernel of lsps_conv2d_fwd with a limb-splitting epilogue): y = LeakyReLU_slope(conv(x, w) + bias), slope < 0: none */
+int lsps_x3_stem_ok(int N, int H, int W, int K, int R, int S, int stride, int pad);
+int lsps_x3_stem_fwd(const float *x, const float *w, const float *bias /*nullable*/, void *yl, int N, int H, int W, int K, int R, int S,
+                     int stride, int pad, float slope, void *stream);
 int lsps_x3_join_nchw(const void *xl, float *y, int N, int C, int HW, void *stream);
 int lsps_x3_conv3x3s2_ok(int N, int C, int H, int W, int K);
 size_t lsps_x3_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K);
@@ -437,8 +446,9 @@ int lsps_x3_conv3x3s2_wgrad(const void *xl, const void *dyl, float *dw, int N, i
 int lsps_x3_convT3x3s2_ok(int N, int Ci, int H, int W, int Co);
 int lsps_x3_convT3x3s2_fwd(const void *xl, const float *w, const float *bias /*nullable*/, float *y /*nullable*/, void *yl /*nullable*/,
                            int N, int Ci, int H, int W, int Co, float slope, void *ws, size_t ws_bytes, void *stream);
-int lsps_x3_convT3x3s2_dgrad(const void *dyl, const float *w, float *dx /*nullable*/, void *dxl /*nullable*/, int N, int Ci, int H, int W,
-                             int Co, void *ws, size_t ws_bytes, void *stream);
+int lsps_x3_convT3x3s2_dgrad(const void *dyl, const float *w, float *dx /*nullable*/, void *dxl /*nullable*/, const void *act_yl /*nullable*/,
+                             float act_slope, float *db_prev /*nullable*/, int N, int Ci, int H, int W, int Co,
+                             void *ws, size_t ws_bytes, void *stream);    /* act_yl / db_prev: as lsps_x3_conv3x3s2_dgrad */
 int lsps_x3_convT3x3s2_wgrad(const void *xl, const void *dyl, float *dw, int N, int Ci, int H, int W, int Co,
                              void *ws, size_t ws_bytes, void *stream);
 /* g (X3) = dy * LeakyReLU'(y) from f32 NCHW dy and the layer's f32 NCHW output y (slope < 0: g = dy), db [C] (nullable) = sum of g:

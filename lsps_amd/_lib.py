@@ -117,10 +117,13 @@ _SIGNATURES = {
     'lsps_x3_conv3x3s2_wgrad': (c_int, [_P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
     'lsps_x3_convT3x3s2_ok': (c_int, [c_int] * 5),
     'lsps_x3_convT3x3s2_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [c_float, _P, c_size_t, _P]),
-    'lsps_x3_convT3x3s2_dgrad': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
+    'lsps_x3_convT3x3s2_dgrad': (c_int, [_P, _P, _P, _P, _P, c_float, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
     'lsps_x3_convT3x3s2_wgrad': (c_int, [_P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
     'lsps_x3_act_bwd_bias_workspace_bytes': (c_size_t, [c_int] * 2),
     'lsps_x3_act_bwd_bias': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
+    'lsps_pw1_dgrad_act_x3': (c_int, [_P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    'lsps_x3_stem_ok': (c_int, [c_int] * 8),
+    'lsps_x3_stem_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [c_float, _P]),
     'lsps_crop_normalize': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     'lsps_crop_augment': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
 }

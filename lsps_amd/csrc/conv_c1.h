@@ -22,7 +22,8 @@ struct C1Params {
   int TP, rows, LW;              // output rows per workgroup, staged input rows, LDS row stride (Wd + 2 pad)
   int act;
   float slope;
-  int out_c8;                    // 1: Y is bf16 in the channel-group layout [N][K/8][P][Q][8] (c8conv.h; bf16 math mode)
+  int out_c8;                    // 1: Y is bf16 in the channel-group layout [N][K/8][P][Q][8] (c8conv.h; bf16 math mode);
+                                 // 2: Y is a three-limb X3 tensor [N][3][K/8][P][Q][8] (x3s2.h; f32 math mode, K == 64)
 };
 
 __device__ __forceinline__ void c1_stage_rows(float *xs, const float *xn, int row0, int rows, int LW, int H, int Wd, int pad,
@@ -110,21 +111,37 @@ __global__ __launch_bounds__(256, 2) void c1_fwd_kernel(C1Params p) {
       for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][i], b, acc[i], 0, 0, 0);
     }
     if (fast && p.out_c8) {                                  // wave-uniform.  A register quad = 4 consecutive channels = 8 bytes
+      const bool x3 = p.out_c8 == 2;                         // three limb planes per image (x = hi + mid + lo exactly)
       const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
-          reinterpret_cast<unsigned short *>(p.Y) + ((long)n * p.K + m0) * PQ, 0, 0x7fffffff, 0x00020000);
+          reinterpret_cast<unsigned short *>(p.Y) + ((long)n * (x3 ? 3 : 1) * p.K + m0) * PQ, 0, 0x7fffffff, 0x00020000);
       const unsigned vo = (unsigned)(((p0 + pr) * p.Q + q0 + l31) * 16 + half * 8);
+      const int limb_bytes = p.K * (int)PQ * 2;
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           bf16x4 v;
+          float y4[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float a = acc[i][rq * 4 + e];
-            v[e] = (__bf16)(lrelu ? fmaxf(a, a * p.slope) : a);
+            y4[e] = lrelu ? fmaxf(a, a * p.slope) : a;
+            v[e] = (__bf16)y4[e];
           }
-          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), crs, vo, (i * 4 + rq) * (int)PQ * 16, 0);
+          const int so = (i * 4 + rq) * (int)PQ * 16;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), crs, vo, so, 0);
+          if (x3) {                                          // wave-uniform
+            bf16x4 vm, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float r1 = y4[e] - (float)v[e];
+              vm[e] = (__bf16)r1;
+              vl[e] = (__bf16)(r1 - (float)vm[e]);
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, vm), crs, vo, so + limb_bytes, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, vl), crs, vo, so + 2 * limb_bytes, 0);
+          }
         }
       continue;
     }

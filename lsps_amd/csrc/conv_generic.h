@@ -557,7 +557,10 @@ __global__ __launch_bounds__(256) void pw1_dgrad_kernel(const float *__restrict_
 // input) and wpart[block][C] = sum dy.
 // blockIdx.y = slice of PW1_CS channels: with all 64 channels per thread the two running sums per channel are 128 registers
 // (two waves per SIMD, 3.4 TB/s on the two 1 GB streams of a bs = 128 step); 16 channels per thread leave room for eight waves
+// X3OUT (round 5): dx is written as a three-limb X3 tensor [N][3][C/8][HW][8] bf16 (csrc/x3s2.h) — the operand format of the
+// three-limb transposed conv in front of the head, whose LeakyReLU backward this kernel applies; C % 16 == 0.
 #define PW1_CS 16
+template <bool X3OUT>
 __global__ __launch_bounds__(256) void pw1_dgrad_act_kernel(const float *__restrict__ dy, const float *__restrict__ w,
                                                             const float *__restrict__ y, float *__restrict__ dx, float *__restrict__ part,
                                                             float *__restrict__ wpart, int C, int HW4, float slope) {
@@ -581,6 +584,7 @@ __global__ __launch_bounds__(256) void pw1_dgrad_act_kernel(const float *__restr
 #pragma unroll
     for (int c = 0; c < PW1_CS; ++c)                   // all loads of the slice in flight before the first store
       yv[c] = yp[(long)(c < nc ? c : 0) * HW4 + q];    // (channels beyond C: a duplicate load, never stored)
+    f32x4 oo[8];                                         // X3OUT: the 8 channels of a group x 4 pixels, split when the group is complete
 #pragma unroll
     for (int c = 0; c < PW1_CS; ++c) {
       if (c < nc) {
@@ -590,9 +594,29 @@ __global__ __launch_bounds__(256) void pw1_dgrad_act_kernel(const float *__restr
         const float v = wv[c] * g[e];
         o[e] = yv[c][e] > 0.f ? v : v * slope;
       }
-      xp[(long)c * HW4 + q] = o;
+      if (!X3OUT) xp[(long)c * HW4 + q] = o;
       s[c] += (o[0] + o[1]) + (o[2] + o[3]);
       sw[c] += (yv[c][0] * g[0] + yv[c][1] * g[1]) + (yv[c][2] * g[2] + yv[c][3] * g[3]);
+      if (X3OUT) {
+        oo[c & 7] = o;
+        if ((c & 7) == 7) {
+          // units of (image n, limb l, channel group cg, pixel 4 q + e): 16 bytes each, the quad's four pixels contiguous
+          const long cgs = C >> 3, cg = (c0 + c) >> 3, HW = (long)HW4 * 4;
+          unsigned short *base = reinterpret_cast<unsigned short *>(dx) + (((long)n * 3 * cgs + cg) * HW + (long)q * 4) * 8;
+          const long ls = cgs * HW * 8;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v8[k] = oo[k][e];
+            bf16x8 h, m, l;
+            split3(v8, h, m, l);
+            *reinterpret_cast<bf16x8 *>(base + e * 8) = h;
+            *reinterpret_cast<bf16x8 *>(base + ls + e * 8) = m;
+            *reinterpret_cast<bf16x8 *>(base + 2 * ls + e * 8) = l;
+          }
+        }
+      }
       }
     }
   }

@@ -1970,6 +1970,23 @@ int lsps_c8_stem_fwd(const float *x, const float *w, const float *bias, void *y,
                     (hipStream_t)stream, 1);
 }
 
+int lsps_x3_stem_ok(int N, int H, int W, int K, int R, int S, int stride, int pad) {
+  int P, Q;
+  return c8_stem_geom(N, H, W, K, R, S, stride, pad, &P, &Q) && (long)3 * K * P * Q * 2 < (1l << 31) ? 1 : 0;
+}
+
+int lsps_x3_stem_fwd(const float *x, const float *w, const float *bias, void *yl, int N, int H, int W, int K, int R, int S, int stride,
+                     int pad, float slope, void *stream) {
+  (void)hipGetLastError();
+  int P, Q;
+  LSPS_CHECK_ARG(x && w && yl, "x3_stem_fwd: null pointer");
+  LSPS_CHECK_ARG(lsps_x3_stem_ok(N, H, W, K, R, S, stride, pad) && c8_stem_geom(N, H, W, K, R, S, stride, pad, &P, &Q),
+                 "x3_stem_fwd: unsupported geometry (one input channel, K == 64)");
+  LSPS_CHECK_ARG(slope <= 1.f, "x3_stem_fwd: LeakyReLU slope in [0, 1] (or < 0: no activation)");
+  return run_c1_fwd(x, w, bias, (float *)yl, N, H, W, K, P, Q, R, S, stride, pad, slope >= 0.f ? LSPS_ACT_LRELU : LSPS_ACT_NONE, slope,
+                    (hipStream_t)stream, 2);
+}
+
 int lsps_c8_stem_wgrad(const float *x, const void *dy, const void *y, float *dw, float *db, int N, int H, int W, int K, int R, int S,
                        int stride, int pad, float slope, void *ws, size_t ws_bytes, void *stream) {
   (void)hipGetLastError();
@@ -2003,15 +2020,32 @@ int lsps_conv2d_stem_wgrad_act(const float *x, const float *dy, const float *y, 
 
 size_t lsps_pw1_dgrad_act_workspace_bytes(int N, int C) { return (size_t)2 * N * (2 * C + 1) * sizeof(float) + 256; }
 
+static int run_pw1_dgrad_act(const float *dpre, const float *w, const float *act_y, float act_slope, float *dx, bool x3out, float *db_prev,
+                             float *dw, float *db, int N, int C, int HW, void *ws, size_t ws_bytes, void *stream);
+
 int lsps_pw1_dgrad_act(const float *dpre, const float *w, const float *act_y, float act_slope, float *dx, float *db_prev, float *dw,
                        float *db, int N, int C, int HW, void *ws, size_t ws_bytes, void *stream) {
+  return run_pw1_dgrad_act(dpre, w, act_y, act_slope, dx, false, db_prev, dw, db, N, C, HW, ws, ws_bytes, stream);
+}
+
+int lsps_pw1_dgrad_act_x3(const float *dpre, const float *w, const float *act_y, float act_slope, void *dxl, float *db_prev, float *dw,
+                          float *db, int N, int C, int HW, void *ws, size_t ws_bytes, void *stream) {
+  LSPS_CHECK_ARG((C & 15) == 0, "pw1_dgrad_act_x3: C %% 16 == 0");
+  return run_pw1_dgrad_act(dpre, w, act_y, act_slope, (float *)dxl, true, db_prev, dw, db, N, C, HW, ws, ws_bytes, stream);
+}
+
+static int run_pw1_dgrad_act(const float *dpre, const float *w, const float *act_y, float act_slope, float *dx, bool x3out, float *db_prev,
+                             float *dw, float *db, int N, int C, int HW, void *ws, size_t ws_bytes, void *stream) {
   (void)hipGetLastError();
   LSPS_CHECK_ARG(dpre && w && act_y && dx && N > 0 && C > 0 && C <= 64 && HW > 0 && (HW & 3) == 0 && act_slope >= 0.f,
                  "pw1_dgrad_act: bad arguments (C <= 64, HW %% 4 == 0)");
   LSPS_CHECK_ARG(ws && ws_bytes >= (size_t)2 * N * (2 * C + 1) * sizeof(float), "pw1_dgrad_act: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float *part = (float *)ws, *wpart = dw ? part + (size_t)2 * N * C : nullptr;
-  hipLaunchKernelGGL(pw1_dgrad_act_kernel, dim3(2 * N, ceil_div(C, PW1_CS)), dim3(256), 0, st, dpre, w, act_y, dx, part, wpart, C, HW / 4, act_slope);
+  if (x3out)
+    hipLaunchKernelGGL(pw1_dgrad_act_kernel<true>, dim3(2 * N, ceil_div(C, PW1_CS)), dim3(256), 0, st, dpre, w, act_y, dx, part, wpart, C, HW / 4, act_slope);
+  else
+    hipLaunchKernelGGL(pw1_dgrad_act_kernel<false>, dim3(2 * N, ceil_div(C, PW1_CS)), dim3(256), 0, st, dpre, w, act_y, dx, part, wpart, C, HW / 4, act_slope);
   LSPS_CHECK_LAUNCH("pw1_dgrad_act");
   note_kernel("pw1_dgrad_kernel");
   if (db_prev) {

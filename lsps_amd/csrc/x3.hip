@@ -128,7 +128,8 @@ static int x3_device_cus() {
 
 // small[n][m] = act(bias + sum Wt[m][kk][r][s] big[n][kk][2p+r-1][2q+s-1]);  W element (m, kk, t) at m*sm + kk*sc + t
 static int x3s2_run_fwd(const void *big, const float *w, long sm, long sc, const float *bias, float *y, void *yl, int N, int Cx, int H, int W,
-                        int M, float slope, void *ws, size_t ws_bytes, hipStream_t st) {
+                        int M, float slope, void *ws, size_t ws_bytes, hipStream_t st, const void *act_y = nullptr, float act_slope = 0.f,
+                        float *db_prev = nullptr) {
   X3S2Params p;
   if (!x3s2_fwd_geom(N, Cx, H, W, M, &p)) {
     set_error("x3 stride-2 conv (forward direction): unsupported geometry N=%d C=%d %dx%d M=%d", N, Cx, H, W, M);
@@ -147,15 +148,33 @@ static int x3s2_run_fwd(const void *big, const float *w, long sm, long sc, const
   p.YL = (unsigned short *)yl;
   p.N = N; p.Cx = Cx; p.M = M;
   p.lrelu = slope >= 0.f ? slope : 1.f;
-  const dim3 grid(std::min((p.ntiles + 7) / 8 * 8 * (M >> 7), x3_device_cus() / 8 * 8));
-  if (yl) {
-    if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_fwd_kernel<true>), X3F_LDS_BYTES, "x3s2_fwd")) return rc;
-    hipLaunchKernelGGL(x3s2_fwd_kernel<true>, grid, dim3(512), X3F_LDS_BYTES, st, p);
-  } else {
-    if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_fwd_kernel<false>), X3F_LDS_BYTES, "x3s2_fwd")) return rc;
-    hipLaunchKernelGGL(x3s2_fwd_kernel<false>, grid, dim3(512), X3F_LDS_BYTES, st, p);
+  p.ActY = (const unsigned short *)act_y;
+  p.act_slope = act_slope;
+  p.dbpart = nullptr;
+  if (act_y) {
+    p.dbpart = x3s2_dbpart(ws, ws_bytes, p.ntiles, M, (size_t)M * Cx * 9 * 3 * sizeof(unsigned short));
+    if (!p.dbpart) {
+      set_error("x3 stride-2 conv: workspace too small for the bias-gradient partial sums");
+      return LSPS_E_ARG;
+    }
   }
+  const dim3 grid(std::min((p.ntiles + 7) / 8 * 8 * (M >> 7), x3_device_cus() / 8 * 8));
+#define X3F_LAUNCH(O3, MK)                                                                                                  \
+  do {                                                                                                                      \
+    if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_fwd_kernel<O3, MK>), X3F_LDS_BYTES, "x3s2_fwd")) return rc;  \
+    hipLaunchKernelGGL((x3s2_fwd_kernel<O3, MK>), grid, dim3(512), X3F_LDS_BYTES, st, p);                                   \
+  } while (0)
+  if (yl) {
+    if (act_y) X3F_LAUNCH(true, true); else X3F_LAUNCH(true, false);
+  } else {
+    if (act_y) X3F_LAUNCH(false, true); else X3F_LAUNCH(false, false);
+  }
+#undef X3F_LAUNCH
   LSPS_CHECK_LAUNCH("x3s2_fwd");
+  if (act_y && db_prev) {
+    hipLaunchKernelGGL(x3_colsum_kernel, dim3(ceil_div(M, 64)), dim3(256), 0, st, (const float *)p.dbpart, db_prev, M, p.ntiles);
+    LSPS_CHECK_LAUNCH("x3_colsum");
+  }
   return 0;
 }
 
@@ -271,6 +290,9 @@ size_t lsps_x3_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K) {
   X3S2TParams q;
   x3s2_tr_geom(N, K, H, W, C, &q);
   size_t need = pack + align_up((size_t)q.ntiles * C * sizeof(float), 256) + 512;     // packed weights + dgrad's bias-gradient partials
+  X3S2Params f;
+  x3s2_fwd_geom(N, C, H, W, K, &f);                                                   // (as a transposed conv's dgrad: tiles x K)
+  need = std::max(need, pack + align_up((size_t)f.ntiles * K * sizeof(float), 256) + 512);
   X3S2WParams wp;
   x3s2_wgrad_geom(N, K, C, H, W, &wp);
   need = std::max(need, (size_t)wp.splits * 9 * K * C * sizeof(float));
@@ -310,10 +332,11 @@ int lsps_x3_convT3x3s2_fwd(const void *xl, const float *w, const float *bias, fl
   return x3s2_run_tr(xl, w, 9, (long)Co * 9, bias, y, yl, N, Ci, 2 * H, 2 * W, Co, slope, ws, ws_bytes, (hipStream_t)stream);
 }
 
-int lsps_x3_convT3x3s2_dgrad(const void *dyl, const float *w, float *dx, void *dxl, int N, int Ci, int H, int W, int Co, void *ws,
-                             size_t ws_bytes, void *stream) {
+int lsps_x3_convT3x3s2_dgrad(const void *dyl, const float *w, float *dx, void *dxl, const void *act_yl, float act_slope, float *db_prev,
+                             int N, int Ci, int H, int W, int Co, void *ws, size_t ws_bytes, void *stream) {
   LSPS_CHECK_ARG(dyl && w && (dx || dxl), "x3 convT dgrad: null pointer");
-  return x3s2_run_fwd(dyl, w, (long)Co * 9, 9, nullptr, dx, dxl, N, Co, 2 * H, 2 * W, Ci, -1.f, ws, ws_bytes, (hipStream_t)stream);
+  return x3s2_run_fwd(dyl, w, (long)Co * 9, 9, nullptr, dx, dxl, N, Co, 2 * H, 2 * W, Ci, -1.f, ws, ws_bytes, (hipStream_t)stream, act_yl,
+                      act_slope, db_prev);
 }
 
 int lsps_x3_convT3x3s2_wgrad(const void *xl, const void *dyl, float *dw, int N, int Ci, int H, int W, int Co, void *ws, size_t ws_bytes,

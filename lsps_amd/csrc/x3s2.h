@@ -107,6 +107,11 @@ struct X3S2Params {
   int TI, TR;                    // pixel tile (of the output map): TI images x TR rows x Q columns = 128 pixels
   int tiles_per_img, ntiles;
   float lrelu;                   // epilogue: v = max(v, v * lrelu) (1 = no activation)
+  // MASKED (ConvTranspose2d dgrad whose result is the gradient w.r.t. the OUTPUT of the X3 layer in front): y *= LeakyReLU'(ActY)
+  // from the hi limb of that layer's saved X3 output (Y's shape), dbpart[pixel tile][M] = its bias-gradient partial sums
+  const unsigned short *ActY;
+  float act_slope;
+  float *dbpart;
 };
 
 #define X3F_BP 10                                          // image pieces (64 units) per limb and stage: <= 640 units
@@ -117,7 +122,7 @@ struct X3S2Params {
 #define X3F_STAGE ((X3F_BPIECES + X3F_APIECES) * 1024)     // 64512
 #define X3F_LDS_BYTES (2 * X3F_STAGE)                      // 129024
 
-template <bool OUT3>
+template <bool OUT3, bool MASKED>
 __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char x3_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
   __builtin_amdgcn_s_barrier();
 
   while (true) {
-    const int mt_c = mt;
+    const int mt_c = mt, ptile_c = ptile;
     const bool yvalid = yil < nimg;
     const long ypix = (long)(n0 + yil) * p.M * PQ + (long)(p0 + ypl) * Q + yql;          // f32 NCHW: + channel * PQ
     const long yunit = (long)(n0 + yil) * 3 * (p.M >> 3) * PQ + (long)(p0 + ypl) * Q + yql;  // X3: + (limb * M/8 + channel group) * PQ
@@ -272,6 +277,19 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
     }
 
     // epilogue: acc[i][r] = channel mt*128 + wm*64 + i*32 + (r&3) + 8 (r>>2) + 4 half of this lane's pixel
+    float sdb[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) sdb[e] = 0.f;
+    u64 am[2][4];                                                  // MASKED: the mask operand's pieces, all fetched before the first store
+    if (MASKED) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int m4 = mt_c * 128 + wm * 64 + i * 32 + 8 * rq + 4 * half;
+          am[i][rq] = yvalid ? reinterpret_cast<const u64 *>(p.ActY)[((yunit + (long)(m4 >> 3) * PQ) << 1) + half] : 0ull;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -282,8 +300,14 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float x = acc[i][rq * 4 + e] + b4[e];
-          v[e] = fmaxf(x, x * p.lrelu);
+          float x = acc[i][rq * 4 + e] + b4[e];
+          x = fmaxf(x, x * p.lrelu);
+          if (MASKED) {
+            const bf16x4 mk = __builtin_bit_cast(bf16x4, am[i][rq]);
+            x = c8_sel_nonpos((float)mk[e], x * p.act_slope, x);
+            if (yvalid) sdb[i * 16 + rq * 4 + e] += x;
+          }
+          v[e] = x;
         }
         if (!yvalid) continue;
         if (!OUT3) {
@@ -306,6 +330,22 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
           Y[o + 2 * ls] = __builtin_bit_cast(u64, lo);
         }
       }
+    if (MASKED) {
+      // per-channel sums over the workgroup's pixels: butterfly over the 32 pixel lanes of a half, then over the 4 pixel waves
+      c8_reduce_scatter32<16>(sdb, l31);                           // lane (half, l31): slot l31 = i*16 + r of its half
+      float *red = reinterpret_cast<float *>(x3_lds + (buf ^ 1) * X3F_STAGE);   // [wave 8][half 2][32] in the dead buffer
+      red[(wave * 2 + half) * 32 + l31] = sdb[0];
+      __syncthreads();
+      if (tid < 128) {                                             // (wm, half, slot)
+        const int w_m = tid >> 6, hf = (tid >> 5) & 1, qs = tid & 31;
+        float t = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) t += red[((w4 * 2 + w_m) * 2 + hf) * 32 + qs];
+        const int m = mt_c * 128 + w_m * 64 + (qs >> 4) * 32 + (qs & 3) + 8 * ((qs >> 2) & 3) + 4 * hf;
+        p.dbpart[(long)ptile_c * p.M + m] = t;
+      }
+      __syncthreads();                                             // before the next tile's DMA lands on `red`
+    }
     if (!more) return;
     lin += G;
   }

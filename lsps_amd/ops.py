@@ -194,10 +194,15 @@ class ActHolder(object):
     (common_net.run_layers pairs consecutive layers): the consumer's dgrad kernel multiplies the gradient it hands back by
     LeakyReLU'(producer output) in its epilogue and leaves the producer's bias gradient here, so the producer's own
     activation-backward pass (lsps_c8_act_bwd_bias / lsps_act_bwd_bias: three passes over the layer's output) is skipped."""
-    __slots__ = ('slope', 'fused', 'db')
+    __slots__ = ('slope', 'fused', 'db', 'grad', 'want')
 
-    def __init__(self, slope):
-        self.slope, self.fused, self.db = float(slope), False, None
+    def __init__(self, slope, want=None):
+        # `want` / `grad` (round 5): the producer and the consumer keep their activations in DIFFERENT layouts (f32 NCHW vs
+        # three-limb X3), so the gradient the consumer's fused epilogue produces cannot travel along the autograd edge (its shape
+        # is the consumer's input's).  The producer announces the layout it needs ('x3' | 'f32'); the consumer's backward writes
+        # it, leaves it in `grad` and returns None for that input; the producer's backward (set_materialize_grads(False): it
+        # receives None) picks it up here.
+        self.slope, self.fused, self.db, self.grad, self.want = float(slope), False, None, None, want
 
 
 def _fuse_enabled():
@@ -397,8 +402,15 @@ class _ConvT2dFn(torch.autograd.Function):
                     if need_w:                                           # (its bias gradient: from the activation backward above)
                         dw = torch.empty_like(w)
                     wsd, wsdb = _lib.workspace(L.lsps_pw1_dgrad_act_workspace_bytes(N, Ci), x.device)
-                    _lib.check(L.lsps_pw1_dgrad_act(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(x), ctx.prev.slope, _lib.ptr(dx), _lib.ptr(dbp),
-                                                    _lib.ptr(dw), None, N, Ci, H * W, wsd, wsdb, st), 'pw1_dgrad_act')
+                    if ctx.prev.want == 'x3' and Ci % 16 == 0:           # the layer in front is a three-limb layer: hand its gradient
+                        dx = None
+                        gl = torch.empty((N, 3, Ci // 8, H, W, 8), dtype=BF16, device=x.device)       # over as X3 (ActHolder.grad)
+                        _lib.check(L.lsps_pw1_dgrad_act_x3(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(x), ctx.prev.slope, _lib.ptr(gl, BF16),
+                                                           _lib.ptr(dbp), _lib.ptr(dw), None, N, Ci, H * W, wsd, wsdb, st), 'pw1_dgrad_act_x3')
+                        ctx.prev.grad, dx = gl, None
+                    else:
+                        _lib.check(L.lsps_pw1_dgrad_act(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(x), ctx.prev.slope, _lib.ptr(dx), _lib.ptr(dbp),
+                                                        _lib.ptr(dw), None, N, Ci, H * W, wsd, wsdb, st), 'pw1_dgrad_act')
                     ctx.prev.fused, ctx.prev.db = True, dbp
                     if need_w and (db is not None or not want_db):
                         return dx, dw, db, None, None, None, None, None, None, None
@@ -980,7 +992,10 @@ def _x3_grad_operand(L, dy, y, slope, own, want_db, channels, out_f32, st):
     and splits) or X3 already multiplied by LeakyReLU' in the consumer's dgrad epilogue (`own.fused`)."""
     if own is not None and own.fused:
         db = own.db if want_db else None
+        handed, own.grad = own.grad, None
         own.fused, own.db = False, None
+        if handed is not None:
+            return handed, db                            # X3, masked by an f32 consumer and handed over through the holder
         if not out_f32:
             return dy, db                                # X3, masked by the consumer
         slope, want_db_here = -1.0, False                # f32, masked by the consumer (1x1 head): split only
@@ -999,6 +1014,66 @@ def _x3_grad_operand(L, dy, y, slope, own, want_db, channels, out_f32, st):
     return g, (dbh if want_db_here else db)
 
 
+def x3_stem_ok(x, w, stride, pad):
+    """7x7 one-input-channel stem writing its activation straight as X3 (f32 math mode; the consumer must be an X3 layer)."""
+    if get_math_mode() != 'f32' or not options.get().x3 or not options.get().fuse_act or x.dim() != 4 or x.dtype != torch.float32:
+        return False
+    N, C, H, W = x.shape
+    K, C2, R, S = w.shape
+    return N > 0 and C == 1 and C2 == 1 and _lib.lib().lsps_x3_stem_ok(N, H, W, K, R, S, stride, pad) == 1
+
+
+class _StemX3Fn(torch.autograd.Function):
+    """LeakyReLUConv2d(1, 64, 7, stride, 3) (lsps_nets.py:117,184) with an X3 output.  The layer behind it (an X3 conv) applies this
+    layer's LeakyReLU backward in its dgrad epilogue and hands the f32 NCHW result + the bias gradient back through `own`."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, slope, own):
+        L = _lib.lib()
+        x, w = _c(x), _c(w)
+        ctx.set_materialize_grads(False)
+        N, _, H, W = x.shape
+        K, _, R, S = w.shape
+        P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
+        y = torch.empty((N, 3, K // 8, P, Q, 8), dtype=BF16, device=x.device)
+        with profiler.span(2.0 * N * K * P * Q * R * S):
+            _lib.check(L.lsps_x3_stem_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y, BF16), N, H, W, K, R, S, stride, pad, slope,
+                                          _lib.stream()), 'x3_stem_fwd')
+        ctx.geom = (N, H, W, K, R, S, stride, pad)
+        ctx.own, ctx.has_bias = own, b is not None
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w = ctx.saved_tensors
+        N, H, W, K, R, S, stride, pad = ctx.geom
+        own = ctx.own
+        assert dy is None and own.fused and own.grad is not None, "X3 stem: the consumer did not hand the gradient over"
+        g, db = own.grad, (own.db if (ctx.has_bias and ctx.needs_input_grad[2]) else None)
+        own.fused, own.db, own.grad = False, None, None
+        st = _lib.stream()
+        flops = 2.0 * N * K * g.shape[2] * g.shape[3] * R * S
+        ws, wsb = _lib.workspace(L.lsps_conv2d_workspace_bytes(N, 1, H, W, K, R, S, stride, pad), x.device)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            with profiler.span(flops):
+                _lib.check(L.lsps_conv2d_dgrad(_lib.ptr(g), _lib.ptr(w), _lib.ptr(dx), N, 1, H, W, K, R, S, stride, pad, ws, wsb, st),
+                           'conv2d_dgrad')
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            with profiler.span(flops):
+                _lib.check(L.lsps_conv2d_wgrad(_lib.ptr(x), _lib.ptr(g), _lib.ptr(dw), None, N, 1, H, W, K, R, S, stride, pad, ws, wsb, st),
+                           'conv2d_wgrad')
+        return dx, dw, db, None, None, None, None
+
+
+def stem_x3(x, w, b, stride, pad, slope, own):
+    return _StemX3Fn.apply(x, w, b, int(stride), int(pad), float(slope), own)
+
+
 class _ConvS2X3Fn(torch.autograd.Function):
     """LeakyReLUConv2d(C, K, 3, 2, 1) (common_net.py:246-256) on the three-limb kernels: x f32 NCHW (split here) or X3 (the
     output of the X3 layer in front: `prev`) -> y f32 NCHW (`out_f32`) or X3 (for the X3 layer behind: `own`)."""
@@ -1007,6 +1082,7 @@ class _ConvS2X3Fn(torch.autograd.Function):
     def forward(ctx, x, w, b, slope, prev, own, out_f32):
         L = _lib.lib()
         w = _c(w)
+        ctx.set_materialize_grads(False)     # the gradient may arrive through the ActHolder instead of the autograd edge
         ctx.x_is_x3 = is_x3(x)
         xl = _c(x) if ctx.x_is_x3 else x3_split(x)
         N, _, G, H, W, _ = xl.shape
@@ -1047,6 +1123,15 @@ class _ConvS2X3Fn(torch.autograd.Function):
                     dx = torch.empty((N, C, H, W), dtype=torch.float32, device=xl.device)
                     _lib.check(L.lsps_x3_conv3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(dx), None, None, 0.0, None, N, C, H, W, K,
                                                          ws, wsb, st), 'x3_conv3x3s2_dgrad')
+                elif _fusable(ctx.prev) and ctx.prev.want == 'f32':
+                    # x is the X3 output of an f32 layer (a 7x7 stem): its LeakyReLU backward rides along, the result goes back
+                    # as f32 NCHW through the holder
+                    gf = torch.empty((N, C, H, W), dtype=torch.float32, device=xl.device)
+                    dbp = torch.empty(C, dtype=torch.float32, device=xl.device)
+                    _lib.check(L.lsps_x3_conv3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(gf), None, _lib.ptr(xl, BF16),
+                                                         ctx.prev.slope, _lib.ptr(dbp), N, C, H, W, K, ws, wsb, st),
+                               'x3_conv3x3s2_dgrad(masked, f32)')
+                    ctx.prev.fused, ctx.prev.db, ctx.prev.grad = True, dbp, gf
                 else:
                     dx = torch.empty_like(xl)
                     if _fusable(ctx.prev):               # x is the previous X3 layer's output: its LeakyReLU backward rides along
@@ -1073,6 +1158,7 @@ class _ConvTS2X3Fn(torch.autograd.Function):
     def forward(ctx, x, w, b, slope, prev, own, out_f32):
         L = _lib.lib()
         w = _c(w)
+        ctx.set_materialize_grads(False)     # the gradient may arrive through the ActHolder instead of the autograd edge
         ctx.x_is_x3 = is_x3(x)
         xl = _c(x) if ctx.x_is_x3 else x3_split(x)
         N, _, G, H, W, _ = xl.shape
@@ -1110,12 +1196,19 @@ class _ConvTS2X3Fn(torch.autograd.Function):
             with profiler.span(flops, 'x3s2_fwd_kernel'):
                 if not ctx.x_is_x3:
                     dx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=xl.device)
-                    _lib.check(L.lsps_x3_convT3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(dx), None, N, Ci, H, W, Co, ws, wsb, st),
-                               'x3_convT3x3s2_dgrad')
-                else:                                    # (no fused mask in the forward-direction kernel: the producer runs its own pass)
+                    _lib.check(L.lsps_x3_convT3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), _lib.ptr(dx), None, None, 0.0, None, N, Ci, H, W, Co,
+                                                          ws, wsb, st), 'x3_convT3x3s2_dgrad')
+                else:
                     dx = torch.empty_like(xl)
-                    _lib.check(L.lsps_x3_convT3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), None, _lib.ptr(dx, BF16), N, Ci, H, W, Co, ws, wsb,
-                                                          st), 'x3_convT3x3s2_dgrad')
+                    if _fusable(ctx.prev):               # x is the previous X3 layer's output: its LeakyReLU backward rides along
+                        dbp = torch.empty(Ci, dtype=torch.float32, device=xl.device)
+                        _lib.check(L.lsps_x3_convT3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), None, _lib.ptr(dx, BF16), _lib.ptr(xl, BF16),
+                                                              ctx.prev.slope, _lib.ptr(dbp), N, Ci, H, W, Co, ws, wsb, st),
+                                   'x3_convT3x3s2_dgrad(masked)')
+                        ctx.prev.fused, ctx.prev.db = True, dbp
+                    else:
+                        _lib.check(L.lsps_x3_convT3x3s2_dgrad(_lib.ptr(g, BF16), _lib.ptr(w), None, _lib.ptr(dx, BF16), None, 0.0, None, N,
+                                                              Ci, H, W, Co, ws, wsb, st), 'x3_convT3x3s2_dgrad')
         return dx, dw, db, None, None, None, None
 
 

@@ -126,7 +126,10 @@ def run_layers(layers, x, noise=None):
         if isinstance(n, LeakyReLUConv2d):
             c = n.model[0]
             return ops.x3_conv_s2_ok(probe, c.weight, c.stride, c.padding)
-        return False                                               # (the X3 transposed-conv dgrad has no fused mask: f32 hand-over)
+        if isinstance(n, LeakyReLUConvTranspose2d) and isinstance(layers[i], LeakyReLUConvTranspose2d):
+            c = n.model[0]
+            return c.act == ACT_LRELU and ops.x3_convT_s2_ok(probe, c.weight, c.stride, c.padding, c.output_padding)
+        return False
 
     for i, l in enumerate(layers):
         if isinstance(l, LeakyINSResBlock):
@@ -146,6 +149,14 @@ def run_layers(layers, x, noise=None):
                 own = ops.ActHolder(LRELU_SLOPE)
                 x = ops.conv3x3s2_c8(xin, c.weight, c.bias, LRELU_SLOPE, prev if xin is x else None, own)
                 prev = own
+            elif ops.x3_stem_ok(x, c.weight, c.stride, c.padding) and \
+                    x3_next(i, (x.shape[0], c.weight.shape[0], ops.conv_out_size(x.shape[2], c.weight.shape[2], c.stride, c.padding),
+                                ops.conv_out_size(x.shape[3], c.weight.shape[3], c.stride, c.padding))):
+                # f32 math mode, 7x7 stem in front of a three-limb layer: the f32 kernel writes its activation as limbs; that layer's
+                # dgrad applies this one's LeakyReLU backward and hands the f32 gradient back through the holder (ops.ActHolder)
+                own = ops.ActHolder(LRELU_SLOPE, want='f32')
+                x = ops.stem_x3(x, c.weight, c.bias, c.stride, c.padding, LRELU_SLOPE, own)
+                prev = own
             elif ops.x3_conv_s2_ok(x, c.weight, c.stride, c.padding):   # f32 math mode: three-limb operands on the bf16 pipe
                 N, C, H, W = ops._x3_shape(x)
                 chain = x3_next(i, (N, c.weight.shape[0], H // 2, W // 2))
@@ -162,10 +173,13 @@ def run_layers(layers, x, noise=None):
                 x = ops.convT3x3s2_c8(xin, c.weight, c.bias, LRELU_SLOPE, prev if xin is x else None, own)
                 prev = own
             elif c.act == ACT_LRELU and ops.x3_convT_s2_ok(x, c.weight, c.stride, c.padding, c.output_padding):
-                # f32 out: the consumer is another transposed conv (splits its input) or the 1x1 head (fuses this layer's LeakyReLU
-                # backward through the ActHolder, like the f32 kernel's path below)
-                own = ops.ActHolder(LRELU_SLOPE)
-                x = ops.convT3x3s2_x3(ops.from_c8(x), c.weight, c.bias, LRELU_SLOPE, None, own, out_f32=True)
+                # X3 out into another three-limb transposed conv (its dgrad applies this layer's LeakyReLU backward); f32 out into
+                # the 1x1 head, which fuses this layer's LeakyReLU backward like on the f32 path below and hands the gradient back
+                # as limbs (ActHolder.want)
+                N, C, H, W = ops._x3_shape(x)
+                chain = x3_next(i, (N, c.weight.shape[1], 2 * H, 2 * W))
+                own = ops.ActHolder(LRELU_SLOPE, want=None if chain else 'x3')
+                x = ops.convT3x3s2_x3(x, c.weight, c.bias, LRELU_SLOPE, prev if ops.is_x3(x) else None, own, out_f32=not chain)
                 prev = own
             else:                                                       # f32 (or a shape without a C8 kernel)
                 own = ops.ActHolder(LRELU_SLOPE)

@@ -548,7 +548,9 @@ def test_frozen_generator_packs_survive_steps_and_follow_weight_changes(graphs, 
         if graphs:
             # a graph captured while the panels were frozen carries the generator epoch it is valid for; those of older epochs
             # are dropped, the one of the current epoch exists (and was replayed by the last call)
-            eps = [k[-1][1] for k in tr._graphs if k[0] == 'post_update']
+            # (the tag is (epoch, count of re-targetings of the library's process-wide frozen table): ops.frozen_resets)
+            tags = [k[-1][1] for k in tr._graphs if k[0] == 'post_update']
+            eps = [None if t is None else t[0] for t in tags]
             assert all(e in (None, epochs[-1]) for e in eps), (eps, epochs)
             assert (epochs[-1] in eps) == frozen, (eps, frozen)
         outs.append((trace, A.params(tr, 'dis'), A.params(tr, 'gen')))
@@ -556,6 +558,46 @@ def test_frozen_generator_packs_survive_steps_and_follow_weight_changes(graphs, 
     for net in (1, 2):
         for k in outs[0][net]:
             assert np.array_equal(outs[0][net][k], outs[1][net][k]), k
+
+
+def test_two_graphed_trainers_alternating_post_update_keep_their_own_frozen_panels():
+    """the library's frozen table is one per process.  Two trainers with DIFFERENT generator weights, both replaying
+    their estimate steps from hipGraphs, alternate post_update in one process: each trainer's results equal, bitwise, those of
+    the same trainer stepping alone in eager mode (every trainer owns its panel buffer, and a graph captured while panels were
+    frozen is dropped as soon as the table has been re-targeted by anybody)."""
+    A = _adapter()
+    hp = cases.hp_for('tiny')
+    sds = [cases.make_weights(hp, lsps_ref), cases.make_weights(hp, lsps_ref)]
+    sds[1]['gen'] = {k: (v * 1.25).astype(v.dtype) for k, v in sds[1]['gen'].items()}
+    b = cases.make_inputs(8)
+    lat, zd = cases.latent_shape(hp, 8), hp['vae']['z_dim']
+
+    def post(tr, rnd):
+        A.post_update(tr, b, 3, hp, cases.noise(lat, 60 + rnd), cases.noise((8, zd), 61 + rnd, 0.05), cases.noise((8, zd), 62 + rnd, 0.05))
+        return A.scalars(tr)
+    alone = []
+    for sd in sds:
+        tr = A.make_trainer(hp, sd)
+        A.set_train(tr, True)
+        alone.append(([post(tr, r) for r in range(6)], A.params(tr, 'dis')))
+        del tr
+    trs = [A.make_trainer(hp, sd) for sd in sds]
+    for tr in trs:
+        tr.use_graphs(True)
+        A.set_train(tr, True)
+    # two steps each first (the panels freeze once two consecutive post_update calls saw the same generator epoch), then strictly
+    # alternating, then a run of one trainer (which captures and replays a frozen graph) before the other comes back
+    order = [0, 0, 1, 1, 0, 1, 0, 1, 0, 0, 1, 1]
+    traces, count = [[], []], [0, 0]
+    for i in order:
+        traces[i].append(post(trs[i], count[i]))
+        count[i] += 1
+    for i in (0, 1):
+        assert traces[i] == alone[i][0], (i, traces[i], alone[i][0])
+        got = A.params(trs[i], 'dis')
+        for k in got:
+            assert np.array_equal(got[k], alone[i][1][k]), (i, k)
+    assert traces[0] != traces[1]
 
 
 def test_two_trainers_in_different_math_modes_alternate_in_one_process():

@@ -127,6 +127,71 @@ def test_transposed_conv_forward_dgrad_wgrad(N, Ci, H, Co):
     assert _rel(dw, wd.grad) < TOL
 
 
+def test_transposed_conv_dgrad_with_fused_activation_backward():
+    """ConvTranspose2d dgrad (forward-direction kernel) with the LeakyReLU backward + bias gradient of the X3 layer in front."""
+    _need_gpu()
+    _lib, L, ops, dev, st = _env()
+    torch.manual_seed(11)
+    N, Ci, H, Co = 3, 256, 16, 128
+    w = torch.randn(Ci, Co, 3, 3, device=dev) * 0.05
+    dy = torch.randn(N, Co, 2 * H, 2 * H, device=dev)
+    yprev = torch.randn(N, Ci, H, H, device=dev)
+    dyl, ypl = ops.x3_split(dy), ops.x3_split(yprev)
+    ws, wsb = _lib.workspace(L.lsps_x3_conv3x3s2_workspace_bytes(N, Co, 2 * H, 2 * H, Ci), dev)
+    ref = F.conv2d(dy.double().cpu(), w.double().cpu(), None, stride=2, padding=1)          # dgrad of the transposed conv
+    g_ref = torch.where(yprev.double().cpu() > 0, ref, ref * 0.01)
+    dxl = torch.empty(N, 3, Ci // 8, H, H, 8, dtype=BF, device=dev)
+    db = torch.empty(Ci, device=dev)
+    _lib.check(L.lsps_x3_convT3x3s2_dgrad(_lib.ptr(dyl, BF), _lib.ptr(w), None, _lib.ptr(dxl, BF), _lib.ptr(ypl, BF), 0.01, _lib.ptr(db), N, Ci, H, H,
+                                          Co, ws, wsb, st), 'dm')
+    assert _rel(ops.x3_join(dxl), g_ref) < TOL
+    assert _rel(db, g_ref.sum((0, 2, 3))) < 1e-4
+    dx = torch.empty(N, Ci, H, H, device=dev)
+    _lib.check(L.lsps_x3_convT3x3s2_dgrad(_lib.ptr(dyl, BF), _lib.ptr(w), _lib.ptr(dx), None, _lib.ptr(ypl, BF), 0.01, _lib.ptr(db), N, Ci, H, H, Co,
+                                          ws, wsb, st), 'dm32')
+    assert _rel(dx, g_ref) < TOL
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_stem_writes_limbs(stride):
+    """The 7x7 one-input-channel stems with the limb-splitting epilogue: exactly the f32 kernel's output, split."""
+    _need_gpu()
+    _lib, L, ops, dev, st = _env()
+    torch.manual_seed(12)
+    N, H, K = 3, 128, 64
+    x = torch.randn(N, 1, H, H, device=dev)
+    w = torch.randn(K, 1, 7, 7, device=dev) * 0.1
+    b = torch.randn(K, device=dev)
+    assert L.lsps_x3_stem_ok(N, H, H, K, 7, 7, stride, 3) == 1
+    P = (H + 6 - 7) // stride + 1
+    yl = torch.empty(N, 3, K // 8, P, P, 8, dtype=BF, device=dev)
+    _lib.check(L.lsps_x3_stem_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(yl, BF), N, H, H, K, 7, 7, stride, 3, 0.01, st), 'stem')
+    y = ops.conv2d(x, w, b, stride, 3, ops.ACT_LRELU, 0.01)
+    assert torch.equal(ops.x3_join(yl), y)
+    ref = F.leaky_relu(F.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), stride=stride, padding=3), 0.01)
+    assert _rel(y, ref) < TOL
+
+
+def test_output_head_dgrad_emits_limbs():
+    """lsps_pw1_dgrad_act_x3: the 1x1 head's input gradient with the LeakyReLU backward of the layer in front, written as limbs —
+    bit for bit the f32 entry's result, split."""
+    _need_gpu()
+    _lib, L, ops, dev, st = _env()
+    torch.manual_seed(13)
+    N, C, H = 3, 64, 64
+    dpre, w, y = torch.randn(N, 1, H, H, device=dev), torch.randn(C, device=dev), torch.randn(N, C, H, H, device=dev)
+    ws, wsb = _lib.workspace(L.lsps_pw1_dgrad_act_workspace_bytes(N, C), dev)
+    dx, db0, dw0 = torch.empty(N, C, H, H, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+    _lib.check(L.lsps_pw1_dgrad_act(_lib.ptr(dpre), _lib.ptr(w), _lib.ptr(y), 0.01, _lib.ptr(dx), _lib.ptr(db0), _lib.ptr(dw0), None, N, C, H * H,
+                                    ws, wsb, st), 'pw1')
+    gl, db1, dw1 = torch.empty(N, 3, C // 8, H, H, 8, dtype=BF, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+    _lib.check(L.lsps_pw1_dgrad_act_x3(_lib.ptr(dpre), _lib.ptr(w), _lib.ptr(y), 0.01, _lib.ptr(gl, BF), _lib.ptr(db1), _lib.ptr(dw1), None, N, C,
+                                       H * H, ws, wsb, st), 'pw1x3')
+    assert torch.equal(ops.x3_join(gl), dx) and torch.equal(db0, db1) and torch.equal(dw0, dw1)
+    ref = torch.where(y > 0, w.view(1, C, 1, 1) * dpre, w.view(1, C, 1, 1) * dpre * 0.01)
+    assert _rel(dx, ref) < 1e-6
+
+
 def test_activation_backward_emits_limbs():
     _need_gpu()
     _lib, L, ops, dev, st = _env()
