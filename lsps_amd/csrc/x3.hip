@@ -107,9 +107,23 @@ static int x3s2_pack(const float *w, int M, int C, long sm, long sc, int BM, voi
   return 0;
 }
 
-// bias-gradient partial sums of a MASKED transposed launch: [ntiles][M] floats at the END of the workspace
+// out[c] = sum over `rows` rows of part[rows][C]; `scratch`: 64 * C floats (used when rows > 64)
+static int x3_colsum(const float *part, float *out, int C, int rows, float *scratch, hipStream_t st) {
+  if (rows > 64) {
+    const int rpc = (rows + 63) / 64, chunks = (rows + rpc - 1) / rpc;
+    hipLaunchKernelGGL(x3_colsum_kernel, dim3(ceil_div(C, 64), chunks), dim3(256), 0, st, part, scratch, C, rows, rpc);
+    LSPS_CHECK_LAUNCH("x3_colsum_stage1");
+    part = scratch;
+    rows = chunks;
+  }
+  hipLaunchKernelGGL(x3_colsum_kernel, dim3(ceil_div(C, 64), 1), dim3(256), 0, st, part, out, C, rows, rows);
+  LSPS_CHECK_LAUNCH("x3_colsum");
+  return 0;
+}
+
+// bias-gradient partial sums of a MASKED launch: [ntiles + 64][M] floats at the END of the workspace (the last 64 rows: scratch of x3_colsum)
 static float *x3s2_dbpart(void *ws, size_t ws_bytes, int ntiles, int M, size_t pack_bytes) {
-  const size_t need = (size_t)ntiles * M * sizeof(float);
+  const size_t need = ((size_t)ntiles + 64) * M * sizeof(float);
   if (!ws || ws_bytes < align_up(pack_bytes, 256) + need + 256) return nullptr;
   return reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + ((ws_bytes - need) & ~(size_t)255));
 }
@@ -171,10 +185,7 @@ static int x3s2_run_fwd(const void *big, const float *w, long sm, long sc, const
   }
 #undef X3F_LAUNCH
   LSPS_CHECK_LAUNCH("x3s2_fwd");
-  if (act_y && db_prev) {
-    hipLaunchKernelGGL(x3_colsum_kernel, dim3(ceil_div(M, 64)), dim3(256), 0, st, (const float *)p.dbpart, db_prev, M, p.ntiles);
-    LSPS_CHECK_LAUNCH("x3_colsum");
-  }
+  if (act_y && db_prev) return x3_colsum(p.dbpart, db_prev, M, p.ntiles, p.dbpart + (size_t)p.ntiles * M, st);
   return 0;
 }
 
@@ -223,10 +234,7 @@ static int x3s2_run_tr(const void *small, const float *w, long sm, long sc, cons
   }
 #undef X3T_LAUNCH
   LSPS_CHECK_LAUNCH("x3s2_tr");
-  if (act_y && db_prev) {
-    hipLaunchKernelGGL(x3_colsum_kernel, dim3(ceil_div(M, 64)), dim3(256), 0, st, (const float *)p.dbpart, db_prev, M, p.ntiles);
-    LSPS_CHECK_LAUNCH("x3_colsum");
-  }
+  if (act_y && db_prev) return x3_colsum(p.dbpart, db_prev, M, p.ntiles, p.dbpart + (size_t)p.ntiles * M, st);
   return 0;
 }
 
@@ -289,10 +297,10 @@ size_t lsps_x3_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K) {
   const size_t pack = align_up((size_t)K * C * 9 * 3 * sizeof(unsigned short), 256);
   X3S2TParams q;
   x3s2_tr_geom(N, K, H, W, C, &q);
-  size_t need = pack + align_up((size_t)q.ntiles * C * sizeof(float), 256) + 512;     // packed weights + dgrad's bias-gradient partials
+  size_t need = pack + align_up(((size_t)q.ntiles + 64) * C * sizeof(float), 256) + 512;     // packed weights + dgrad's bias-gradient partials
   X3S2Params f;
   x3s2_fwd_geom(N, C, H, W, K, &f);                                                   // (as a transposed conv's dgrad: tiles x K)
-  need = std::max(need, pack + align_up((size_t)f.ntiles * K * sizeof(float), 256) + 512);
+  need = std::max(need, pack + align_up(((size_t)f.ntiles + 64) * K * sizeof(float), 256) + 512);
   X3S2WParams wp;
   x3s2_wgrad_geom(N, K, C, H, W, &wp);
   need = std::max(need, (size_t)wp.splits * 9 * K * C * sizeof(float));
@@ -347,7 +355,7 @@ int lsps_x3_convT3x3s2_wgrad(const void *xl, const void *dyl, float *dw, int N, 
 
 size_t lsps_x3_act_bwd_bias_workspace_bytes(int N, int C) {
   if (N <= 0 || C <= 0) return 0;
-  return ((size_t)256 + 8) * C * sizeof(float);
+  return ((size_t)256 + 64 + 8) * C * sizeof(float);
 }
 
 /* g (X3) = dy * LeakyReLU'(y) from f32 NCHW dy and the layer's f32 NCHW OUTPUT y (slope < 0: g = dy, y may be NULL);
@@ -364,16 +372,13 @@ int lsps_x3_act_bwd_bias(const float *dy, const float *y, void *gl, float *db, i
   splits = (N + ips - 1) / ips;
   float *part = nullptr;
   if (db) {
-    LSPS_CHECK_ARG(ws && ws_bytes >= (size_t)splits * C * sizeof(float), "x3 act_bwd_bias: workspace too small");
+    LSPS_CHECK_ARG(ws && ws_bytes >= ((size_t)splits + 64) * C * sizeof(float), "x3 act_bwd_bias: workspace too small");
     part = (float *)ws;
   }
   hipLaunchKernelGGL(x3_act_bwd_bias_nchw_kernel, dim3(C >> 3, splits), dim3(256), 0, st, dy, y, (unsigned short *)gl, part, N, C, HW, ips,
                      slope);
   LSPS_CHECK_LAUNCH("x3_act_bwd_bias");
-  if (db) {
-    hipLaunchKernelGGL(x3_colsum_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, (const float *)part, db, C, splits);
-    LSPS_CHECK_LAUNCH("x3_colsum");
-  }
+  if (db) return x3_colsum(part, db, C, splits, part + (size_t)splits * C, st);
   return 0;
 }
 

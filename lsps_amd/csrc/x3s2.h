@@ -860,17 +860,20 @@ __global__ __launch_bounds__(256) void x3_wgrad_reduce_kernel(const float *__res
   }
 }
 
-// out[c] = sum over rows of part[rows][C] (bias-gradient partial sums of the MASKED transposed kernel): one thread per channel,
-// four interleaved row slices
-__global__ __launch_bounds__(256) void x3_colsum_kernel(const float *__restrict__ part, float *__restrict__ out, int C, int rows) {
+// Column sums of part[rows][C] (bias-gradient partial sums of the MASKED kernels: up to thousands of rows).  Stage 1: grid
+// (ceil(C / 64), chunks): part2[chunk][c] = sum of the chunk's rows (thread = (row lane 0..3, channel)); stage 2 (the same kernel
+// with one chunk): out[c] = sum of part2's rows.  Fixed summation order.
+__global__ __launch_bounds__(256) void x3_colsum_kernel(const float *__restrict__ part, float *__restrict__ out, int C, int rows,
+                                                        int rows_per_chunk) {
   __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, chunk = blockIdx.y;
+  const int r0 = chunk * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
   float s = 0.f;
   if (c < C)
-    for (int r = rl; r < rows; r += 4) s += part[(long)r * C + c];
+    for (int r = r0 + rl; r < r1; r += 4) s += part[(long)r * C + c];
   red[rl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rl == 0 && c < C) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (rl == 0 && c < C) out[(long)chunk * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

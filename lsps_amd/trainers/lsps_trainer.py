@@ -295,6 +295,8 @@ class LSPSTrainer(nn.Module):
             sig = sig + (('gen_epoch', tag),)
             for old in [k for k in self._graphs if k[0] == 'post_update' and k[-1][1] not in (None, tag)]:
                 del self._graphs[old]
+            if not self._graphs:
+                self._graph_pool = None      # torch releases a private pool with its last graph: never capture into a dead handle
         g = self._graphs.get(sig)
         if g is not None:
             self._frozen_decided = None
