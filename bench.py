@@ -542,14 +542,23 @@ def main():
                                     'mfma_issued_frac) is the utilisation of the MFMA pipe (f32: sustained ceiling 0.874, '
                                     'profiles/r1i_mfma_sustained_probe.txt; plain VALU does not overlap the f32 MFMA, '
                                     'profiles/r2_mfma_valu_overlap.txt)' % ('2x2' if wino_x == 2.25 else '4x4', wino_x))
-        # whole step: MFMA flops actually ISSUED by all conv kernels (algorithmic / 2.25 for the F2, / 4 for the F4 Winograd
-        # kernels, algorithmic otherwise; from the fully profiled pass) over the step time, against the pipe's peak
+        # whole step: time the matrix pipes are busy with the MFMAs the conv kernels ISSUE (from the fully profiled pass) over the
+        # step time.  f32 pipe: algorithmic flops / 2.25 (F2) resp. / 4 (F4 Winograd), algorithmic otherwise, at 157.3 TFLOP/s;
+        # the three-limb kernels (csrc/x3s2.h) issue SIX v_mfma_f32_32x32x16_bf16 per algorithmic 32x32x16 product on the bf16
+        # pipe (2.5 PFLOP/s dense).  (A bf16-mode line: every conv kernel on the bf16 pipe, one MFMA per product.)
         step_issued_frac = None
         if prof_all:
             wx = {'wino_f3x3_kernel': 2.25, 'wino_w3x3_kernel': 2.25, 'wino4_f3x3_kernel': 4.0, 'wino4_w3x3_kernel': 4.0,
                   'wino_f3x3_bf16_kernel': 2.25, 'wino_f3x3_in_bf16_kernel': 2.25}
-            issued = sum(a['tflops'] * a['total_ms'] * 1e9 / wx.get(k, 1.0) for k, a in prof_all.items()) / prof_all_steps
-            step_issued_frac = issued / (elapsed / args.steps) / (peak * 1e12)
+            busy_s = 0.0
+            for k, a in prof_all.items():
+                alg = a['tflops'] * 1e12 * a['total_ms'] * 1e-3
+                if k.startswith('x3s2_'):
+                    busy_s += 6.0 * alg / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+                    a['pipe'] = 'bf16 (six MFMAs per product): %.3f of the pipe busy' % (6.0 * a['tflops'] / BF16_MFMA_PEAK_TFLOPS)
+                else:
+                    busy_s += alg / wx.get(k, 1.0) / (peak * 1e12)
+            step_issued_frac = busy_s / prof_all_steps / (elapsed / args.steps)
         out = {
             'metric': 'depth_train steps/sec (128x128x1, bs=%d)' % args.batch, 'value': world * args.steps / elapsed,
             'unit': 'steps/s',

@@ -253,8 +253,11 @@ def test_layer_chains_match_the_f32_kernels(what, monkeypatch):
         assert any(k.startswith('x3s2_') for k in names) == (gmac == '0'), names
         res.append([out.detach().clone(), xx.grad.clone()] + [p.grad.clone() for m in layers for p in m.parameters()])
     assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5 * float(res[0][0].abs().max())
-    for a, b in zip(res[1][1:], res[0][1:]):
+    for i, (a, b) in enumerate(zip(res[1][1:], res[0][1:])):
         d, am = (a - b).abs().double().flatten(), float(b.abs().max())
         q = float(torch.quantile(d[:: max(1, d.numel() // 1000000)], 0.5))
         assert q <= 2e-5 * am + 1e-12, (a.shape, q, am)
-        assert float(d.norm()) <= 1e-3 * float(b.double().norm()) + 1e-12, (a.shape, float(d.norm()), float(b.double().norm()))
+        # ONE flipped mask at 128 x 128 changes ~0.3 % of the input gradient's elements by ~3 % each = 1.6e-3 of its L2 norm
+        # (measured: 1.4e-3 with one flip); the parameter gradients sum over every pixel and barely see a flip
+        l2 = 5e-3 if i == 0 else 1e-3
+        assert float(d.norm()) <= l2 * float(b.double().norm()) + 1e-12, (a.shape, float(d.norm()), float(b.double().norm()))
