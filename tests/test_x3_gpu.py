@@ -258,6 +258,7 @@ def test_layer_chains_match_the_f32_kernels(what, monkeypatch):
         q = float(torch.quantile(d[:: max(1, d.numel() // 1000000)], 0.5))
         assert q <= 2e-5 * am + 1e-12, (a.shape, q, am)
         # ONE flipped mask at 128 x 128 changes ~0.3 % of the input gradient's elements by ~3 % each = 1.6e-3 of its L2 norm
-        # (measured: 1.4e-3 with one flip); the parameter gradients sum over every pixel and barely see a flip
-        l2 = 5e-3 if i == 0 else 1e-3
+        # (measured: 1.4e-3 with one flip); the parameter gradients sum over every pixel of only 3 samples here and see it at ~1e-3
+        # (measured 1.15e-3 on the first transposed conv's weight).  A wrong tap, mask or scale would show at 0.1 - 1.
+        l2 = 5e-3 if i == 0 else 3e-3
         assert float(d.norm()) <= l2 * float(b.double().norm()) + 1e-12, (a.shape, float(d.norm()), float(b.double().norm()))
