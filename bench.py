@@ -559,6 +559,25 @@ def main():
                 else:
                     busy_s += alg / wx.get(k, 1.0) / (peak * 1e12)
             step_issued_frac = busy_s / prof_all_steps / (elapsed / args.steps)
+        # the three-limb stride-2 family (round 5): live event times of this run + the PMC pass of the same build (offline:
+        # rocprofv3 --pmc cannot run inside the timed bench): bf16-pipe busy fraction and HBM bytes per launch
+        if roofline is not None and prof_all:
+            x3 = {k: a for k, a in prof_all.items() if k.startswith('x3s2_')}
+            if x3:
+                tot_ms = sum(a['total_ms'] for a in x3.values()) / prof_all_steps
+                alg = sum(a['tflops'] * a['total_ms'] for a in x3.values()) / max(sum(a['total_ms'] for a in x3.values()), 1e-9)
+                blk = {'kernels': sorted(x3), 'ms_per_step': tot_ms, 'share_of_step_time': tot_ms / (1e3 * elapsed / args.steps),
+                       'algorithmic_tflops': alg, 'bf16_mfma_issued_tflops': 6.0 * alg,
+                       'bf16_pipe_issued_frac': 6.0 * alg / BF16_MFMA_PEAK_TFLOPS,
+                       'note': 'f32-class arithmetic on the bf16 matrix pipe: operands as three exact bf16 limbs, six '
+                               'v_mfma_f32_32x32x16_bf16 per product, f32 accumulation (csrc/x3s2.h); issued_frac is against the '
+                               'nominal 2.5 PFLOP/s (2.4 GHz), pmc.bf16_pipe_busy_frac against the clock the kernels actually hold'}
+                try:
+                    with open(os.path.join(REPO, 'profiles', 'r5i_pmc_x3.json')) as f:
+                        blk['pmc'] = json.load(f)
+                except (OSError, ValueError):
+                    blk['pmc'] = None
+                roofline['three_limb_stride2_family'] = blk
         out = {
             'metric': 'depth_train steps/sec (128x128x1, bs=%d)' % args.batch, 'value': world * args.steps / elapsed,
             'unit': 'steps/s',
