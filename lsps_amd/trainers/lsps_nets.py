@@ -185,6 +185,29 @@ class SharedDis(_Net):
     def regress_b(self, x_B):
         return self._regress(self.model_B, x_B)
 
+    def regress_feats(self, x_A, x_B, x_aa, x_ba, x_ab, x_bb):
+        """`regress_a(x_A)[1]` (and `regress_b(x_B)[1]` when x_B is given) together with `feats(x_aa, x_ba, x_ab, x_bb)` from ONE
+        pass of each front and ONE pass of the shared trunk: the samples of the two calls are concatenated along the batch
+        (front A: [x_A | x_aa | x_ba], front B: [x_B | x_ab | x_bb]; every layer of the discriminator is per-sample, so the
+        results are those of the separate calls up to the summation order of the weight gradients).  Round 5: the estimate
+        modes call the two on 128 and 16 samples (lsps_trainer.py:238-247) and the 16-sample pass ran ~75 launches of kernels
+        that fill a sixteenth of the chip; riding along in the 128-sample pass costs next to nothing.
+        Returns (post_a, post_b or None, (f_aa, f_ba, f_ab, f_bb))."""
+        na, nb = x_A.size(0), (x_B.size(0) if x_B is not None else 0)
+        k = x_aa.size(0)
+        fa = run_layers(self.model_A, torch.cat((x_A, x_aa, x_ba), 0))
+        fb = run_layers(self.model_B, torch.cat((x_B, x_ab, x_bb), 0) if x_B is not None else torch.cat((x_ab, x_bb), 0))
+        if ops.is_c8(fa) != ops.is_c8(fb):
+            fa, fb = ops.from_c8(fa), ops.from_c8(fb)
+        # batch order in the trunk: regression samples first (A, then B), then the four feature groups
+        parts = (fa[:na], fb[:nb], fa[na:], fb[nb:])
+        t = self._trunk(torch.cat([p for p in parts if p.size(0) > 0], 0))
+        post = self.Post(t[:na + nb])
+        post_a = post[:na].squeeze()
+        post_b = post[na:].squeeze() if nb else None
+        f = t[na + nb:]
+        return post_a, post_b, torch.split(f, k, dim=0)
+
     def feats(self, x_aa, x_ba, x_ab, x_bb):
         f = self._cat0(run_layers(self.model_A, torch.cat((x_aa, x_ba), 0)), run_layers(self.model_B, torch.cat((x_ab, x_bb), 0)))
         f = self._trunk(f)

@@ -515,6 +515,29 @@ class LSPSTrainer(nn.Module):
                     first_a, first_b = first_a.contiguous(), first_b.contiguous()
                     torch.distributed.broadcast(first_a, 0)
                     torch.distributed.broadcast(first_b, 0)
+            if ops.options.get().est_merge:
+                # Round 5: ONE pass of the discriminator over [regression samples | the 16 feature samples] (SharedDis.regress_feats).
+                # The generator pass on the first 4 + 4 samples has no consumer but that pass, so nothing is left to overlap it
+                # with except the host: it runs on the launch stream.  Per-sample identical to the two separate calls; every
+                # discriminator weight gets ONE gradient contribution (data parallel: the reducer's plain learned set).
+                with torch.no_grad():
+                    x_aa, x_ba, x_ab, x_bb = self.gen(first_a, first_b, noise=noise.get('gen'))[:4]
+                post_a, post_b, (f_x_aa, f_x_ba, f_x_ab, f_x_bb) = self.dis.regress_feats(
+                    images_a, images_b if mode == 4 else None, x_aa, x_ba, x_ab, x_bb)
+
+                def reg_term(pred, labels, nz):
+                    with torch.no_grad():                                         # target: noisy vae code (:229,:246)
+                        target, _, _ = self.vae.encode(labels, noise=nz)
+                    return self._compute_l2_loss(pred, target.reshape(pred.shape))
+                reg_loss = reg_term(post_a, labels_a, noise.get('vae_a'))
+                if mode == 4:
+                    reg_loss = reg_loss + reg_term(post_b, labels_b, noise.get('vae_b'))
+                feat_loss = self._compute_ll_loss(f_x_ab, f_x_aa) + self._compute_ll_loss(f_x_ba, f_x_bb)
+                total_loss = hp['reg_w'] * reg_loss + hp['feature_w_reg'] * feat_loss
+                self._step('dis', self.dis_opt, total_loss, ['dis_reg_loss', 'dis_total_loss'], [reg_loss, total_loss],
+                           ('post_update', int(mode), 'merged'))
+                return (x_aa, x_ba, x_ab, x_bb, x_aa, x_bb, x_aa, x_bb)
+            # (est_merge off: the round-4 schedule)
             # The feature branch (generator on 8 samples -> dis.feats on 16) and the regression branch (dis on the whole
             # batch) are independent until the loss is summed, and the first one's launches fill a quarter of the chip at
             # best: it runs on a second HIP stream (forward here, its backward follows it there: autograd replays a node on

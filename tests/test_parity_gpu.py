@@ -475,7 +475,10 @@ def test_post_update_overlapped_branches_match_serial_bitwise(mode, monkeypatch)
     outs = []
     for variant in ('overlap', 'serial', 'graph'):
         from lsps_amd import options
-        monkeypatch.setattr(options, '_current', options.from_env({'LSPS_NO_OVERLAP': '1'} if variant == 'serial' else {}))
+        env = {'LSPS_EST_MERGE': '0'}           # the two-pass schedule of round 4 (round 5's default merges the passes: next test)
+        if variant == 'serial':
+            env['LSPS_NO_OVERLAP'] = '1'
+        monkeypatch.setattr(options, '_current', options.from_env(env))
         tr = A.make_trainer(hp, sds)
         tr.use_graphs(variant == 'graph')
         A.set_train(tr, True)
@@ -490,6 +493,43 @@ def test_post_update_overlapped_branches_match_serial_bitwise(mode, monkeypatch)
         assert o[0] == outs[0][0], (o[0], outs[0][0])
         for k in outs[0][1]:
             assert np.array_equal(o[1][k], outs[0][1][k]), k
+
+
+@pytest.mark.parametrize("mode", [3, 4])
+def test_post_update_merged_discriminator_pass_equals_the_two_pass_schedule(mode, monkeypatch):
+    """Round 5: the estimate modes run `dis.regress_*` (whole batch) and `dis.feats` (16 generator outputs) as ONE pass of the
+    discriminator (SharedDis.regress_feats).  Per sample the arithmetic is that of the separate calls; what changes is the
+    summation order of the weight gradients.  Two steps of the merged schedule (eager and replayed from a hipGraph: bitwise
+    equal) against the two-pass schedule: losses to 1e-5, discriminator weights after the Adam steps to the golden rule."""
+    A = _adapter()
+    from lsps_amd import options
+    hp = cases.hp_for('tiny')
+    sds = cases.make_weights(hp, lsps_ref)
+    b = cases.make_inputs(8)
+    lat, zd = cases.latent_shape(hp, 8), hp['vae']['z_dim']
+    outs = {}
+    for variant in ('two_pass', 'merged', 'merged_graph'):
+        monkeypatch.setattr(options, '_current', options.from_env({'LSPS_EST_MERGE': '0' if variant == 'two_pass' else '1'}))
+        tr = A.make_trainer(hp, sds)
+        tr.use_graphs(variant == 'merged_graph')
+        A.set_train(tr, True)
+        trace = []
+        for rnd in range(3):
+            A.post_update(tr, b, mode, hp, cases.noise(lat, 80 + rnd), cases.noise((8, zd), 81 + rnd, 0.05),
+                          cases.noise((8, zd), 82 + rnd, 0.05))
+            trace.append(A.scalars(tr))
+        outs[variant] = (trace, A.params(tr, 'dis'))
+    assert outs['merged'][0] == outs['merged_graph'][0]
+    for k in outs['merged'][1]:
+        assert np.array_equal(outs['merged'][1][k], outs['merged_graph'][1][k]), k
+    for t_m, t_2 in zip(outs['merged'][0], outs['two_pass'][0]):
+        for k in t_m:
+            assert abs(float(t_m[k]) - float(t_2[k])) <= 1e-5 * max(1.0, abs(float(t_2[k]))), (k, t_m[k], t_2[k])
+    for k in outs['merged'][1]:
+        a, b2 = outs['merged'][1][k], outs['two_pass'][1][k]
+        d = np.abs(a.astype(np.float64) - b2.astype(np.float64))
+        # three Adam steps of lr 1e-4: a weight whose gradient is round-off around 0 may step the other way
+        assert float(d.max()) <= 6.5e-4 and float((d > 1e-6).mean()) <= 0.03, (k, float(d.max()), float((d > 1e-6).mean()))
 
 
 @pytest.mark.parametrize("graphs", [False, True])
