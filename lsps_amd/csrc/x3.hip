@@ -107,6 +107,19 @@ static int x3s2_pack(const float *w, int M, int C, long sm, long sc, int BM, voi
   return 0;
 }
 
+// split-K decision of the forward / transposed kernels: `base` workgroups without a split, `nk` reduction chunks of 16 channels
+static int x3_ksplit(int base, int nk, int *kper) {
+  int ks = 1;
+  const int cus = 256;
+  if (base * 4 <= cus * 3 && nk >= 8) {                          // < 3/4 of one round of workgroups and a reduction worth cutting
+    ks = std::min(8, (cus + base - 1) / base);
+    ks = std::min(ks, nk / 4);
+  }
+  if (ks < 1) ks = 1;
+  *kper = (nk + ks - 1) / ks;
+  return (nk + *kper - 1) / *kper;
+}
+
 // out[c] = sum over `rows` rows of part[rows][C]; `scratch`: 64 * C floats (used when rows > 64)
 static int x3_colsum(const float *part, float *out, int C, int rows, float *scratch, hipStream_t st) {
   if (rows > 64) {
@@ -165,6 +178,34 @@ static int x3s2_run_fwd(const void *big, const float *w, long sm, long sc, const
   p.ActY = (const unsigned short *)act_y;
   p.act_slope = act_slope;
   p.dbpart = nullptr;
+  const size_t pack_bytes = align_up((size_t)M * Cx * 9 * 3 * sizeof(unsigned short), 256);
+  p.ksplit = x3_ksplit((p.ntiles + 7) / 8 * 8 * (M >> 7), Cx >> 4, &p.kper);
+  p.ysplit = 0;
+  if (p.ksplit > 1) {
+    // raw partial outputs [range][N][M][P][Q] behind the packed weights; the epilogue runs in x3_splitk_finish_kernel
+    const long out_elems = (long)N * M * p.P * p.Q;
+    const size_t part_bytes = (size_t)p.ksplit * out_elems * sizeof(float);
+    const int isplits = std::max(1, std::min(N, (1024 + (M >> 3) - 1) / (M >> 3)));
+    const int ips = (N + isplits - 1) / isplits, nis = (N + ips - 1) / ips;
+    const size_t db_bytes = act_y ? ((size_t)nis + 64) * M * sizeof(float) : 0;
+    if (!ws || ws_bytes < pack_bytes + part_bytes + db_bytes + 256) {
+      set_error("x3 stride-2 conv: workspace too small for the split-K partial sums");
+      return LSPS_E_ARG;
+    }
+    float *part = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + pack_bytes);
+    float *dbp = act_y ? reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + pack_bytes + align_up(part_bytes, 256)) : nullptr;
+    X3S2Params q = p;
+    q.bias = nullptr; q.lrelu = 1.f; q.ActY = nullptr; q.Y = part; q.YL = nullptr; q.ysplit = out_elems;
+    const dim3 sgrid(std::min((p.ntiles + 7) / 8 * 8 * (M >> 7) * p.ksplit, x3_device_cus() / 8 * 8));
+    if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_fwd_kernel<false, false>), X3F_LDS_BYTES, "x3s2_fwd")) return rc;
+    hipLaunchKernelGGL((x3s2_fwd_kernel<false, false>), sgrid, dim3(512), X3F_LDS_BYTES, st, q);
+    LSPS_CHECK_LAUNCH("x3s2_fwd(split-K)");
+    hipLaunchKernelGGL(x3_splitk_finish_kernel, dim3(M >> 3, nis), dim3(256), 0, st, (const float *)part, p.ksplit, out_elems, bias, p.lrelu,
+                       (const unsigned short *)act_y, act_slope, y, (unsigned short *)yl, dbp, N, M, p.P * p.Q, ips);
+    LSPS_CHECK_LAUNCH("x3_splitk_finish");
+    if (act_y && db_prev) return x3_colsum(dbp, db_prev, M, nis, dbp + (size_t)nis * M, st);
+    return 0;
+  }
   if (act_y) {
     p.dbpart = x3s2_dbpart(ws, ws_bytes, p.ntiles, M, (size_t)M * Cx * 9 * 3 * sizeof(unsigned short));
     if (!p.dbpart) {
@@ -214,6 +255,33 @@ static int x3s2_run_tr(const void *small, const float *w, long sm, long sc, cons
   p.ActY = (const unsigned short *)act_y;
   p.act_slope = act_slope;
   p.dbpart = nullptr;
+  const size_t pack_bytes = align_up((size_t)M * Cx * 9 * 3 * sizeof(unsigned short), 256);
+  p.ksplit = x3_ksplit((p.ntiles + 7) / 8 * 8 * (M >> 6), Cx >> 4, &p.kper);
+  p.ysplit = 0;
+  if (p.ksplit > 1) {
+    const long out_elems = (long)N * M * H * W;
+    const size_t part_bytes = (size_t)p.ksplit * out_elems * sizeof(float);
+    const int isplits = std::max(1, std::min(N, (1024 + (M >> 3) - 1) / (M >> 3)));
+    const int ips = (N + isplits - 1) / isplits, nis = (N + ips - 1) / ips;
+    const size_t db_bytes = act_y ? ((size_t)nis + 64) * M * sizeof(float) : 0;
+    if (!ws || ws_bytes < pack_bytes + part_bytes + db_bytes + 256) {
+      set_error("x3 stride-2 conv: workspace too small for the split-K partial sums");
+      return LSPS_E_ARG;
+    }
+    float *part = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + pack_bytes);
+    float *dbp = act_y ? reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + pack_bytes + align_up(part_bytes, 256)) : nullptr;
+    X3S2TParams q = p;
+    q.bias = nullptr; q.lrelu = 1.f; q.ActY = nullptr; q.Y = part; q.YL = nullptr; q.ysplit = out_elems;
+    const dim3 sgrid(std::min((p.ntiles + 7) / 8 * 8 * (M >> 6) * p.ksplit, x3_device_cus() / 8 * 8));
+    if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_tr_kernel<false, false>), X3T_LDS_BYTES, "x3s2_tr")) return rc;
+    hipLaunchKernelGGL((x3s2_tr_kernel<false, false>), sgrid, dim3(512), X3T_LDS_BYTES, st, q);
+    LSPS_CHECK_LAUNCH("x3s2_tr(split-K)");
+    hipLaunchKernelGGL(x3_splitk_finish_kernel, dim3(M >> 3, nis), dim3(256), 0, st, (const float *)part, p.ksplit, out_elems, bias, p.lrelu,
+                       (const unsigned short *)act_y, act_slope, y, (unsigned short *)yl, dbp, N, M, H * W, ips);
+    LSPS_CHECK_LAUNCH("x3_splitk_finish");
+    if (act_y && db_prev) return x3_colsum(dbp, db_prev, M, nis, dbp + (size_t)nis * M, st);
+    return 0;
+  }
   if (act_y) {
     p.dbpart = x3s2_dbpart(ws, ws_bytes, p.ntiles, M, (size_t)M * Cx * 9 * 3 * sizeof(unsigned short));
     if (!p.dbpart) {
@@ -301,6 +369,12 @@ size_t lsps_x3_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K) {
   X3S2Params f;
   x3s2_fwd_geom(N, C, H, W, K, &f);                                                   // (as a transposed conv's dgrad: tiles x K)
   need = std::max(need, pack + align_up(((size_t)f.ntiles + 64) * K * sizeof(float), 256) + 512);
+  // split-K partial outputs (<= 8 ranges) + the finish kernel's bias-gradient partial sums (<= 1024 rows)
+  int kper;
+  const int ksf = x3_ksplit((f.ntiles + 7) / 8 * 8 * (K >> 7), C >> 4, &kper);      // forward direction: out [N][K][P][Q]
+  if (ksf > 1) need = std::max(need, pack + align_up((size_t)ksf * N * K * f.P * f.Q * sizeof(float), 256) + ((size_t)N + 64) * K * sizeof(float) + 512);
+  const int kst = x3_ksplit((q.ntiles + 7) / 8 * 8 * (C >> 6), K >> 4, &kper);      // transposed direction: out [N][C][H][W]
+  if (kst > 1) need = std::max(need, pack + align_up((size_t)kst * N * C * H * W * sizeof(float), 256) + ((size_t)N + 64) * C * sizeof(float) + 512);
   X3S2WParams wp;
   x3s2_wgrad_geom(N, K, C, H, W, &wp);
   need = std::max(need, (size_t)wp.splits * 9 * K * C * sizeof(float));

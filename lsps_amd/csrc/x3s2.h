@@ -112,6 +112,11 @@ struct X3S2Params {
   const unsigned short *ActY;
   float act_slope;
   float *dbpart;
+  // split-K (few tiles, long reductions: the deep discriminator layers at estimate-mode batch sizes): the 16-channel chunks are cut
+  // into `ksplit` ranges of `kper` chunks, each (tile, range) is a workgroup that stores its RAW f32 accumulators (no bias /
+  // activation / mask: bias = null, lrelu = 1) at Y + range * ysplit; x3_splitk_finish_kernel sums the ranges and applies the epilogue
+  int ksplit, kper;
+  long ysplit;
 };
 
 #define X3F_BP 10                                          // image pieces (64 units) per limb and stage: <= 640 units
@@ -132,13 +137,13 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
   typedef unsigned long long u64;
 
   // persistent workgroups as in c8s2_fwd_kernel: tiles lin = blockIdx.x, + grid, ...; lin -> (pixel tile, m tile)
-  const int MT = p.M >> 7, G = gridDim.x, nlin = ((p.ntiles + 7) >> 3) * 8 * MT;
+  const int MT = p.M >> 7, KS = p.ksplit, G = gridDim.x, nlin = ((p.ntiles + 7) >> 3) * 8 * MT * KS;
   const int TI = p.TI, TR = p.TR, Q = p.Q;
   const int CB = 2 * Q + 1, blk = TR * CB, plane = TI * blk, bunits = 2 * plane;
   const int W16 = p.W * 16, HW16 = p.H * W16, img_bytes = (p.Cx >> 3) * HW16, nch = p.Cx >> 4;
   const int PQ = p.P * Q, tpi = TR * Q;
 
-  int mt, ptile, n0, p0, nimg;                                  // the tile whose DMA set-up is current
+  int mt, ptile, n0, p0, nimg, kc0, kc1, ksp;                   // the tile whose DMA set-up is current (chunks kc0 .. kc1 - 1)
   __amdgpu_buffer_rsrc_t xrs, wrs;                              // image piece wave + 8 i belongs to limb (wave + 8 i) / 9
   unsigned voffb[4], voffa[5];
   int pimg[4], prow[4];
@@ -163,14 +168,17 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
 #pragma unroll
   for (int i = 0; i < 5; ++i) voffa[i] = (unsigned)(((wave + 8 * i) * 64 + lane) * 16);
 
-  auto decode = [&](int lin, int &mt_, int &ptile_) {
+  auto decode = [&](int lin, int &mt_, int &ptile_) {                // mt_ carries (m tile, k range): mt + MT * range
     const int xcd = lin & 7, qq = lin >> 3;
-    mt_ = qq % MT;
-    ptile_ = xcd + 8 * (qq / MT);
+    mt_ = qq % (MT * KS);
+    ptile_ = xcd + 8 * (qq / (MT * KS));
     return lin < nlin && ptile_ < p.ntiles;
   };
   auto setup = [&](int mt_, int ptile_) {
-    mt = mt_; ptile = ptile_;
+    ksp = mt_ / MT;
+    mt = mt_ - ksp * MT; ptile = ptile_;
+    kc0 = ksp * p.kper;
+    kc1 = min(nch, kc0 + p.kper);
     if (TI == 1) {
       n0 = ptile / p.tiles_per_img;
       p0 = (ptile - n0 * p.tiles_per_img) * TR;
@@ -226,14 +234,14 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
     if (!decode(lin, m_, t_)) return;
     setup(m_, t_);
   }
-  issue(0, 0, 0);
+  issue(kc0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   while (true) {
-    const int mt_c = mt, ptile_c = ptile;
+    const int mt_c = mt, ptile_c = ptile, kb = kc0, ke = kc1;
     const bool yvalid = yil < nimg;
-    const long ypix = (long)(n0 + yil) * p.M * PQ + (long)(p0 + ypl) * Q + yql;          // f32 NCHW: + channel * PQ
+    const long ypix = (long)ksp * p.ysplit + (long)(n0 + yil) * p.M * PQ + (long)(p0 + ypl) * Q + yql;   // f32 NCHW: + channel * PQ
     const long yunit = (long)(n0 + yil) * 3 * (p.M >> 3) * PQ + (long)(p0 + ypl) * Q + yql;  // X3: + (limb * M/8 + channel group) * PQ
     int mt_n, ptile_n;
     const bool more = decode(lin + G, mt_n, ptile_n);
@@ -244,16 +252,16 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    for (int ch = 0; ch < nch; ++ch) {
+    for (int ch = kb; ch < ke; ++ch) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         if (r < 2) {
           issue(ch, r + 1, buf ^ 1);
-        } else if (ch + 1 < nch) {
+        } else if (ch + 1 < ke) {
           issue(ch + 1, 0, buf ^ 1);
         } else if (more) {
           setup(mt_n, ptile_n);
-          issue(0, 0, buf ^ 1);
+          issue(kc0, 0, buf ^ 1);
         }
         const unsigned char *S = x3_lds + buf * X3F_STAGE;
 #pragma unroll
@@ -374,6 +382,8 @@ struct X3S2TParams {
   const unsigned short *ActY;    // MASKED: X3 saved output of the previous layer (Y's shape); only its hi limb is read
   float act_slope;
   float *dbpart;                 // MASKED: [ntiles][M]
+  int ksplit, kper;              // split-K as in X3S2Params (k-steps of 16 channels); raw f32 accumulators at Y + range * ysplit
+  long ysplit;
 };
 
 // Wq[m tile of 64][k-step of 16 c][tap row r][limb][tap column s][k-half][64 m][8 c]
@@ -419,27 +429,30 @@ __global__ __launch_bounds__(512, 1) void x3s2_tr_kernel(X3S2TParams p) {
   const int wm = wave & 1, wp = wave >> 1;
   typedef unsigned long long u64;
 
-  const int MT = p.M >> 6, G = gridDim.x, nlin = ((p.ntiles + 7) >> 3) * 8 * MT;
+  const int MT = p.M >> 6, KS = p.ksplit, G = gridDim.x, nlin = ((p.ntiles + 7) >> 3) * 8 * MT * KS;
   const int TI = p.TI, TR = p.TR, Q = p.Q;
   const int CB = Q + 1, blk = TR * CB, plane = TI * blk, bunits = 2 * plane;
   const int Q16 = Q * 16, PQ16 = p.P * Q16, img_bytes = (p.Cx >> 3) * PQ16, nks = p.Cx >> 4;
   const long HWl = (long)p.H * p.W;
 
-  int mt, ptile, n0, p0, nimg;
+  int mt, ptile, n0, p0, nimg, kc0, kc1, ksp;
   __amdgpu_buffer_rsrc_t xrs, wrs;
   constexpr int NB = (X3T_BPIECES + 7) / 8, NA = (X3T_APIECES + 7) / 8;      // 5, 3
   unsigned voffb[NB];                                           // source offset for the un-shifted rows (r = 1, 2), or X3_OOB
   unsigned lastrow = 0;                                         // bit i: piece i's unit is in small row P - 1 (dead under r = 0)
   const unsigned voffa = (unsigned)((wave * 64 + lane) * 16);
 
-  auto decode = [&](int lin, int &mt_, int &ptile_) {
+  auto decode = [&](int lin, int &mt_, int &ptile_) {                // mt_ carries (m tile, k range): mt + MT * range
     const int xcd = lin & 7, qq = lin >> 3;
-    mt_ = qq % MT;
-    ptile_ = xcd + 8 * (qq / MT);
+    mt_ = qq % (MT * KS);
+    ptile_ = xcd + 8 * (qq / (MT * KS));
     return lin < nlin && ptile_ < p.ntiles;
   };
   auto setup = [&](int mt_, int ptile_) {
-    mt = mt_; ptile = ptile_;
+    ksp = mt_ / MT;
+    mt = mt_ - ksp * MT; ptile = ptile_;
+    kc0 = ksp * p.kper;
+    kc1 = min(nks, kc0 + p.kper);
     if (TI == 1) {
       n0 = ptile / p.tiles_per_img;
       p0 = (ptile - n0 * p.tiles_per_img) * TR;
@@ -510,12 +523,13 @@ __global__ __launch_bounds__(512, 1) void x3s2_tr_kernel(X3S2TParams p) {
     if (!decode(lin, m_, t_)) return;
     setup(m_, t_);
   }
-  issue(0, 0, 0);
+  issue(kc0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   while (true) {
-    const int mt_c = mt, ptile_c = ptile;
+    const int mt_c = mt, ptile_c = ptile, kb = kc0, ke = kc1;
+    float *const Ysp = p.Y + (long)ksp * p.ysplit;               // split-K: this range's raw partial output
     long ypix[2];                                                // pixel index of (n, row 2p, column 2q) in an H x W plane set, or -1
     int yn[2];
 #pragma unroll
@@ -535,16 +549,16 @@ __global__ __launch_bounds__(512, 1) void x3s2_tr_kernel(X3S2TParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
 
-    for (int ks = 0; ks < nks; ++ks) {
+    for (int ks = kb; ks < ke; ++ks) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         if (r < 2) {
           issue(ks, r + 1, buf ^ 1);
-        } else if (ks + 1 < nks) {
+        } else if (ks + 1 < ke) {
           issue(ks + 1, 0, buf ^ 1);
         } else if (more) {
           setup(mt_n, ptile_n);
-          issue(0, 0, buf ^ 1);
+          issue(kc0, 0, buf ^ 1);
         }
         const unsigned char *S = x3_lds + buf * X3T_STAGE;
         bf16x8 bf[2][2][3];                                      // [column shift][j][limb]
@@ -611,7 +625,7 @@ __global__ __launch_bounds__(512, 1) void x3s2_tr_kernel(X3S2TParams p) {
             // f32 NCHW: a lane's (b = 0, 1) pair of one channel is 8 contiguous bytes; 32 lanes = 256 contiguous bytes
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              float *dst = p.Y + ((long)yn[j] * p.M + m8 + 4 * half + e) * HWl + ypix[j] + (long)a * p.W;
+              float *dst = Ysp + ((long)yn[j] * p.M + m8 + 4 * half + e) * HWl + ypix[j] + (long)a * p.W;
               *reinterpret_cast<f32x2 *>(dst) = f32x2{v[0][e], v[1][e]};
             }
           } else {
@@ -917,6 +931,70 @@ __global__ __launch_bounds__(256) void x3_act_bwd_bias_nchw_kernel(const float *
   }
   __syncthreads();
   if (tid < 8 && dbpart) dbpart[(long)split * C + cg * 8 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Epilogue of a split-K launch (x3s2_fwd_kernel / x3s2_tr_kernel with ksplit > 1): v = sum of the `ns` raw partial outputs
+// part[s][N][C][HW] (f32) + bias, LeakyReLU (lrelu: max(v, v * lrelu)), optionally the fused mask of the layer in front
+// (v *= LeakyReLU'(ActY), ActY = hi limb of that layer's X3 output, + its bias-gradient partial sums), written as f32 NCHW (y) or
+// as limbs (yl).  grid = (C / 8, splits over images).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void x3_splitk_finish_kernel(const float *__restrict__ part, int ns, long sstride,
+                                                               const float *__restrict__ bias, float lrelu,
+                                                               const unsigned short *__restrict__ act_y, float act_slope,
+                                                               float *__restrict__ y, unsigned short *__restrict__ yl, float *__restrict__ dbpart,
+                                                               int N, int C, int HW, int imgs_per_split) {
+  __shared__ float red[4][8];
+  const int cg = blockIdx.x, split = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = split * imgs_per_split, n1 = min(N, n0 + imgs_per_split);
+  const long cgs = C >> 3, ls = cgs * HW * 8;
+  float s[8], b8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    s[e] = 0.f;
+    b8[e] = bias ? bias[cg * 8 + e] : 0.f;
+  }
+  for (int n = n0; n < n1; ++n) {
+    const float *pp = part + ((long)n * C + cg * 8) * HW;
+    const long ubase = ((long)n * 3 * cgs + cg) * HW;            // unit index of (n, limb 0, cg, pixel 0)
+    for (int u = tid; u < HW; u += 256) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = b8[e];
+        for (int k = 0; k < ns; ++k) a += pp[(long)k * sstride + (long)e * HW + u];
+        v[e] = fmaxf(a, a * lrelu);
+      }
+      if (act_y) {
+        const bf16x8 mk = *reinterpret_cast<const bf16x8 *>(act_y + (ubase + u) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = c8_sel_nonpos((float)mk[e], v[e] * act_slope, v[e]);
+          s[e] += v[e];
+        }
+      }
+      if (y) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[((long)n * C + cg * 8 + e) * HW + u] = v[e];
+      }
+      if (yl) {
+        bf16x8 h, m, l;
+        split3(v, h, m, l);
+        unsigned short *gp = yl + (ubase + u) * 8;
+        *reinterpret_cast<bf16x8 *>(gp) = h;
+        *reinterpret_cast<bf16x8 *>(gp + ls) = m;
+        *reinterpret_cast<bf16x8 *>(gp + 2 * ls) = l;
+      }
+    }
+  }
+  if (!dbpart) return;                                            // uniform
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    s[e] = wave_sum(s[e]);
+    if (lane == 0) red[wave][e] = s[e];
+  }
+  __syncthreads();
+  if (tid < 8) dbpart[(long)split * C + cg * 8 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
 }  // namespace lsps

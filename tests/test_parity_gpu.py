@@ -55,7 +55,7 @@ def test_full_steps_match_reference_golden_per_conv_algorithm(mode, golden, monk
     from lsps_amd import ops
     prev = ops.get_winograd()
     ops.set_winograd(mode if mode != 'x3' else 'auto')
-    env = {'LSPS_X3_MIN_GMAC': '0'} if mode == 'x3' else {'LSPS_CHWN_MIN_N': '1' if mode == 'always' else '1000000'}
+    env = {'LSPS_X3_MIN_GMAC': '0'} if mode == 'x3' else {'LSPS_CHWN_MIN_N': '1' if mode == 'always' else '1000000', 'LSPS_X3': '0'}
     monkeypatch.setattr(ops.options, '_current', ops.options.from_env(env))
     ops.kernel_log_begin()
     try:
