@@ -107,13 +107,17 @@ static int x3s2_pack(const float *w, int M, int C, long sm, long sc, int BM, voi
   return 0;
 }
 
-// split-K decision of the forward / transposed kernels: `base` workgroups without a split, `nk` reduction chunks of 16 channels
+// split-K decision of the forward / transposed kernels: `base` real workgroups (tiles x m tiles) without a split, `nk` reduction
+// chunks of 16 channels
 static int x3_ksplit(int base, int nk, int *kper) {
   int ks = 1;
   const int cus = 256;
-  if (base * 4 <= cus * 3 && nk >= 8) {                          // < 3/4 of one round of workgroups and a reduction worth cutting
+  // fewer than 3/4 of one round of workgroups AND a long reduction (>= 512 channels: the deep discriminator layers, whose
+  // outputs are small); on the generator's layers (<= 256 channels, large maps) the partial outputs cost more than the idle CUs
+  // (measured: the 8-sample transposed convs of the estimate modes 76 -> 140 us with a 4-way split)
+  if (base * 4 <= cus * 3 && nk >= 32) {
     ks = std::min(8, (cus + base - 1) / base);
-    ks = std::min(ks, nk / 4);
+    ks = std::min(ks, nk / 8);
   }
   if (ks < 1) ks = 1;
   *kper = (nk + ks - 1) / ks;
@@ -179,7 +183,7 @@ static int x3s2_run_fwd(const void *big, const float *w, long sm, long sc, const
   p.act_slope = act_slope;
   p.dbpart = nullptr;
   const size_t pack_bytes = align_up((size_t)M * Cx * 9 * 3 * sizeof(unsigned short), 256);
-  p.ksplit = x3_ksplit((p.ntiles + 7) / 8 * 8 * (M >> 7), Cx >> 4, &p.kper);
+  p.ksplit = x3_ksplit(p.ntiles * (M >> 7), Cx >> 4, &p.kper);
   p.ysplit = 0;
   if (p.ksplit > 1) {
     // raw partial outputs [range][N][M][P][Q] behind the packed weights; the epilogue runs in x3_splitk_finish_kernel
@@ -256,7 +260,7 @@ static int x3s2_run_tr(const void *small, const float *w, long sm, long sc, cons
   p.act_slope = act_slope;
   p.dbpart = nullptr;
   const size_t pack_bytes = align_up((size_t)M * Cx * 9 * 3 * sizeof(unsigned short), 256);
-  p.ksplit = x3_ksplit((p.ntiles + 7) / 8 * 8 * (M >> 6), Cx >> 4, &p.kper);
+  p.ksplit = x3_ksplit(p.ntiles * (M >> 6), Cx >> 4, &p.kper);
   p.ysplit = 0;
   if (p.ksplit > 1) {
     const long out_elems = (long)N * M * H * W;
@@ -371,9 +375,9 @@ size_t lsps_x3_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K) {
   need = std::max(need, pack + align_up(((size_t)f.ntiles + 64) * K * sizeof(float), 256) + 512);
   // split-K partial outputs (<= 8 ranges) + the finish kernel's bias-gradient partial sums (<= 1024 rows)
   int kper;
-  const int ksf = x3_ksplit((f.ntiles + 7) / 8 * 8 * (K >> 7), C >> 4, &kper);      // forward direction: out [N][K][P][Q]
+  const int ksf = x3_ksplit(f.ntiles * (K >> 7), C >> 4, &kper);      // forward direction: out [N][K][P][Q]
   if (ksf > 1) need = std::max(need, pack + align_up((size_t)ksf * N * K * f.P * f.Q * sizeof(float), 256) + ((size_t)N + 64) * K * sizeof(float) + 512);
-  const int kst = x3_ksplit((q.ntiles + 7) / 8 * 8 * (C >> 6), K >> 4, &kper);      // transposed direction: out [N][C][H][W]
+  const int kst = x3_ksplit(q.ntiles * (C >> 6), K >> 4, &kper);      // transposed direction: out [N][C][H][W]
   if (kst > 1) need = std::max(need, pack + align_up((size_t)kst * N * C * H * W * sizeof(float), 256) + ((size_t)N + 64) * C * sizeof(float) + 512);
   X3S2WParams wp;
   x3s2_wgrad_geom(N, K, C, H, W, &wp);

@@ -906,23 +906,24 @@ __global__ __launch_bounds__(256) void x3_act_bwd_bias_nchw_kernel(const float *
   float s[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = 0.f;
-  for (int n = n0; n < n1; ++n) {
+  // (image, pixel) pairs of the split flattened: small maps (2x2 ... 8x8 at the end of the discriminator) keep every thread busy
+  const long items = (long)(n1 - n0) * HW;
+  for (long it = tid; it < items; it += 256) {
+    const int n = n0 + (int)(it / HW), u = (int)(it - (long)(n - n0) * HW);
     const float *dyp = dy + ((long)n * C + cg * 8) * HW, *yp = y + ((long)n * C + cg * 8) * HW;
     unsigned short *gp = g + ((long)n * 3 * cgs + cg) * HW * 8;
-    for (int u = tid; u < HW; u += 256) {
-      float v[8];
+    float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = dyp[(long)e * HW + u];
-        v[e] = slope < 0.f ? d : c8_sel_nonpos(yp[(long)e * HW + u], d * slope, d);
-        s[e] += v[e];
-      }
-      bf16x8 h, m, l;
-      split3(v, h, m, l);
-      *reinterpret_cast<bf16x8 *>(gp + (long)u * 8) = h;
-      *reinterpret_cast<bf16x8 *>(gp + ls + (long)u * 8) = m;
-      *reinterpret_cast<bf16x8 *>(gp + 2 * ls + (long)u * 8) = l;
+    for (int e = 0; e < 8; ++e) {
+      const float d = dyp[(long)e * HW + u];
+      v[e] = slope < 0.f ? d : c8_sel_nonpos(yp[(long)e * HW + u], d * slope, d);
+      s[e] += v[e];
     }
+    bf16x8 h, m, l;
+    split3(v, h, m, l);
+    *reinterpret_cast<bf16x8 *>(gp + (long)u * 8) = h;
+    *reinterpret_cast<bf16x8 *>(gp + ls + (long)u * 8) = m;
+    *reinterpret_cast<bf16x8 *>(gp + 2 * ls + (long)u * 8) = l;
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -954,37 +955,37 @@ __global__ __launch_bounds__(256) void x3_splitk_finish_kernel(const float *__re
     s[e] = 0.f;
     b8[e] = bias ? bias[cg * 8 + e] : 0.f;
   }
-  for (int n = n0; n < n1; ++n) {
+  const long items = (long)(n1 - n0) * HW;                       // (image, pixel) pairs flattened: small maps keep every thread busy
+  for (long it = tid; it < items; it += 256) {
+    const int n = n0 + (int)(it / HW), u = (int)(it - (long)(n - n0) * HW);
     const float *pp = part + ((long)n * C + cg * 8) * HW;
     const long ubase = ((long)n * 3 * cgs + cg) * HW;            // unit index of (n, limb 0, cg, pixel 0)
-    for (int u = tid; u < HW; u += 256) {
-      float v[8];
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = b8[e];
+      for (int k = 0; k < ns; ++k) a += pp[(long)k * sstride + (long)e * HW + u];
+      v[e] = fmaxf(a, a * lrelu);
+    }
+    if (act_y) {
+      const bf16x8 mk = *reinterpret_cast<const bf16x8 *>(act_y + (ubase + u) * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float a = b8[e];
-        for (int k = 0; k < ns; ++k) a += pp[(long)k * sstride + (long)e * HW + u];
-        v[e] = fmaxf(a, a * lrelu);
+        v[e] = c8_sel_nonpos((float)mk[e], v[e] * act_slope, v[e]);
+        s[e] += v[e];
       }
-      if (act_y) {
-        const bf16x8 mk = *reinterpret_cast<const bf16x8 *>(act_y + (ubase + u) * 8);
+    }
+    if (y) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] = c8_sel_nonpos((float)mk[e], v[e] * act_slope, v[e]);
-          s[e] += v[e];
-        }
-      }
-      if (y) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[((long)n * C + cg * 8 + e) * HW + u] = v[e];
-      }
-      if (yl) {
-        bf16x8 h, m, l;
-        split3(v, h, m, l);
-        unsigned short *gp = yl + (ubase + u) * 8;
-        *reinterpret_cast<bf16x8 *>(gp) = h;
-        *reinterpret_cast<bf16x8 *>(gp + ls) = m;
-        *reinterpret_cast<bf16x8 *>(gp + 2 * ls) = l;
-      }
+      for (int e = 0; e < 8; ++e) y[((long)n * C + cg * 8 + e) * HW + u] = v[e];
+    }
+    if (yl) {
+      bf16x8 h, m, l;
+      split3(v, h, m, l);
+      unsigned short *gp = yl + (ubase + u) * 8;
+      *reinterpret_cast<bf16x8 *>(gp) = h;
+      *reinterpret_cast<bf16x8 *>(gp + ls) = m;
+      *reinterpret_cast<bf16x8 *>(gp + 2 * ls) = l;
     }
   }
   if (!dbpart) return;                                            // uniform

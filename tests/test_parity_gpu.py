@@ -81,14 +81,15 @@ def test_n16_full_width_default_dispatch_against_the_oracle(monkeypatch):
     abs-max, gradients through the robust criteria of cases.compare; the kernel log must show the F(4x4,3x3) forward / dgrad and
     weight-gradient kernels, the stride-2 family (three-limb kernels where the work threshold routes to them, the exact-f32
     ones elsewhere) and the batch-innermost trunk (its batch threshold is lowered to this batch: the 16- and 32-image passes
-    of post_update / gen_update; dis_update's 96-image pass is above the three-limb family's work threshold)."""
+    of post_update / gen_update; dis_update's 96-image pass is above the three-limb family's work threshold, set to 4 x 10^9
+    multiply-adds here so that all of these families appear at this batch)."""
     A = _adapter()
     from lsps_amd import ops
     import os
     torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
     O = cases.NativeAdapter(lsps_ref, 'cpu')
     gold = cases.flatten(cases.run_n16_cases(O, lsps_ref))
-    monkeypatch.setattr(ops.options, '_current', ops.options.from_env({'LSPS_CHWN_MIN_N': '16'}))
+    monkeypatch.setattr(ops.options, '_current', ops.options.from_env({'LSPS_CHWN_MIN_N': '16', 'LSPS_X3_MIN_GMAC': '4'}))
     ops.kernel_log_begin()
     try:
         R = cases.run_n16_cases(A, lsps_ref)
