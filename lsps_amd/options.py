@@ -38,7 +38,7 @@ class Options:
     c8: bool = True                    # LSPS_C8=0: bf16 mode without the C8 layout
     c8s2: bool = True                  # LSPS_C8S2=0: bf16 mode without the C8 stride-2 family
     x3: bool = True                    # LSPS_X3=0: f32 mode without the three-limb stride-2 family (csrc/x3s2.h)
-    x3_min_gmac: float = 2.0           # LSPS_X3_MIN_GMAC: smallest layer (10^9 multiply-adds per launch) routed to it
+    x3_min_gmac: float = 1.0           # LSPS_X3_MIN_GMAC: smallest layer (10^9 multiply-adds per launch) routed to it
     force_dp: bool = False             # LSPS_FORCE_DP=1: gradient exchange also in a 1-rank group
     dp_graphs: bool = True             # LSPS_DP_GRAPHS=0: data-parallel steps never captured
     bucket_bytes: int = DEFAULT_BUCKET_BYTES   # LSPS_BUCKET_BYTES
@@ -64,7 +64,7 @@ def from_env(env=None):
         side_prio=int(e.get('LSPS_SIDE_PRIO', '0')), pack_cache=not on('LSPS_NO_PACK_CACHE'),
         frozen_packs=not on('LSPS_NO_FROZEN_PACKS'), est_split_backward=off('LSPS_EST_SPLIT_BACKWARD'),
         est_order=e.get('LSPS_EST_ORDER', 'feat_first'), est_merge=off('LSPS_EST_MERGE'), fuse_act=off('LSPS_FUSE_ACT'), c8_fuse_act=off('LSPS_C8_FUSE_ACT'),
-        c8=off('LSPS_C8'), c8s2=off('LSPS_C8S2'), x3=off('LSPS_X3'), x3_min_gmac=float(e.get('LSPS_X3_MIN_GMAC', '2.0')), force_dp=on('LSPS_FORCE_DP'), dp_graphs=off('LSPS_DP_GRAPHS'),
+        c8=off('LSPS_C8'), c8s2=off('LSPS_C8S2'), x3=off('LSPS_X3'), x3_min_gmac=float(e.get('LSPS_X3_MIN_GMAC', '1.0')), force_dp=on('LSPS_FORCE_DP'), dp_graphs=off('LSPS_DP_GRAPHS'),
         bucket_bytes=int(e.get('LSPS_BUCKET_BYTES', DEFAULT_BUCKET_BYTES)),
         native=tuple((k, e[k]) for k in _NATIVE if k in e))
 
