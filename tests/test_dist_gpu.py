@@ -260,13 +260,14 @@ def test_two_rank_hip_trainer_matches_reference_golden_and_overlaps(golden):
 # estimate modes' side stream under data parallelism.  One rank on RCCL (LSPS_FORCE_DP=1): RCCL refuses two ranks on one
 # device, so this pins the capture / replay machinery and its bookkeeping, not a transfer.
 # ---------------------------------------------------------------------------------------------------------------
-def _dp_graph_worker(port, out, trace_buf='2000'):
+def _dp_graph_worker(port, out, trace_buf='2000', est_merge='1'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
     os.environ['LSPS_FORCE_DP'] = '1'
     os.environ['LSPS_BUCKET_BYTES'] = str(1 << 16)
     os.environ['TORCH_NCCL_TRACE_BUFFER_SIZE'] = os.environ['TORCH_FR_BUFFER_SIZE'] = trace_buf   # dist.drain_watchdog ('0': off)
+    os.environ['LSPS_EST_MERGE'] = est_merge              # '0': the two-pass estimate schedule with its side stream (round 4)
     from lsps_amd import options
     options.reload_env()
     torch.cuda.set_device(0)
@@ -306,8 +307,8 @@ def _dp_graph_worker(port, out, trace_buf='2000'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("trace_buf", ["2000", "0"])
-def test_data_parallel_steps_replay_from_hip_graphs_bitwise(trace_buf):
+@pytest.mark.parametrize("trace_buf,est_merge", [("2000", "1"), ("2000", "0"), ("0", "1")])
+def test_data_parallel_steps_replay_from_hip_graphs_bitwise(trace_buf, est_merge):
     """trace_buf '2000': RCCL's flight recorder is on, dist.drain_watchdog CONFIRMS that the watchdog holds no eager work
     and the three update steps are captured and replayed, bitwise equal to eager.  '0' (torch's default): the drain cannot
     be confirmed, so the steps must stay eager (no capture beside a polling watchdog, no abort) — same results."""
@@ -315,7 +316,7 @@ def test_data_parallel_steps_replay_from_hip_graphs_bitwise(trace_buf):
         pytest.skip("no HIP device")
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
-    p = ctx.Process(target=_dp_graph_worker, args=(_free_port(), out, trace_buf))
+    p = ctx.Process(target=_dp_graph_worker, args=(_free_port(), out, trace_buf, est_merge))
     p.start()
     got = out.get(timeout=900)
     p.join(timeout=120)
@@ -323,7 +324,8 @@ def test_data_parallel_steps_replay_from_hip_graphs_bitwise(trace_buf):
     assert p.exitcode == 0
     eager, graphed = got
     assert graphed['n_graphs'] == (3 if trace_buf != '0' else 0) and eager['n_graphs'] == 0
-    assert eager['side'] and graphed['side'], "the estimate modes' side stream must also run under data parallelism"
+    # the two-pass estimate schedule (est_merge '0') keeps its side stream under data parallelism; the merged pass has none
+    assert eager['side'] == graphed['side'] == (est_merge == '0'), "the estimate modes' side stream must also run under data parallelism"
     assert eager['trace'] == graphed['trace'], (eager['trace'], graphed['trace'])
     for net in ('gen', 'dis'):
         for k in eager[net]:
