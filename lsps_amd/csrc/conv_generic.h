@@ -580,11 +580,45 @@ __global__ __launch_bounds__(256) void pw1_dgrad_act_kernel(const float *__restr
   for (int q = q0 + tid; q < q1; q += 256) {
     const f32x4 g = gp[q];
     sd += (g[0] + g[1]) + (g[2] + g[3]);
+    if (X3OUT) {
+      // one channel group (8 channels x this lane's 4 pixels) at a time: 8 loads in flight, then 12 stores of 16 bytes; the 16
+      // channels of the slice at once need 233 registers (one wave per SIMD: 0.53 ms against the f32 form's 0.30)
+      const long cgs = C >> 3, HW = (long)HW4 * 4, ls = cgs * HW * 8;
+#pragma unroll
+      for (int grp = 0; grp < PW1_CS / 8; ++grp) {
+        f32x4 yv[8], oo[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) yv[k] = yp[(long)(grp * 8 + k) * HW4 + q];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int c = grp * 8 + k;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = wv[c] * g[e];
+            oo[k][e] = yv[k][e] > 0.f ? v : v * slope;
+          }
+          s[c] += (oo[k][0] + oo[k][1]) + (oo[k][2] + oo[k][3]);
+          sw[c] += (yv[k][0] * g[0] + yv[k][1] * g[1]) + (yv[k][2] * g[2] + yv[k][3] * g[3]);
+        }
+        unsigned short *base = reinterpret_cast<unsigned short *>(dx) + (((long)n * 3 * cgs + ((c0 >> 3) + grp)) * HW + (long)q * 4) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v8[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v8[k] = oo[k][e];
+          bf16x8 h, m, l;
+          split3(v8, h, m, l);
+          *reinterpret_cast<bf16x8 *>(base + e * 8) = h;
+          *reinterpret_cast<bf16x8 *>(base + ls + e * 8) = m;
+          *reinterpret_cast<bf16x8 *>(base + 2 * ls + e * 8) = l;
+        }
+      }
+      continue;
+    }
     f32x4 yv[PW1_CS];
 #pragma unroll
     for (int c = 0; c < PW1_CS; ++c)                   // all loads of the slice in flight before the first store
       yv[c] = yp[(long)(c < nc ? c : 0) * HW4 + q];    // (channels beyond C: a duplicate load, never stored)
-    f32x4 oo[8];                                         // X3OUT: the 8 channels of a group x 4 pixels, split when the group is complete
 #pragma unroll
     for (int c = 0; c < PW1_CS; ++c) {
       if (c < nc) {
@@ -594,29 +628,9 @@ __global__ __launch_bounds__(256) void pw1_dgrad_act_kernel(const float *__restr
         const float v = wv[c] * g[e];
         o[e] = yv[c][e] > 0.f ? v : v * slope;
       }
-      if (!X3OUT) xp[(long)c * HW4 + q] = o;
+      xp[(long)c * HW4 + q] = o;
       s[c] += (o[0] + o[1]) + (o[2] + o[3]);
       sw[c] += (yv[c][0] * g[0] + yv[c][1] * g[1]) + (yv[c][2] * g[2] + yv[c][3] * g[3]);
-      if (X3OUT) {
-        oo[c & 7] = o;
-        if ((c & 7) == 7) {
-          // units of (image n, limb l, channel group cg, pixel 4 q + e): 16 bytes each, the quad's four pixels contiguous
-          const long cgs = C >> 3, cg = (c0 + c) >> 3, HW = (long)HW4 * 4;
-          unsigned short *base = reinterpret_cast<unsigned short *>(dx) + (((long)n * 3 * cgs + cg) * HW + (long)q * 4) * 8;
-          const long ls = cgs * HW * 8;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v8[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v8[k] = oo[k][e];
-            bf16x8 h, m, l;
-            split3(v8, h, m, l);
-            *reinterpret_cast<bf16x8 *>(base + e * 8) = h;
-            *reinterpret_cast<bf16x8 *>(base + ls + e * 8) = m;
-            *reinterpret_cast<bf16x8 *>(base + 2 * ls + e * 8) = l;
-          }
-        }
-      }
       }
     }
   }

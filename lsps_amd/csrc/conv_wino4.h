@@ -128,6 +128,12 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = wave & 3, wt = wave >> 2;
   const int l31 = lane & 31, half = lane >> 5, tr = l31 >> 3, tc = l31 & 7;
+#ifdef W4_PRIO_YOUNG           // experiment (MI355X_MICROARCH.md, two waves per SIMD): static priority for the second-dispatched half
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef W4_PRIO_OLD
+  if (wave < 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
   // workgroup -> (image, k slice).  Workgroups go to the 8 XCDs round-robin in launch order; each XCD has its own 4 MB
   // L2 and a 32-channel slice of U is 1.18 MB (256 input channels): an XCD works on TWO slices (resident in its L2) and

@@ -73,6 +73,12 @@ __global__ __launch_bounds__(KH == 2 ? 256 : 512, KH == 2 ? 1 : 2) void wino4_w3
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef W4_PRIO_YOUNG
+  if (KH == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef W4_PRIO_OLD
+  if (KH == 1 && wave < 4) __builtin_amdgcn_s_setprio(1);
+#endif
   const int l31 = lane & 31, half = lane >> 5;
   const int wp = wave & 3, kh0 = KH == 1 ? wave >> 2 : 0;
   // XCD-aware mapping (workgroups go to the 8 XCDs round-robin in launch order): all (k, c) blocks of one split of the
