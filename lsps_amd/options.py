@@ -25,7 +25,6 @@ _NATIVE = ('LSPS_WINO', 'LSPS_WINO4_SPLIT', 'LSPS_FS2_CC', 'LSPS_WINO4W', 'LSPS_
 class Options:
     chwn: bool = True                  # LSPS_CHWN=0: discriminator trunk stays NCHW (csrc/chwn.hip off)
     chwn_min_n: int = 96               # LSPS_CHWN_MIN_N: smallest batch that takes the batch-innermost trunk
-    chwn_small: bool = True            # LSPS_CHWN_SMALL=0: no small-batch (16 ... 95 samples) variant of that trunk
     overlap: bool = True               # LSPS_NO_OVERLAP=1: estimate modes on one stream
     side_prio: int = 0                 # LSPS_SIDE_PRIO: priority of the side stream
     pack_cache: bool = True            # LSPS_NO_PACK_CACHE=1: pack weights per call
@@ -59,7 +58,7 @@ def from_env(env=None):
     def on(name):                       # default off, "1" switches on
         return e.get(name) == '1'
     return Options(
-        chwn=off('LSPS_CHWN'), chwn_min_n=int(e.get('LSPS_CHWN_MIN_N', '96')), chwn_small=off('LSPS_CHWN_SMALL'),
+        chwn=off('LSPS_CHWN'), chwn_min_n=int(e.get('LSPS_CHWN_MIN_N', '96')),
         overlap=not on('LSPS_NO_OVERLAP'),
         side_prio=int(e.get('LSPS_SIDE_PRIO', '0')), pack_cache=not on('LSPS_NO_PACK_CACHE'),
         frozen_packs=not on('LSPS_NO_FROZEN_PACKS'), est_split_backward=off('LSPS_EST_SPLIT_BACKWARD'),
