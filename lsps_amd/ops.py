@@ -1050,7 +1050,9 @@ class _StemX3Fn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         N, H, W, K, R, S, stride, pad = ctx.geom
         own = ctx.own
-        assert dy is None and own.fused and own.grad is not None, "X3 stem: the consumer did not hand the gradient over"
+        if dy is not None or not own.fused or own.grad is None:
+            raise _lib.LspsHipError("X3 stem: its output feeds exactly ONE three-limb conv, whose backward hands the gradient over "
+                                    "through the ActHolder (got dy=%s, fused=%s)" % ('None' if dy is None else 'tensor', own.fused))
         g, db = own.grad, (own.db if (ctx.has_bias and ctx.needs_input_grad[2]) else None)
         own.fused, own.db, own.grad = False, None, None
         st = _lib.stream()
