@@ -451,6 +451,13 @@ def main():
             ops.set_math_mode('f32')
             del tr5, b5
             torch.cuda.empty_cache()
+        # opt-in: the encoder half of gen(images_a, images_b) once per iteration instead of once per update (options.share_encoder:
+        # gen_update continues from dis_update's pass; identical results; NOT the headline, whose algorithmic work counts both passes)
+        t_share = None
+        if args.dtype == 'f32':
+            from lsps_amd import options as _opt
+            with _opt.override(share_encoder=True):
+                t_share = timed(pretrain_step, 3)
         # the reference's own shipped batch size (exps/*.yaml `batch_size: 32`), eager and replayed from hipGraphs
         t_ref_bs = t_ref_bs_graph = None
         ref_bs = 32
@@ -471,6 +478,12 @@ def main():
                                                        'mfma_floor_ms': 0.579 * args.batch / 128.0 / F32_MFMA_PEAK_TFLOPS * 1e3},
                  'gen_forward_bs%d' % args.batch: {'calls_per_s': 1.0 / t_fwd, 'ms_per_call': 1e3 * t_fwd,
                                                    'tflops': 7.76 * args.batch / 128.0 / t_fwd}})
+        if t_share:
+            extra['pretrain_step_bs%d_shared_encoder_pass' % args.batch] = {
+                'ms_per_step': 1e3 * t_share, 'steps_per_s': 1.0 / t_share,
+                'note': 'opt-in (LSPS_SHARE_ENCODER=1): gen_update reuses the encoder pass (with its tape) of the dis_update in front '
+                        'of it - same images, same weights, the two calls differ in the noise draw only; bit-identical gen_update; '
+                        'not the headline: 2.8 of the 50 algorithmic TFLOP per step are not launched'}
         if t_ref_bs:
             extra['pretrain_step_bs%d_reference_yaml_batch' % ref_bs] = {
                 'ms_per_step': 1e3 * t_ref_bs, 'steps_per_s': 1.0 / t_ref_bs, 'hip_graph_ms_per_step': 1e3 * t_ref_bs_graph,

@@ -274,12 +274,25 @@ class SharedResGen(_Net):
         return (ops.from_c8(self._enc_shared(run_layers(self.encode_A, x_A), noise_a)),
                 ops.from_c8(self._enc_shared(run_layers(self.encode_B, x_B), noise_b)))
 
-    def forward(self, x_A, x_B, noise=None):
+    def encode_pre(self, x_A, x_B):
+        """The deterministic part of `forward`'s encoder half: both encoders and the residual blocks of `enc_shared`, i.e. the
+        input of its GaussianNoiseLayer.  `forward(..., pre=...)` continues from it.  (LSPSTrainer's opt-in encoder sharing:
+        dis_update and gen_update of one iteration call `gen(images_a, images_b)` with the same images and weights and differ only
+        in the noise draw, lsps_trainer.py:86,145.)"""
         ha, hb = run_layers(self.encode_A, x_A), run_layers(self.encode_B, x_B)
         if ops.is_c8(ha) != ops.is_c8(hb):
             ha, hb = ops.from_c8(ha), ops.from_c8(hb)
-        out = torch.cat((ha, hb), 0)
-        shared = self._enc_shared(out, noise)
+        return run_layers([l for l in self.enc_shared if not isinstance(l, GaussianNoiseLayer)], torch.cat((ha, hb), 0))
+
+    def forward(self, x_A, x_B, noise=None, pre=None):
+        if pre is not None:
+            shared = run_layers([l for l in self.enc_shared if isinstance(l, GaussianNoiseLayer)], pre, noise)
+        else:
+            ha, hb = run_layers(self.encode_A, x_A), run_layers(self.encode_B, x_B)
+            if ops.is_c8(ha) != ops.is_c8(hb):
+                ha, hb = ops.from_c8(ha), ops.from_c8(hb)
+            out = torch.cat((ha, hb), 0)
+            shared = self._enc_shared(out, noise)
         out = run_layers(self.dec_shared, shared)
         out_A, out_B = ops.from_c8(run_layers(self.decode_A, out)), ops.from_c8(run_layers(self.decode_B, out))
         x_Aa, x_Ba = torch.split(out_A, x_A.size(0), dim=0)

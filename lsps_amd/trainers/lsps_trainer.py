@@ -175,6 +175,7 @@ class LSPSTrainer(nn.Module):
         self._side = None
         self._frozen_decided = None
         self._gen_epoch_last = None
+        self._enc_shared_pass = None        # (key, pre): options.share_encoder
         self.math_mode = None               # None: whatever the process-wide mode is (ops.set_math_mode); see set_modes
         self.winograd = None
 
@@ -355,6 +356,18 @@ class LSPSTrainer(nn.Module):
             return
         self._finish_step(opt, names, scal, red.reduced_scalars())
 
+    def _encoder_key(self, images_a, images_b):
+        """What the encoder pass depends on, or None when sharing it is off / impossible: hipGraph replay (a tape cannot cross two
+        captures), residual-block dropout (the reference draws a fresh mask per pass), generators without `encode_pre`."""
+        if not ops.options.get().share_encoder or self._graphs_on or not hasattr(self.gen, 'encode_pre'):
+            return None
+        if any(getattr(m, 'dropout', 0) for m in self.gen.modules() if hasattr(m, 'dropout') and isinstance(getattr(m, 'dropout'), float)):
+            return None
+        arena = self.gen_opt.arena
+        return (images_a.data_ptr(), images_a._version, tuple(images_a.shape), images_b.data_ptr(), images_b._version,
+                tuple(images_b.shape), arena.epoch() if arena is not None else None, self.gen.training,
+                ops.get_math_mode(), ops.get_winograd(), ops.options.get())
+
     def _begin_backward(self, key, sig):
         """Opens the gradient exchange of a step whose loss terms are differentiated one by one (post_update)."""
         self._reducers[key].begin(sig)
@@ -400,7 +413,13 @@ class LSPSTrainer(nn.Module):
     def gen_update(self, images_a, labels_a, images_b, labels_b, hyperparameters, noise=(None, None, None)):
         hp = hyperparameters
         self.gen.zero_grad()                                   # one arena: also zeroes the Mapping grads (:85)
-        x_aa, x_ba, x_ab, x_bb, shared = self.gen(images_a, images_b, noise=noise[0])
+        pre = None
+        if self._enc_shared_pass is not None:
+            key, cached = self._enc_shared_pass
+            self._enc_shared_pass = None
+            if key == self._encoder_key(images_a, images_b):
+                pre = cached
+        x_aa, x_ba, x_ab, x_bb, shared = self.gen(images_a, images_b, noise=noise[0], pre=pre)
         x_bab, shared_bab = self.gen.forward_a2b(x_ba, noise=noise[1])
         x_aba, shared_aba = self.gen.forward_b2a(x_ab, noise=noise[2])
         decode_A, decode_B, data_a, data_b = x_ba, x_ab, x_ba, x_ab
@@ -441,8 +460,17 @@ class LSPSTrainer(nn.Module):
         hp = hyperparameters
         self.dis.zero_grad()
         nz_gen, nz_vae = (noise if isinstance(noise, (tuple, list)) else (noise, None))
+        self._enc_shared_pass = None
+        key = self._encoder_key(images_a, images_b)
+        if key is not None:
+            # opt-in (options.share_encoder): the encoder half of gen(images_a, images_b) is the same function of the same images and
+            # weights in this call and in the gen_update behind it (the two differ in the noise draw only): it runs ONCE, with its
+            # tape, and gen_update continues from it.  Identical results (the same kernels as gen_update's own encoder pass).
+            with torch.enable_grad():
+                pre = self.gen.encode_pre(images_a, images_b)
+            self._enc_shared_pass = (key, pre)
         with torch.no_grad():
-            x_aa, x_ba, x_ab, x_bb, _ = self.gen(images_a, images_b, noise=nz_gen)
+            x_aa, x_ba, x_ab, x_bb, _ = self.gen(images_a, images_b, noise=nz_gen, pre=pre.detach() if key is not None else None)
             if hp['train_map']:
                 _, decode_A, decode_B = self._pose2depth(labels_a, labels_b, nz_vae)
         if hp['train_map']:                                                       # :147-158

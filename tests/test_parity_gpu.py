@@ -496,6 +496,51 @@ def test_post_update_overlapped_branches_match_serial_bitwise(mode, monkeypatch)
             assert np.array_equal(o[1][k], outs[0][1][k]), k
 
 
+@pytest.mark.parametrize("config", ["tiny", "full"])
+def test_shared_encoder_pass_gives_the_same_iteration(config, monkeypatch):
+    """Opt-in `options.share_encoder`: the encoder half of `gen(images_a, images_b)` runs once per pretrain iteration (dis_update keeps
+    its tape, gen_update continues from it; the reference runs it twice with the same images and weights, lsps_trainer.py:86,145).
+    Two iterations with and without: gen_update's outputs, every loss scalar and the weights of both nets after the Adam steps are
+    bit-identical (the differentiated pass runs the same kernels either way; dis_update's generator pass at these small batches
+    takes the differentiated kernels instead of the no-grad ones, which is allowed to move its scalars by round-off)."""
+    A = _adapter()
+    from lsps_amd import options
+    hp = cases.hp_for(config)
+    sds = cases.make_weights(hp, lsps_ref)
+    n = 2 if config == 'full' else 4
+    b = cases.make_inputs(n)
+    lat2, lat1 = cases.latent_shape(hp, 2 * n), cases.latent_shape(hp, n)
+    res = []
+    for share in ('0', '1'):
+        monkeypatch.setattr(options, '_current', options.from_env({'LSPS_SHARE_ENCODER': share}))
+        tr = A.make_trainer(hp, sds)
+        A.set_train(tr, True)
+        dev = {k: A.T(v) for k, v in b.items()}                      # the SAME device tensors go to both calls, as in depth_train.py
+        trace, outs = [], None
+        for it in range(2):
+            nz = [A.T(cases.noise(lat2, 300 + it)), A.T(cases.noise(lat2, 310 + it)), A.T(cases.noise(lat1, 320 + it)),
+                  A.T(cases.noise(lat1, 330 + it))]
+            tr.dis_update(dev['xa'], dev['la'], dev['xb'], dev['lb'], dev['ca'], dev['cb'], hp, noise=nz[0])
+            assert (tr._enc_shared_pass is not None) == (share == '1')
+            outs = tr.gen_update(dev['xa'], dev['la'], dev['xb'], dev['lb'], hp, noise=(nz[1], nz[2], nz[3]))
+            assert tr._enc_shared_pass is None
+            trace.append(A.scalars(tr))
+        res.append((trace, [A.N(o) for o in outs[:6]], A.params(tr, 'gen'), A.params(tr, 'dis')))
+    (t0, o0, g0, d0), (t1, o1, g1, d1) = res
+    for a, b_ in zip(t0, t1):
+        for k in a:
+            if k.startswith('gen_'):
+                assert a[k] == b_[k], (k, a[k], b_[k])
+            else:
+                assert abs(float(a[k]) - float(b_[k])) <= 1e-5 * max(1.0, abs(float(a[k]))), (k, a[k], b_[k])
+    for a, b_ in zip(o0, o1):
+        assert np.array_equal(a, b_)
+    for k in g0:
+        assert np.array_equal(g0[k], g1[k]), k
+    for k in d0:
+        assert float(np.abs(d0[k] - d1[k]).max()) <= 6.5e-4, k       # two Adam steps of lr 1e-4 behind a round-off-different dis_update
+
+
 @pytest.mark.parametrize("mode", [3, 4])
 def test_post_update_merged_discriminator_pass_equals_the_two_pass_schedule(mode, monkeypatch):
     """Round 5: the estimate modes run `dis.regress_*` (whole batch) and `dis.feats` (16 generator outputs) as ONE pass of the
