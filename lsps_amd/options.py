@@ -32,7 +32,6 @@ class Options:
     est_split_backward: bool = True    # LSPS_EST_SPLIT_BACKWARD=0: one backward over the summed estimate loss
     est_order: str = 'feat_first'      # LSPS_EST_ORDER: feat_first | reg_first | chain
     share_encoder: bool = False        # LSPS_SHARE_ENCODER=1: gen_update reuses the encoder pass of the dis_update in front of it
-    cycle_merge: bool = True           # LSPS_CYCLE_MERGE=0: gen_update runs forward_a2b and forward_b2a as two passes
     est_merge: bool = True             # LSPS_EST_MERGE=0: estimate modes run dis.regress_* and dis.feats as two passes (round 4)
     fuse_act: bool = True              # LSPS_FUSE_ACT=0: LeakyReLU backward as separate passes (f32 and C8)
     c8_fuse_act: bool = True           # LSPS_C8_FUSE_ACT=0: the same, C8 kernels only
@@ -64,7 +63,7 @@ def from_env(env=None):
         overlap=not on('LSPS_NO_OVERLAP'),
         side_prio=int(e.get('LSPS_SIDE_PRIO', '0')), pack_cache=not on('LSPS_NO_PACK_CACHE'),
         frozen_packs=not on('LSPS_NO_FROZEN_PACKS'), est_split_backward=off('LSPS_EST_SPLIT_BACKWARD'),
-        est_order=e.get('LSPS_EST_ORDER', 'feat_first'), est_merge=off('LSPS_EST_MERGE'), cycle_merge=off('LSPS_CYCLE_MERGE'), share_encoder=on('LSPS_SHARE_ENCODER'), fuse_act=off('LSPS_FUSE_ACT'), c8_fuse_act=off('LSPS_C8_FUSE_ACT'),
+        est_order=e.get('LSPS_EST_ORDER', 'feat_first'), est_merge=off('LSPS_EST_MERGE'), share_encoder=on('LSPS_SHARE_ENCODER'), fuse_act=off('LSPS_FUSE_ACT'), c8_fuse_act=off('LSPS_C8_FUSE_ACT'),
         c8=off('LSPS_C8'), c8s2=off('LSPS_C8S2'), x3=off('LSPS_X3'), x3_min_gmac=float(e.get('LSPS_X3_MIN_GMAC', '1.0')), force_dp=on('LSPS_FORCE_DP'), dp_graphs=off('LSPS_DP_GRAPHS'),
         bucket_bytes=int(e.get('LSPS_BUCKET_BYTES', DEFAULT_BUCKET_BYTES)),
         native=tuple((k, e[k]) for k in _NATIVE if k in e))

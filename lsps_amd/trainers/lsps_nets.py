@@ -299,26 +299,6 @@ class SharedResGen(_Net):
         x_Ab, x_Bb = torch.split(out_B, x_A.size(0), dim=0)
         return x_Aa, x_Ba, x_Ab, x_Bb, ops.from_c8(shared)
 
-    def forward_cycle(self, x_A, x_B, noise_a=None, noise_b=None):
-        """`forward_a2b(x_A)` and `forward_b2a(x_B)` (lsps_nets.py:260-272) in one pass: the two translations share `enc_shared` and
-        `dec_shared`, which therefore run ONCE on the concatenated batch (every layer is per-sample, InstanceNorm included; the
-        per-domain encoders / decoders run on their halves as before).  Returns (x_ab, shared_a, x_ba, shared_b); per sample the
-        arithmetic of the two separate calls, the shared blocks' weight gradients summed in one launch instead of two."""
-        ha, hb = run_layers(self.encode_A, x_A), run_layers(self.encode_B, x_B)
-        if ops.is_c8(ha) != ops.is_c8(hb):
-            ha, hb = ops.from_c8(ha), ops.from_c8(hb)
-        na = x_A.size(0)
-        noise = None
-        if noise_a is not None or noise_b is not None:
-            assert noise_a is not None and noise_b is not None, "forward_cycle: give both noise draws or neither"
-            noise = torch.cat((noise_a, noise_b), 0)
-        shared = self._enc_shared(torch.cat((ha, hb), 0), noise)
-        out = run_layers(self.dec_shared, shared)
-        x_ab = ops.from_c8(run_layers(self.decode_B, out[:na]))
-        x_ba = ops.from_c8(run_layers(self.decode_A, out[na:]))
-        sh = ops.from_c8(shared)
-        return x_ab, sh[:na], x_ba, sh[na:]
-
     def forward_a2b(self, x_A, noise=None):
         shared = self._enc_shared(run_layers(self.encode_A, x_A), noise)
         return ops.from_c8(run_layers(self.decode_B, run_layers(self.dec_shared, shared))), ops.from_c8(shared)

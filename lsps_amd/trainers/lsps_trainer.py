@@ -420,12 +420,8 @@ class LSPSTrainer(nn.Module):
             if key == self._encoder_key(images_a, images_b):
                 pre = cached
         x_aa, x_ba, x_ab, x_bb, shared = self.gen(images_a, images_b, noise=noise[0], pre=pre)
-        if ops.options.get().cycle_merge and hasattr(self.gen, 'forward_cycle') and x_ba.shape == x_ab.shape:
-            # the two cycle translations share the generator's shared blocks: one pass on the concatenated batch (round 5)
-            x_bab, shared_bab, x_aba, shared_aba = self.gen.forward_cycle(x_ba, x_ab, noise[1], noise[2])
-        else:
-            x_bab, shared_bab = self.gen.forward_a2b(x_ba, noise=noise[1])
-            x_aba, shared_aba = self.gen.forward_b2a(x_ab, noise=noise[2])
+        x_bab, shared_bab = self.gen.forward_a2b(x_ba, noise=noise[1])
+        x_aba, shared_aba = self.gen.forward_b2a(x_ab, noise=noise[2])
         decode_A, decode_B, data_a, data_b = x_ba, x_ab, x_ba, x_ab
         map_terms = None
         if hp['train_map']:                                                       # :84-100

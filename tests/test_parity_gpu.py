@@ -497,33 +497,6 @@ def test_post_update_overlapped_branches_match_serial_bitwise(mode, monkeypatch)
 
 
 @pytest.mark.parametrize("config", ["tiny", "full"])
-def test_forward_cycle_equals_the_two_translations(config):
-    """SharedResGen.forward_cycle (round 5: gen_update's two cycle translations with the shared blocks run once on the concatenated
-    batch) against forward_a2b + forward_b2a (lsps_nets.py:260-272): outputs and latents within f32 round-off, input gradients too."""
-    A = _adapter()
-    hp = cases.hp_for(config)
-    sds = cases.make_weights(hp, lsps_ref)
-    tr = A.make_trainer(hp, sds)
-    A.set_train(tr, True)
-    n = 3
-    b = cases.make_inputs(n)
-    lat = cases.latent_shape(hp, n)
-    na, nb = A.T(cases.noise(lat, 41)), A.T(cases.noise(lat, 42))
-    res = []
-    for merged in (False, True):
-        xa, xb = A.T(b['xa']).requires_grad_(True), A.T(b['xb']).requires_grad_(True)
-        if merged:
-            x_ab, sh_a, x_ba, sh_b = tr.gen.forward_cycle(xa, xb, na, nb)
-        else:
-            x_ab, sh_a = tr.gen.forward_a2b(xa, noise=na)
-            x_ba, sh_b = tr.gen.forward_b2a(xb, noise=nb)
-        (x_ab.square().mean() + x_ba.square().mean() + sh_a.square().mean() + sh_b.square().mean()).backward()
-        res.append([A.N(t) for t in (x_ab, sh_a, x_ba, sh_b, xa.grad, xb.grad)])
-    for a, b_ in zip(*res):
-        assert float(np.abs(a - b_).max()) <= 2e-5 * float(np.abs(a).max()) + 1e-12
-
-
-@pytest.mark.parametrize("config", ["tiny", "full"])
 def test_shared_encoder_pass_gives_the_same_iteration(config, monkeypatch):
     """Opt-in `options.share_encoder`: the encoder half of `gen(images_a, images_b)` runs once per pretrain iteration (dis_update keeps
     its tape, gen_update continues from it; the reference runs it twice with the same images and weights, lsps_trainer.py:86,145).
