@@ -602,6 +602,7 @@ def main():
                        'parallelism': 'dp%d' % world,
                        'unit_of_work': 'one bs=%d step; value = n_gpus * steps / time (aggregate over ranks)' % args.batch, 'algorithmic_tflop_per_step_per_gpu': 50.0 * args.batch / 128.0},
             'step_tflops_per_gpu': 50.0 * args.batch / 128.0 / (elapsed / args.steps),
+            'peak_hbm_gb_allocated': torch.cuda.max_memory_allocated(dev) / 1e9,
             'step_mfma_issued_frac': step_issued_frac,
             'global_iterations_per_s': args.steps / elapsed,
             'roofline': roofline, 'data_parallel': dp_stats, 'other_workloads': extra,
