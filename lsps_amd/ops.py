@@ -1000,6 +1000,8 @@ def _x3_grad_operand(L, dy, y, slope, own, want_db, channels, out_f32, st):
             return dy, db                                # X3, masked by the consumer
         slope, want_db_here = -1.0, False                # f32, masked by the consumer (1x1 head): split only
     else:
+        if dy is None:
+            raise _lib.LspsHipError("three-limb layer: no gradient arrived, neither along the autograd edge nor through the ActHolder")
         want_db_here = want_db
         db = None
         if not out_f32:                                  # an X3 output nobody masked (fusion switched off): via f32
