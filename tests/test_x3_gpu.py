@@ -187,7 +187,9 @@ def test_output_head_dgrad_emits_limbs():
     gl, db1, dw1 = torch.empty(N, 3, C // 8, H, H, 8, dtype=BF, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
     _lib.check(L.lsps_pw1_dgrad_act_x3(_lib.ptr(dpre), _lib.ptr(w), _lib.ptr(y), 0.01, _lib.ptr(gl, BF), _lib.ptr(db1), _lib.ptr(dw1), None, N, C,
                                        H * H, ws, wsb, st), 'pw1x3')
-    assert torch.equal(ops.x3_join(gl), dx) and torch.equal(db0, db1) and torch.equal(dw0, dw1)
+    assert torch.equal(ops.x3_join(gl), dx)
+    # (the two instantiations contract their partial sums differently: round-off, not bitwise)
+    assert _rel(db1, db0) < 1e-6 and _rel(dw1, dw0) < 1e-6
     ref = torch.where(y > 0, w.view(1, C, 1, 1) * dpre, w.view(1, C, 1, 1) * dpre * 0.01)
     assert _rel(dx, ref) < 1e-6
 
