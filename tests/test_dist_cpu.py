@@ -394,7 +394,9 @@ def _resume_worker(rank, world, port, root, out):
         assert tr.gpu is None                                   # resume BEFORE cuda(), as the reference's driver calls it
         it = tr.resume(os.path.join(mine, 'pre'), idx=-1, load_opt=True)
         flags = (ldist.agree_all(True), ldist.agree_all(rank == 0), ldist.drain_watchdog())
-        out.put((rank, it, flags))
+        # the out-of-band agreement of the capture decision (rendezvous store, no collective of the backend: ADVICE r4)
+        oob = (ldist.agree_all_oob(True), ldist.agree_all_oob(rank == 0), ldist.agree_all_oob(rank == 1), ldist.agree_all_oob(True))
+        out.put((rank, it, flags, oob))
     except Exception as e:                                       # the parent would otherwise wait for its timeout
         import traceback
         out.put((rank, 'error', repr(e) + traceback.format_exc()))
@@ -416,6 +418,7 @@ def test_resume_before_cuda_agrees_on_rank0s_iteration_count(tmp_path):
         assert p.exitcode == 0
     assert [g[1] for g in got] == [7000, 7000], got             # rank 1 found nothing locally and still continues at 7000
     assert all(g[2] == (True, False, True) for g in got), got   # agree_all = AND over ranks; gloo has no watchdog to drain
+    assert all(g[3] == (True, False, False, True) for g in got), got   # the same answer on every rank, round after round
 
 
 def test_estimate_first4_broadcast_slices_by_the_real_count():
