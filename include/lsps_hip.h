@@ -429,6 +429,11 @@ int lsps_x3_stem_fwd(const float *x, const float *w, const float *bias /*nullabl
 int lsps_x3_join_nchw(const void *xl, float *y, int N, int C, int HW, void *stream);
 int lsps_x3_conv3x3s2_ok(int N, int C, int H, int W, int K);
 size_t lsps_x3_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K);
+/* the launch plan of Conv2d(C, K, 3, 2, 1) on [N,C,H,W] (no GPU needed; what the calls below will do): plan[0..3] = {k ranges
+ * (1: no split-K), 16-channel chunks per range, workgroup walk (0: pixel tile -> XCD tile % 8, 1: linear, m tile / range fastest),
+ * workgroups} of the forward kernel (transposed = 0) or of the dgrad / ConvTranspose2d-forward kernel (transposed = 1).
+ * Returns 0, or LSPS_E_ARG for an unsupported geometry. */
+int lsps_x3_conv3x3s2_plan(int transposed, int N, int C, int H, int W, int K, int plan[4]);
 int lsps_x3_conv3x3s2_fwd(const void *xl, const float *w, const float *bias /*nullable*/, float *y /*nullable*/, void *yl /*nullable*/,
                           int N, int C, int H, int W, int K, float slope, void *ws, size_t ws_bytes, void *stream);
 /* dx [N,C,H,W] (f32 NCHW `dx` or X3 `dxl`) from the X3 gradient dyl [N,K,H/2,W/2] w.r.t. the conv's OUTPUT (its own activation

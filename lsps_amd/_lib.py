@@ -112,6 +112,7 @@ _SIGNATURES = {
     'lsps_x3_join_nchw': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'lsps_x3_conv3x3s2_ok': (c_int, [c_int] * 5),
     'lsps_x3_conv3x3s2_workspace_bytes': (c_size_t, [c_int] * 5),
+    'lsps_x3_conv3x3s2_plan': (c_int, [c_int] * 6 + [ctypes.POINTER(c_int)]),
     'lsps_x3_conv3x3s2_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [c_float, _P, c_size_t, _P]),
     'lsps_x3_conv3x3s2_dgrad': (c_int, [_P, _P, _P, _P, _P, c_float, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
     'lsps_x3_conv3x3s2_wgrad': (c_int, [_P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),

@@ -100,28 +100,94 @@ static int x3s2_pack(const float *w, int M, int C, long sm, long sc, int BM, voi
   X3S2Pack pp;
   pp.W = w; pp.Wq = (unsigned short *)slot; pp.M = M; pp.C = C; pp.sm = sm; pp.sc = sc;
   if (BM == 128)
-    hipLaunchKernelGGL(x3s2_pack_kernel, dim3(ceil_div((long)M * C * 9, 256)), dim3(256), 0, st, pp);
+    hipLaunchKernelGGL(x3s2_pack_kernel<128>, dim3(ceil_div((long)M * C / 8, 256)), dim3(256), 0, st, pp);
   else
-    hipLaunchKernelGGL(x3s2_pack_tr_kernel, dim3(ceil_div((long)M * C * 9, 256)), dim3(256), 0, st, pp);
+    hipLaunchKernelGGL(x3s2_pack_kernel<64>, dim3(ceil_div((long)M * C / 8, 256)), dim3(256), 0, st, pp);
   LSPS_CHECK_LAUNCH("x3s2_pack");
   return 0;
 }
 
-// split-K decision of the forward / transposed kernels: `base` real workgroups (tiles x m tiles) without a split, `nk` reduction
-// chunks of 16 channels
-static int x3_ksplit(int base, int nk, int *kper) {
-  int ks = 1;
-  const int cus = 256;
-  // fewer than 3/4 of one round of workgroups AND a long reduction (>= 512 channels: the deep discriminator layers, whose
-  // outputs are small); on the generator's layers (<= 256 channels, large maps) the partial outputs cost more than the idle CUs
-  // (measured: the 8-sample transposed convs of the estimate modes 76 -> 140 us with a 4-way split)
-  if (base * 4 <= cus * 3 && nk >= 32) {
-    ks = std::min(8, (cus + base - 1) / base);
-    ks = std::min(ks, nk / 8);
+// Launch plan of the forward / transposed kernels: how many k ranges (split-K) and which workgroup -> unit walk.
+// `ntiles` pixel tiles x `MT` m tiles, `nk` reduction chunks of 16 channels, `out_mb` = 10^6 bytes of f32 output.
+//
+// Both kernels are persistent (one workgroup per CU) and a unit's time is ~ its chunks, so a launch costs
+//   rounds(units over workgroups) x (chunks per unit + fixed part) [+ the partial sums' round trip and x3_splitk_finish_kernel],
+// in units of one chunk (~5 us): e.g. 288 units = 2 rounds of which the second is 1/8 full, and with the XCD walk (a pixel tile
+// lives on XCD tile % 8) three pixel tiles leave five XCDs without any work.  The plan is the cheapest of {XCD walk, linear walk}
+// x {1 .. 8 ranges} under that model; measured on the estimate-mode discriminator (N = 144: 5.76 -> 5.3 ms per estimate3 step,
+// `profiles/r5z_*`) — the constants only have to rank the candidates.  LSPS_X3_PLAN=0: the round-5 rule (XCD walk; split only
+// below 3/4 of a round and >= 512 channels).
+struct X3Plan {
+  int ks, kper, linear, grid;
+};
+
+static int x3_plan_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *e = getenv("LSPS_X3_PLAN");
+    mode = e ? atoi(e) : 1;
   }
-  if (ks < 1) ks = 1;
-  *kper = (nk + ks - 1) / ks;
-  return (nk + *kper - 1) / *kper;
+  return mode;
+}
+
+static int x3_device_cus();
+
+static X3Plan x3_plan(int ntiles, int MT, int nk, double out_mb) {
+  const int cus = x3_device_cus() / 8 * 8;
+  X3Plan best = {1, nk, 0, 0};
+  if (x3_plan_mode() == 0) {
+    const int base = ntiles * MT;
+    int ks = 1;
+    if (base * 4 <= 256 * 3 && nk >= 32) {
+      ks = std::min(8, (256 + base - 1) / base);
+      ks = std::min(ks, nk / 8);
+    }
+    if (ks < 1) ks = 1;
+    best.kper = (nk + ks - 1) / ks;
+    best.ks = (nk + best.kper - 1) / best.kper;
+    best.grid = std::min((ntiles + 7) / 8 * 8 * MT * best.ks, cus);
+    return best;
+  }
+  const double fixed = 1.5;                                  // prologue + epilogue of a unit, in chunks
+  double best_cost = 0;
+  for (int linear = 0; linear < 2; ++linear)
+    for (int req = 1; req <= 8; ++req) {
+      const int kper = (nk + req - 1) / req, ks = (nk + kper - 1) / kper;
+      if (ks != req || (ks > 1 && (kper < 4 || ks * out_mb > 768.))) continue;      // (the partial sums live in the workspace)
+      long units, groups, rounds;
+      if (linear) {
+        units = (long)ntiles * MT * ks;
+        groups = std::min<long>(units, cus);
+        rounds = (units + groups - 1) / groups;
+      } else {
+        units = (long)((ntiles + 7) / 8) * MT * ks;          // of the busiest XCD
+        groups = std::min<long>((long)(ntiles + 7) / 8 * 8 * MT * ks, cus) / 8;
+        rounds = (units + groups - 1) / groups;
+      }
+      double cost = rounds * (kper + fixed);
+      if (ks > 1) cost += (8.0 + (2.0 * ks + 1.5) * out_mb / 2.5) / 5.2;      // partial sums: written, read, + the finish launch
+      if (linear) cost *= 1.03;                              // ties go to the walk that keeps an image's rows in one L2
+      if (ks > 1) cost *= 1.05;                              // ... and to the launch without partial sums
+      if (best.grid == 0 || cost < best_cost) {
+        best_cost = cost;
+        best.ks = ks; best.kper = kper; best.linear = linear;
+        best.grid = linear ? (int)groups : (int)(groups * 8);
+      }
+    }
+  return best;
+}
+
+// x3_splitk_finish_kernel's cut of the N * HW (image, pixel) items: ~2048 workgroups over (C / 8) x ranges, ranges of whole
+// 256-item passes, at most X3_FINISH_MAX_RANGES of them (= rows of its bias-gradient partial sums)
+#define X3_FINISH_MAX_RANGES 1024
+static int x3_finish_ranges(int N, int M, long HW, long *items_per_range) {
+  const long total = (long)N * HW;
+  long want = std::max<long>(1, (2048 + (M >> 3) - 1) / (M >> 3));
+  want = std::min<long>(want, X3_FINISH_MAX_RANGES);
+  long ipr = (total + want - 1) / want;
+  ipr = (ipr + 255) / 256 * 256;
+  *items_per_range = ipr;
+  return (int)((total + ipr - 1) / ipr);
 }
 
 // out[c] = sum over `rows` rows of part[rows][C]; `scratch`: 64 * C floats (used when rows > 64)
@@ -183,14 +249,15 @@ static int x3s2_run_fwd(const void *big, const float *w, long sm, long sc, const
   p.act_slope = act_slope;
   p.dbpart = nullptr;
   const size_t pack_bytes = align_up((size_t)M * Cx * 9 * 3 * sizeof(unsigned short), 256);
-  p.ksplit = x3_ksplit(p.ntiles * (M >> 7), Cx >> 4, &p.kper);
+  const X3Plan plan = x3_plan(p.ntiles, M >> 7, Cx >> 4, 4e-6 * N * M * p.P * p.Q);
+  p.ksplit = plan.ks; p.kper = plan.kper; p.linear = plan.linear;
   p.ysplit = 0;
   if (p.ksplit > 1) {
     // raw partial outputs [range][N][M][P][Q] behind the packed weights; the epilogue runs in x3_splitk_finish_kernel
     const long out_elems = (long)N * M * p.P * p.Q;
     const size_t part_bytes = (size_t)p.ksplit * out_elems * sizeof(float);
-    const int isplits = std::max(1, std::min(N, (1024 + (M >> 3) - 1) / (M >> 3)));
-    const int ips = (N + isplits - 1) / isplits, nis = (N + ips - 1) / ips;
+    long ips;
+    const int nis = x3_finish_ranges(N, M, (long)p.P * p.Q, &ips);
     const size_t db_bytes = act_y ? ((size_t)nis + 64) * M * sizeof(float) : 0;
     if (!ws || ws_bytes < pack_bytes + part_bytes + db_bytes + 256) {
       set_error("x3 stride-2 conv: workspace too small for the split-K partial sums");
@@ -200,7 +267,7 @@ static int x3s2_run_fwd(const void *big, const float *w, long sm, long sc, const
     float *dbp = act_y ? reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + pack_bytes + align_up(part_bytes, 256)) : nullptr;
     X3S2Params q = p;
     q.bias = nullptr; q.lrelu = 1.f; q.ActY = nullptr; q.Y = part; q.YL = nullptr; q.ysplit = out_elems;
-    const dim3 sgrid(std::min((p.ntiles + 7) / 8 * 8 * (M >> 7) * p.ksplit, x3_device_cus() / 8 * 8));
+    const dim3 sgrid(plan.grid);
     if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_fwd_kernel<false, false>), X3F_LDS_BYTES, "x3s2_fwd")) return rc;
     hipLaunchKernelGGL((x3s2_fwd_kernel<false, false>), sgrid, dim3(512), X3F_LDS_BYTES, st, q);
     LSPS_CHECK_LAUNCH("x3s2_fwd(split-K)");
@@ -217,7 +284,7 @@ static int x3s2_run_fwd(const void *big, const float *w, long sm, long sc, const
       return LSPS_E_ARG;
     }
   }
-  const dim3 grid(std::min((p.ntiles + 7) / 8 * 8 * (M >> 7), x3_device_cus() / 8 * 8));
+  const dim3 grid(plan.grid);
 #define X3F_LAUNCH(O3, MK)                                                                                                  \
   do {                                                                                                                      \
     if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_fwd_kernel<O3, MK>), X3F_LDS_BYTES, "x3s2_fwd")) return rc;  \
@@ -260,13 +327,14 @@ static int x3s2_run_tr(const void *small, const float *w, long sm, long sc, cons
   p.act_slope = act_slope;
   p.dbpart = nullptr;
   const size_t pack_bytes = align_up((size_t)M * Cx * 9 * 3 * sizeof(unsigned short), 256);
-  p.ksplit = x3_ksplit(p.ntiles * (M >> 6), Cx >> 4, &p.kper);
+  const X3Plan plan = x3_plan(p.ntiles, M >> 6, Cx >> 4, 4e-6 * N * M * H * W);
+  p.ksplit = plan.ks; p.kper = plan.kper; p.linear = plan.linear;
   p.ysplit = 0;
   if (p.ksplit > 1) {
     const long out_elems = (long)N * M * H * W;
     const size_t part_bytes = (size_t)p.ksplit * out_elems * sizeof(float);
-    const int isplits = std::max(1, std::min(N, (1024 + (M >> 3) - 1) / (M >> 3)));
-    const int ips = (N + isplits - 1) / isplits, nis = (N + ips - 1) / ips;
+    long ips;
+    const int nis = x3_finish_ranges(N, M, (long)H * W, &ips);
     const size_t db_bytes = act_y ? ((size_t)nis + 64) * M * sizeof(float) : 0;
     if (!ws || ws_bytes < pack_bytes + part_bytes + db_bytes + 256) {
       set_error("x3 stride-2 conv: workspace too small for the split-K partial sums");
@@ -276,7 +344,7 @@ static int x3s2_run_tr(const void *small, const float *w, long sm, long sc, cons
     float *dbp = act_y ? reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + pack_bytes + align_up(part_bytes, 256)) : nullptr;
     X3S2TParams q = p;
     q.bias = nullptr; q.lrelu = 1.f; q.ActY = nullptr; q.Y = part; q.YL = nullptr; q.ysplit = out_elems;
-    const dim3 sgrid(std::min((p.ntiles + 7) / 8 * 8 * (M >> 6) * p.ksplit, x3_device_cus() / 8 * 8));
+    const dim3 sgrid(plan.grid);
     if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_tr_kernel<false, false>), X3T_LDS_BYTES, "x3s2_tr")) return rc;
     hipLaunchKernelGGL((x3s2_tr_kernel<false, false>), sgrid, dim3(512), X3T_LDS_BYTES, st, q);
     LSPS_CHECK_LAUNCH("x3s2_tr(split-K)");
@@ -293,7 +361,7 @@ static int x3s2_run_tr(const void *small, const float *w, long sm, long sc, cons
       return LSPS_E_ARG;
     }
   }
-  const dim3 grid(std::min((p.ntiles + 7) / 8 * 8 * (M >> 6), x3_device_cus() / 8 * 8));
+  const dim3 grid(plan.grid);
 #define X3T_LAUNCH(O3, MK)                                                                                                \
   do {                                                                                                                    \
     if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_tr_kernel<O3, MK>), X3T_LDS_BYTES, "x3s2_tr")) return rc;  \
@@ -373,16 +441,31 @@ size_t lsps_x3_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K) {
   X3S2Params f;
   x3s2_fwd_geom(N, C, H, W, K, &f);                                                   // (as a transposed conv's dgrad: tiles x K)
   need = std::max(need, pack + align_up(((size_t)f.ntiles + 64) * K * sizeof(float), 256) + 512);
-  // split-K partial outputs (<= 8 ranges) + the finish kernel's bias-gradient partial sums (<= 1024 rows)
-  int kper;
-  const int ksf = x3_ksplit(f.ntiles * (K >> 7), C >> 4, &kper);      // forward direction: out [N][K][P][Q]
-  if (ksf > 1) need = std::max(need, pack + align_up((size_t)ksf * N * K * f.P * f.Q * sizeof(float), 256) + ((size_t)N + 64) * K * sizeof(float) + 512);
-  const int kst = x3_ksplit(q.ntiles * (C >> 6), K >> 4, &kper);      // transposed direction: out [N][C][H][W]
-  if (kst > 1) need = std::max(need, pack + align_up((size_t)kst * N * C * H * W * sizeof(float), 256) + ((size_t)N + 64) * C * sizeof(float) + 512);
+  // split-K partial outputs (<= 8 ranges) + the finish kernel's bias-gradient partial sums (<= X3_FINISH_MAX_RANGES rows)
+  const int ksf = x3_plan(f.ntiles, K >> 7, C >> 4, 4e-6 * N * K * f.P * f.Q).ks;      // forward direction: out [N][K][P][Q]
+  if (ksf > 1) need = std::max(need, pack + align_up((size_t)ksf * N * K * f.P * f.Q * sizeof(float), 256) + ((size_t)X3_FINISH_MAX_RANGES + 64) * K * sizeof(float) + 512);
+  const int kst = x3_plan(q.ntiles, C >> 6, K >> 4, 4e-6 * N * C * H * W).ks;           // transposed direction: out [N][C][H][W]
+  if (kst > 1) need = std::max(need, pack + align_up((size_t)kst * N * C * H * W * sizeof(float), 256) + ((size_t)X3_FINISH_MAX_RANGES + 64) * C * sizeof(float) + 512);
   X3S2WParams wp;
   x3s2_wgrad_geom(N, K, C, H, W, &wp);
   need = std::max(need, (size_t)wp.splits * 9 * K * C * sizeof(float));
   return need;
+}
+
+int lsps_x3_conv3x3s2_plan(int transposed, int N, int C, int H, int W, int K, int plan[4]) {
+  LSPS_CHECK_ARG(plan, "x3 conv plan: null pointer");
+  X3Plan pl;
+  if (transposed) {
+    X3S2TParams q;
+    LSPS_CHECK_ARG(x3s2_tr_geom(N, K, H, W, C, &q), "x3 conv plan: unsupported geometry");
+    pl = x3_plan(q.ntiles, C >> 6, K >> 4, 4e-6 * N * C * H * W);
+  } else {
+    X3S2Params f;
+    LSPS_CHECK_ARG(x3s2_fwd_geom(N, C, H, W, K, &f), "x3 conv plan: unsupported geometry");
+    pl = x3_plan(f.ntiles, K >> 7, C >> 4, 4e-6 * N * K * f.P * f.Q);
+  }
+  plan[0] = pl.ks; plan[1] = pl.kper; plan[2] = pl.linear; plan[3] = pl.grid;
+  return 0;
 }
 
 int lsps_x3_conv3x3s2_fwd(const void *xl, const float *w, const float *bias, float *y, void *yl, int N, int C, int H, int W, int K,

@@ -70,35 +70,62 @@ struct X3S2Pack {
   long sm, sc;                   // element strides of m and of the reduction channel in W; tap t = 3 r + s at offset t
 };
 
-// Wq[m tile of 128][chunk of 16 c][tap row r][limb][tap column s][k-half][128 m][8 c]: the LDS image of a stage's A operand
+// Wq[m tile of BM][chunk of 16 c][tap row r][limb][tap column s][k-half][BM m][8 c]: the LDS image of a stage's A operand
+// (BM = 128: x3s2_fwd_kernel, BM = 64: x3s2_tr_kernel).  One thread = the 8 channels x 9 taps of one (m, k-half): 27 stores of
+// 16 bytes, contiguous over the BM threads of an (m tile, chunk, k-half); the 72 source floats are one 288-byte run when the
+// reduction channel is the inner dimension of W (sc = 9: float4 loads), nine-float runs contiguous ACROSS the threads otherwise
+// (sm = 9).  The deepest discriminator layer (1024 x 2048 x 9 weights: 75 MB in, 113 MB out) is re-packed twice per estimate-mode
+// step (forward and dgrad panels), 70 us each with one thread per ELEMENT (4-byte strided loads, 2-byte stores).
+template <int BM>
 __global__ __launch_bounds__(256) void x3s2_pack_kernel(X3S2Pack p) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // over [mt][chunk][r][s][kh][128][8]
-  const long total = (long)p.M * p.C * 9;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // over [mt][chunk][kh][BM]
+  const long total = (long)p.M * p.C >> 3;
   if (idx >= total) return;
-  const int e = (int)(idx & 7), ml = (int)((idx >> 3) & 127), kh = (int)((idx >> 10) & 1);
-  long rest = idx >> 11;
-  const int s = (int)(rest % 3);
-  rest /= 3;
-  const int r = (int)(rest % 3);
-  rest /= 3;
+  const int ml = (int)(idx % BM);
+  long rest = idx / BM;
+  const int kh = (int)(rest & 1);
+  rest >>= 1;
   const int chunks = p.C >> 4;
   const int chunk = (int)(rest % chunks), mt = (int)(rest / chunks);
-  const int m = mt * 128 + ml, c = chunk * 16 + kh * 8 + e;
-  const float x = p.W[(long)m * p.sm + (long)c * p.sc + 3 * r + s];
-  const __bf16 h = (__bf16)x;
-  const float r1 = x - (float)h;
-  const __bf16 mi = (__bf16)r1;
-  const __bf16 lo = (__bf16)(r1 - (float)mi);
-  const long stage = ((long)mt * chunks + chunk) * 3 + r;
-  const long o = (stage * 9 + s) * 2048 + kh * 1024 + ml * 8 + e;   // limb 0; limb l at + l * 3 * 2048
-  p.Wq[o] = __builtin_bit_cast(unsigned short, h);
-  p.Wq[o + 3 * 2048] = __builtin_bit_cast(unsigned short, mi);
-  p.Wq[o + 6 * 2048] = __builtin_bit_cast(unsigned short, lo);
+  const int m = mt * BM + ml, c0 = chunk * 16 + kh * 8;
+  float x[8][9];
+  const float *src = p.W + (long)m * p.sm + (long)c0 * p.sc;
+  if (p.sc == 9 && !(reinterpret_cast<uintptr_t>(src) & 15)) {       // uniform: W 16-byte aligned, sm and 8 sc multiples of 4 floats
+    float v[72];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      const f32x4 q = reinterpret_cast<const f32x4 *>(src)[i];
+      v[4 * i] = q[0]; v[4 * i + 1] = q[1]; v[4 * i + 2] = q[2]; v[4 * i + 3] = q[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) x[e][t] = v[e * 9 + t];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) x[e][t] = src[(long)e * p.sc + t];
+  }
+  const long stage0 = ((long)mt * chunks + chunk) * 3;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = x[e][t];
+    bf16x8 h, mi, lo;
+    split3(v, h, mi, lo);
+    const int r = t / 3, sx = t - 3 * r;
+    unsigned short *o = p.Wq + (((stage0 + r) * 9 + sx) * 2 + kh) * (BM * 8) + ml * 8;       // limb 0; limb l at + l * 3 * 2 BM 8
+    *reinterpret_cast<bf16x8 *>(o) = h;
+    *reinterpret_cast<bf16x8 *>(o + 3 * 2 * BM * 8) = mi;
+    *reinterpret_cast<bf16x8 *>(o + 6 * 2 * BM * 8) = lo;
+  }
 }
 
 struct X3S2Params {
   const unsigned short *X;       // [N][3][Cx/8][H][W][8]
-  const unsigned short *Wq;      // x3s2_pack_kernel's layout
+  const unsigned short *Wq;      // x3s2_pack_kernel<128>'s layout
   const float *bias;             // [M] or null
   float *Y;                      // f32 [N][M][P][Q] (OUT3 = false)
   unsigned short *YL;            // [N][3][M/8][P][Q][8] (OUT3 = true)
@@ -117,6 +144,11 @@ struct X3S2Params {
   // activation / mask: bias = null, lrelu = 1) at Y + range * ysplit; x3_splitk_finish_kernel sums the ranges and applies the epilogue
   int ksplit, kper;
   long ysplit;
+  // workgroup -> (pixel tile, m tile, k range) walk.  0: a pixel tile lives on XCD tile % 8 (its image rows are fetched into ONE L2 and
+  // shared by the m tiles: the large-map layers); 1: unit = workgroup index, m tile / k range fastest — every CU gets work when
+  // there are fewer than 8 pixel tiles (or not a multiple of 8), and with (M tiles x ranges) % 8 == 0 an XCD only ever reads its own
+  // eighth of the weight panels (the deep discriminator layers: 113 MB of limbs against a few MB of activations)
+  int linear;
 };
 
 #define X3F_BP 10                                          // image pieces (64 units) per limb and stage: <= 640 units
@@ -169,6 +201,11 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
   for (int i = 0; i < 5; ++i) voffa[i] = (unsigned)(((wave + 8 * i) * 64 + lane) * 16);
 
   auto decode = [&](int lin, int &mt_, int &ptile_) {                // mt_ carries (m tile, k range): mt + MT * range
+    if (p.linear) {                                                  // weight-stationary walk (x3_plan in x3.hip): see X3S2Params::linear
+      mt_ = lin % (MT * KS);
+      ptile_ = lin / (MT * KS);
+      return ptile_ < p.ntiles;
+    }
     const int xcd = lin & 7, qq = lin >> 3;
     mt_ = qq % (MT * KS);
     ptile_ = xcd + 8 * (qq / (MT * KS));
@@ -370,7 +407,7 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
 // ------------------------------------------------------------------------------------------------------------------
 struct X3S2TParams {
   const unsigned short *X;       // small [N][3][Cx/8][P][Q][8]
-  const unsigned short *Wq;      // x3s2_pack_tr_kernel's layout
+  const unsigned short *Wq;      // x3s2_pack_kernel<64>'s layout
   const float *bias;             // [M] or null
   float *Y;                      // f32 [N][M][H][W] (OUT3 = false)
   unsigned short *YL;            // [N][3][M/8][H][W][8] (OUT3 = true)
@@ -384,33 +421,8 @@ struct X3S2TParams {
   float *dbpart;                 // MASKED: [ntiles][M]
   int ksplit, kper;              // split-K as in X3S2Params (k-steps of 16 channels); raw f32 accumulators at Y + range * ysplit
   long ysplit;
+  int linear;                    // as in X3S2Params
 };
-
-// Wq[m tile of 64][k-step of 16 c][tap row r][limb][tap column s][k-half][64 m][8 c]
-__global__ __launch_bounds__(256) void x3s2_pack_tr_kernel(X3S2Pack p) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // over [mt][ks][r][s][kh][64][8]
-  const long total = (long)p.M * p.C * 9;
-  if (idx >= total) return;
-  const int e = (int)(idx & 7), ml = (int)((idx >> 3) & 63), kh = (int)((idx >> 9) & 1);
-  long rest = idx >> 10;
-  const int s = (int)(rest % 3);
-  rest /= 3;
-  const int r = (int)(rest % 3);
-  rest /= 3;
-  const int chunks = p.C >> 4;
-  const int chunk = (int)(rest % chunks), mt = (int)(rest / chunks);
-  const int m = mt * 64 + ml, c = chunk * 16 + kh * 8 + e;
-  const float x = p.W[(long)m * p.sm + (long)c * p.sc + 3 * r + s];
-  const __bf16 h = (__bf16)x;
-  const float r1 = x - (float)h;
-  const __bf16 mi = (__bf16)r1;
-  const __bf16 lo = (__bf16)(r1 - (float)mi);
-  const long stage = ((long)mt * chunks + chunk) * 3 + r;
-  const long o = (stage * 9 + s) * 1024 + kh * 512 + ml * 8 + e;    // limb 0; limb l at + l * 3 * 1024
-  p.Wq[o] = __builtin_bit_cast(unsigned short, h);
-  p.Wq[o + 3 * 1024] = __builtin_bit_cast(unsigned short, mi);
-  p.Wq[o + 6 * 1024] = __builtin_bit_cast(unsigned short, lo);
-}
 
 #define X3T_BP 12                                          // image pieces per limb and stage: <= 768 units (2 k-halves)
 #define X3T_AP 6                                           // weight pieces per limb and stage: 3 taps x 2 k-halves x 64 m
@@ -443,6 +455,11 @@ __global__ __launch_bounds__(512, 1) void x3s2_tr_kernel(X3S2TParams p) {
   const unsigned voffa = (unsigned)((wave * 64 + lane) * 16);
 
   auto decode = [&](int lin, int &mt_, int &ptile_) {                // mt_ carries (m tile, k range): mt + MT * range
+    if (p.linear) {                                                  // weight-stationary walk (x3_plan in x3.hip): see X3S2Params::linear
+      mt_ = lin % (MT * KS);
+      ptile_ = lin / (MT * KS);
+      return ptile_ < p.ntiles;
+    }
     const int xcd = lin & 7, qq = lin >> 3;
     mt_ = qq % (MT * KS);
     ptile_ = xcd + 8 * (qq / (MT * KS));
@@ -938,16 +955,15 @@ __global__ __launch_bounds__(256) void x3_act_bwd_bias_nchw_kernel(const float *
 // Epilogue of a split-K launch (x3s2_fwd_kernel / x3s2_tr_kernel with ksplit > 1): v = sum of the `ns` raw partial outputs
 // part[s][N][C][HW] (f32) + bias, LeakyReLU (lrelu: max(v, v * lrelu)), optionally the fused mask of the layer in front
 // (v *= LeakyReLU'(ActY), ActY = hi limb of that layer's X3 output, + its bias-gradient partial sums), written as f32 NCHW (y) or
-// as limbs (yl).  grid = (C / 8, splits over images).
+// as limbs (yl).  grid = (C / 8, ranges of the flattened (image, pixel) space); dbpart[range][C].
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void x3_splitk_finish_kernel(const float *__restrict__ part, int ns, long sstride,
                                                                const float *__restrict__ bias, float lrelu,
                                                                const unsigned short *__restrict__ act_y, float act_slope,
                                                                float *__restrict__ y, unsigned short *__restrict__ yl, float *__restrict__ dbpart,
-                                                               int N, int C, int HW, int imgs_per_split) {
+                                                               int N, int C, int HW, long items_per_split) {
   __shared__ float red[4][8];
   const int cg = blockIdx.x, split = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = split * imgs_per_split, n1 = min(N, n0 + imgs_per_split);
   const long cgs = C >> 3, ls = cgs * HW * 8;
   float s[8], b8[8];
 #pragma unroll
@@ -955,9 +971,10 @@ __global__ __launch_bounds__(256) void x3_splitk_finish_kernel(const float *__re
     s[e] = 0.f;
     b8[e] = bias ? bias[cg * 8 + e] : 0.f;
   }
-  const long items = (long)(n1 - n0) * HW;                       // (image, pixel) pairs flattened: small maps keep every thread busy
-  for (long it = tid; it < items; it += 256) {
-    const int n = n0 + (int)(it / HW), u = (int)(it - (long)(n - n0) * HW);
+  // (image, pixel) pairs flattened and cut into gridDim.y ranges: small maps keep every thread busy, large ones every CU
+  const long it0 = (long)split * items_per_split, it1 = min((long)N * HW, it0 + items_per_split);
+  for (long it = it0 + tid; it < it1; it += 256) {
+    const int n = (int)(it / HW), u = (int)(it - (long)n * HW);
     const float *pp = part + ((long)n * C + cg * 8) * HW;
     const long ubase = ((long)n * 3 * cgs + cg) * HW;            // unit index of (n, limb 0, cg, pixel 0)
     float v[8];

@@ -18,7 +18,7 @@ DEFAULT_BUCKET_BYTES = 16 << 20
 
 # switches the library reads (csrc/igemm.hip, chwn.hip, c8.hip); values are fixed for the life of the process
 _NATIVE = ('LSPS_WINO', 'LSPS_WINO4_SPLIT', 'LSPS_FS2_CC', 'LSPS_WINO4W', 'LSPS_WINO4W_WAVES', 'LSPS_CHWN_GROUP', 'LSPS_C8W_QUEUE',
-           'LSPS_C8_STEM_BF16', 'LSPS_HIP_LIB')
+           'LSPS_C8_STEM_BF16', 'LSPS_X3_PLAN', 'LSPS_HIP_LIB')
 
 
 @dataclasses.dataclass(frozen=True)

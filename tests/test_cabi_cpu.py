@@ -43,6 +43,36 @@ def test_argument_validation_without_gpu():
     assert h.lsps_loss_workspace_bytes(10) > 0
 
 
+def test_x3_launch_plan_fills_the_chip_on_the_deep_discriminator_layers():
+    """The three-limb stride-2 kernels are persistent (one workgroup per CU) and walk (pixel tile, m tile, k range) units; with
+    the XCD walk alone the estimate-mode batch (128 + 16 samples) left five of eight XCDs idle on `model_S.3`'s dgrad (three
+    pixel tiles).  The plan (csrc/x3.hip: x3_plan) is computable without a GPU: deep layers split and take the linear walk,
+    large-map layers keep one range and the XCD walk, and no plan starts more workgroups than CUs."""
+    import ctypes
+    from lsps_amd import _lib
+    h = _lib.lib()
+
+    def plan(tr, N, C, H, K):
+        out = (ctypes.c_int * 4)()
+        assert h.lsps_x3_conv3x3s2_plan(tr, N, C, H, H, K, out) == 0, h.lsps_last_error()
+        return tuple(out)
+    # model_S.3 (lsps_nets.py:119-121: 1024 -> 2048, 4x4 -> 2x2) at N = 144: dgrad has 3 pixel tiles x 16 m tiles
+    ks, kper, linear, grid = plan(1, 144, 1024, 4, 2048)
+    assert linear == 1 and ks >= 4 and ks * kper >= 128 and 200 <= grid <= 256
+    ks, kper, linear, grid = plan(0, 144, 1024, 4, 2048)
+    assert linear == 1 and ks >= 2 and 200 <= grid <= 256
+    # the generator's down-sampling layer (64 -> 128 at 128x128, N = 256) and the 8-sample estimate-mode decoder: untouched
+    assert plan(0, 256, 64, 128, 128)[:3] == (1, 4, 0)
+    assert plan(1, 8, 128, 64, 256)[0] == 1            # ConvTranspose2d(256 -> 128) forward = dgrad of Conv2d(128 -> 256): 16.8 MB of output
+    for N in (1, 5, 16, 40, 144, 256, 384, 768):
+        for C, H, K in ((64, 64, 128), (128, 32, 256), (256, 16, 512), (512, 8, 1024), (1024, 4, 2048)):
+            for tr in (0, 1):
+                ks, kper, linear, grid = plan(tr, N, C, H, K)
+                nk = (K if tr else C) // 16
+                assert 1 <= ks <= 8 and (ks - 1) * kper < nk <= ks * kper and 1 <= grid <= 256, (tr, N, C, H, K, ks, kper, grid)
+    assert h.lsps_x3_conv3x3s2_plan(0, 4, 60, 32, 32, 128, (ctypes.c_int * 4)()) == -1      # C % 16 != 0
+
+
 def test_namespace_matches_reference_package():
     import lsps_amd.trainers as t
     # every public name of the reference's `from trainers import *` (probed list, SURVEY.md §8(b))
