@@ -1,5 +1,6 @@
 // C-ABI of the three-limb ("X3") stride-2 conv prototype (x3s2.h): f32-class arithmetic on the bf16 matrix pipe.
 #include <algorithm>
+#include <numeric>
 #include "common.h"
 #include "x3s2.h"
 
@@ -132,7 +133,7 @@ static int x3_plan_mode() {
 
 static int x3_device_cus();
 
-static X3Plan x3_plan(int ntiles, int MT, int nk, double out_mb) {
+static X3Plan x3_plan(int ntiles, int MT, int nk, double out_mb, bool tr) {
   const int cus = x3_device_cus() / 8 * 8;
   X3Plan best = {1, nk, 0, 0};
   if (x3_plan_mode() == 0) {
@@ -164,10 +165,26 @@ static X3Plan x3_plan(int ntiles, int MT, int nk, double out_mb) {
         groups = std::min<long>((long)(ntiles + 7) / 8 * 8 * MT * ks, cus) / 8;
         rounds = (units + groups - 1) / groups;
       }
-      double cost = rounds * (kper + fixed);
+      // operand bytes a unit pulls through its XCD's L2 per chunk (KB), divided by how many of the XCD's concurrent workgroups want
+      // the same bytes; beyond ~70 KB per chunk and CU (4.5 TB/s over 256 CUs at 4 us per chunk) the chunk takes longer.  Weights are
+      // 2.25 x the activations: 384 units of `model_S.3` with nothing shared would stream 2.7 GB of limbs per launch.
+      const double wkb = tr ? 55.3 : 110.6, akb = tr ? 24.6 : 49.2;
+      const long gpx = std::max<long>(1, linear ? groups / 8 : groups);      // workgroups per XCD
+      const long panels = (long)MT * ks;
+      double sw, sa;
+      if (linear) {
+        const long distinct = panels / std::gcd<long, long>(panels, 8);         // panels an XCD ever sees at one time
+        sw = std::min<double>(ntiles, std::max<double>(1., (double)gpx / distinct));
+        sa = std::max(1., MT / 8.);
+      } else {
+        sw = std::min<double>((ntiles + 7) / 8, std::max<double>(1., (double)gpx / panels));
+        sa = std::min<double>(MT, gpx);
+      }
+      const double slow = std::max(1., (wkb / sw + akb / sa) / 70.);
+      double cost = rounds * (kper * slow + fixed);
       if (ks > 1) cost += (8.0 + (2.0 * ks + 1.5) * out_mb / 2.5) / 5.2;      // partial sums: written, read, + the finish launch
-      if (linear) cost *= 1.03;                              // ties go to the walk that keeps an image's rows in one L2
-      if (ks > 1) cost *= 1.05;                              // ... and to the launch without partial sums
+      if (linear || ks > 1) cost *= 1.1;                     // the model ranks, it does not measure: leave the plain launch (one range, an
+                                                             // image's rows in one L2) only for a predicted gain of 10 %
       if (best.grid == 0 || cost < best_cost) {
         best_cost = cost;
         best.ks = ks; best.kper = kper; best.linear = linear;
@@ -249,7 +266,7 @@ static int x3s2_run_fwd(const void *big, const float *w, long sm, long sc, const
   p.act_slope = act_slope;
   p.dbpart = nullptr;
   const size_t pack_bytes = align_up((size_t)M * Cx * 9 * 3 * sizeof(unsigned short), 256);
-  const X3Plan plan = x3_plan(p.ntiles, M >> 7, Cx >> 4, 4e-6 * N * M * p.P * p.Q);
+  const X3Plan plan = x3_plan(p.ntiles, M >> 7, Cx >> 4, 4e-6 * N * M * p.P * p.Q, false);
   p.ksplit = plan.ks; p.kper = plan.kper; p.linear = plan.linear;
   p.ysplit = 0;
   if (p.ksplit > 1) {
@@ -327,7 +344,7 @@ static int x3s2_run_tr(const void *small, const float *w, long sm, long sc, cons
   p.act_slope = act_slope;
   p.dbpart = nullptr;
   const size_t pack_bytes = align_up((size_t)M * Cx * 9 * 3 * sizeof(unsigned short), 256);
-  const X3Plan plan = x3_plan(p.ntiles, M >> 6, Cx >> 4, 4e-6 * N * M * H * W);
+  const X3Plan plan = x3_plan(p.ntiles, M >> 6, Cx >> 4, 4e-6 * N * M * H * W, true);
   p.ksplit = plan.ks; p.kper = plan.kper; p.linear = plan.linear;
   p.ysplit = 0;
   if (p.ksplit > 1) {
@@ -442,9 +459,9 @@ size_t lsps_x3_conv3x3s2_workspace_bytes(int N, int C, int H, int W, int K) {
   x3s2_fwd_geom(N, C, H, W, K, &f);                                                   // (as a transposed conv's dgrad: tiles x K)
   need = std::max(need, pack + align_up(((size_t)f.ntiles + 64) * K * sizeof(float), 256) + 512);
   // split-K partial outputs (<= 8 ranges) + the finish kernel's bias-gradient partial sums (<= X3_FINISH_MAX_RANGES rows)
-  const int ksf = x3_plan(f.ntiles, K >> 7, C >> 4, 4e-6 * N * K * f.P * f.Q).ks;      // forward direction: out [N][K][P][Q]
+  const int ksf = x3_plan(f.ntiles, K >> 7, C >> 4, 4e-6 * N * K * f.P * f.Q, false).ks;      // forward direction: out [N][K][P][Q]
   if (ksf > 1) need = std::max(need, pack + align_up((size_t)ksf * N * K * f.P * f.Q * sizeof(float), 256) + ((size_t)X3_FINISH_MAX_RANGES + 64) * K * sizeof(float) + 512);
-  const int kst = x3_plan(q.ntiles, C >> 6, K >> 4, 4e-6 * N * C * H * W).ks;           // transposed direction: out [N][C][H][W]
+  const int kst = x3_plan(q.ntiles, C >> 6, K >> 4, 4e-6 * N * C * H * W, true).ks;           // transposed direction: out [N][C][H][W]
   if (kst > 1) need = std::max(need, pack + align_up((size_t)kst * N * C * H * W * sizeof(float), 256) + ((size_t)X3_FINISH_MAX_RANGES + 64) * C * sizeof(float) + 512);
   X3S2WParams wp;
   x3s2_wgrad_geom(N, K, C, H, W, &wp);
@@ -458,11 +475,11 @@ int lsps_x3_conv3x3s2_plan(int transposed, int N, int C, int H, int W, int K, in
   if (transposed) {
     X3S2TParams q;
     LSPS_CHECK_ARG(x3s2_tr_geom(N, K, H, W, C, &q), "x3 conv plan: unsupported geometry");
-    pl = x3_plan(q.ntiles, C >> 6, K >> 4, 4e-6 * N * C * H * W);
+    pl = x3_plan(q.ntiles, C >> 6, K >> 4, 4e-6 * N * C * H * W, true);
   } else {
     X3S2Params f;
     LSPS_CHECK_ARG(x3s2_fwd_geom(N, C, H, W, K, &f), "x3 conv plan: unsupported geometry");
-    pl = x3_plan(f.ntiles, K >> 7, C >> 4, 4e-6 * N * K * f.P * f.Q);
+    pl = x3_plan(f.ntiles, K >> 7, C >> 4, 4e-6 * N * K * f.P * f.Q, false);
   }
   plan[0] = pl.ks; plan[1] = pl.kper; plan[2] = pl.linear; plan[3] = pl.grid;
   return 0;
