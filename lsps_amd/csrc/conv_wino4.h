@@ -493,6 +493,15 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
     // InstanceNorm over the (n, k) plane = 64 tiles = the 32 lanes of this half in waves (wp, wt = 0) and (wp, wt = 1).
     // Two passes over the registers (mean, then centred sum of squares), each: 16-value lane sum, xor-shuffles inside
     // the 32-lane half, one LDS hand-off between the two waves.
+    // the residual's 16 float4 per lane are requested BEFORE the statistics: their latency runs under the two reduction passes
+    // (one workgroup per CU: nothing else covers an epilogue load)
+    f32x4 res[4][4];
+    if (p.norm == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int yy = 0; yy < 4; ++yy) res[i][yy] = *reinterpret_cast<const f32x4 *>(p.R + (ybase - p.Y) + (long)i * HW + yy * 32);
+    }
     __syncthreads();                             // phase-2 regions are read
     float *red = w4_lds;                         // [pass 2][wt 2][wp 4][half 2][i 4]
     float mean[4], rs[4];
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
           if (p.norm == 1 && p.slope >= 0.f) v = v > 0.f ? v : v * p.slope;
           o[x] = v;
         }
-        if (p.norm == 2) o += *reinterpret_cast<const f32x4 *>(p.R + (ym - p.Y) + yy * 32);
+        if (p.norm == 2) o += res[i][yy];
         *reinterpret_cast<f32x4 *>(ym + yy * 32) = o;
       }
     }

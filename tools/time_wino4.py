@@ -18,5 +18,7 @@ for N in [int(a) for a in (sys.argv[1:] or ['256'])]:
     fl = 2.0 * N * 1024 * 256 * 256 * 9
     ms = t_ms(lambda: ops.conv2d(x, w, None, 1, 1), 20)
     ms2 = t_ms(lambda: conv_in(x, w, None, 0.01), 20)
-    out += '  N=%d: %.3f ms %.0f TF (fused IN %.3f ms)' % (N, ms, fl / ms / 1e9, ms2)
+    res = torch.randn(N, 256, 32, 32, device=dev)
+    ms3 = t_ms(lambda: conv_in(x, w, res, -1.0), 20)
+    out += '  N=%d: %.3f ms %.0f TF (fused IN + LeakyReLU %.3f ms, fused IN + residual %.3f ms)' % (N, ms, fl / ms / 1e9, ms2, ms3)
 print(out)
