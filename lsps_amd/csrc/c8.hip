@@ -191,7 +191,7 @@ static int c8s2_pack(const float *w, int M, int C, long sm, long sc, int BM, voi
   pp.W = w;
   pp.Wq = (unsigned short *)slot;
   pp.M = M; pp.C = C; pp.BM = BM; pp.sm = sm; pp.sc = sc;
-  hipLaunchKernelGGL(c8s2_pack_kernel, dim3(ceil_div((long)M * C * 9, 256)), dim3(256), 0, st, pp);
+  hipLaunchKernelGGL(c8s2_pack_kernel, dim3(ceil_div((long)M * C / 8, 256)), dim3(256), 0, st, pp);
   LSPS_CHECK_LAUNCH("c8s2_pack");
   return 0;
 }
@@ -205,7 +205,9 @@ static int c8_colsum(const float *part, float *out, int C, int rows, float *scra
     part = scratch;
     rows = chunks;
   }
-  hipLaunchKernelGGL(c8_colsum_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, out, C, rows);
+  // the last <= 64 rows: the stage-1 kernel with ONE chunk (four row lanes per channel: 16 dependent loads instead of 64 —
+  // 15.7 -> 5 us per call, ~16 calls per config-5 step)
+  hipLaunchKernelGGL(c8_colsum_stage1_kernel, dim3(ceil_div(C, 64), 1), dim3(256), 0, st, part, out, C, rows, rows);
   LSPS_CHECK_LAUNCH("c8_colsum");
   return 0;
 }
@@ -644,7 +646,7 @@ int lsps_c8_act_bwd_bias(const void *dy, const void *y, void *g, float *db, int 
                      (unsigned short *)g, (float *)ws, N, C, HW, ips, slope);
   LSPS_CHECK_LAUNCH("c8_act_bwd_bias");
   if (db) {
-    hipLaunchKernelGGL(c8_colsum_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)ws, db, C, splits);
+    hipLaunchKernelGGL(c8_colsum_stage1_kernel, dim3(ceil_div(C, 64), 1), dim3(256), 0, st, (const float *)ws, db, C, splits, splits);
     LSPS_CHECK_LAUNCH("c8_colsum");
   }
   return 0;

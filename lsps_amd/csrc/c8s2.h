@@ -38,7 +38,7 @@ struct C8S2Params {
   float lrelu;                   // epilogue: v = max(v, v * lrelu) (1 = no activation; 0 <= slope <= 1)
   // dgrad entries with the PREVIOUS layer's LeakyReLU backward fused (the layer whose output this gradient belongs to):
   // y = y * (ActY > 0 ? 1 : act_slope) with ActY that layer's saved output (Y's shape), and dbpart[pixel tile][M] = the
-  // per-channel sums of the masked result over the workgroup's pixels (that layer's bias gradient, summed by c8_colsum_kernel)
+  // per-channel sums of the masked result over the workgroup's pixels (that layer's bias gradient, summed by c8_colsum_stage1_kernel)
   const unsigned short *ActY;
   float act_slope;
   float *dbpart;
@@ -51,23 +51,47 @@ struct C8S2Pack {
   long sm, sc;                   // element strides of m and of the reduction channel in W; tap t = 3 r + s at offset t
 };
 
-// Wq[m tile][chunk of 16 c][tap][k-half][BM][8 c]
+// Wq[m tile][chunk of 16 c][tap][k-half][BM][8 c].  One thread = the 8 channels x 9 taps of one (m, k-half): nine 16-byte stores,
+// contiguous over the BM threads of an (m tile, chunk, tap, k-half) (as x3s2_pack_kernel: one thread per ELEMENT took 60 us for the
+// deepest discriminator layer, twice per step)
 __global__ __launch_bounds__(256) void c8s2_pack_kernel(C8S2Pack p) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long total = (long)p.M * p.C * 9;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // over [mt][chunk][kh][BM]
+  const long total = (long)p.M * p.C >> 3;
   if (idx >= total) return;
-  const int e = (int)(idx & 7);
-  long rest = idx >> 3;
-  const int ml = (int)(rest % p.BM);
-  rest /= p.BM;
+  const int ml = (int)(idx % p.BM);
+  long rest = idx / p.BM;
   const int kh = (int)(rest & 1);
   rest >>= 1;
-  const int t = (int)(rest % 9);
-  rest /= 9;
   const int chunks = p.C >> 4;
   const int chunk = (int)(rest % chunks), mt = (int)(rest / chunks);
-  const int m = mt * p.BM + ml, c = chunk * 16 + kh * 8 + e;
-  p.Wq[idx] = __builtin_bit_cast(unsigned short, (__bf16)p.W[(long)m * p.sm + (long)c * p.sc + t]);
+  const int m = mt * p.BM + ml, c0 = chunk * 16 + kh * 8;
+  const float *src = p.W + (long)m * p.sm + (long)c0 * p.sc;
+  float x[8][9];
+  if (p.sc == 9 && !(reinterpret_cast<uintptr_t>(src) & 15)) {       // one 288-byte run
+    float v[72];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      const f32x4 q = reinterpret_cast<const f32x4 *>(src)[i];
+      v[4 * i] = q[0]; v[4 * i + 1] = q[1]; v[4 * i + 2] = q[2]; v[4 * i + 3] = q[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) x[e][t] = v[e * 9 + t];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) x[e][t] = src[(long)e * p.sc + t];
+  }
+  const long base = ((long)mt * chunks + chunk) * 9;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    bf16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (__bf16)x[e][t];
+    *reinterpret_cast<bf16x8 *>(p.Wq + ((((base + t) * 2 + kh) * p.BM + ml) << 3)) = h;
+  }
 }
 
 #define C8S2_OOB 0x80000000u
@@ -765,7 +789,7 @@ __global__ __launch_bounds__(512, 1) void c8s2_wgrad_kernel(C8S2WParams p) {
 // ------------------------------------------------------------------------------------------------------------------
 // LeakyReLU backward from the OUTPUT + the layer's bias gradient in one pass over C8 tensors (act_bwd_bias_kernel of
 // norm_act.hip in this layout): g = dy * (y > 0 ? 1 : slope), dbpart[split][c] = sum over the split's images and pixels of g.
-// grid = (C / 8, splits); the partial sums are added up by c8_colsum_kernel.
+// grid = (C / 8, splits); the partial sums are added up by c8_colsum_stage1_kernel.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void c8_act_bwd_bias_kernel(const unsigned short *__restrict__ dy, const unsigned short *__restrict__ y,
                                                               unsigned short *__restrict__ g, float *__restrict__ dbpart, int N, int C,
@@ -801,7 +825,8 @@ __global__ __launch_bounds__(256) void c8_act_bwd_bias_kernel(const unsigned sho
   if (tid < 8) dbpart[(long)split * C + cg * 8 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
-// part2[chunk][c] = sum of rows [chunk * rows_per_chunk, ...) of part[rows][C]: the first stage of a column sum over many rows
+// part2[chunk][c] = sum of rows [chunk * rows_per_chunk, ...) of part[rows][C]: a stage of a column sum over many rows (the last
+// stage: one chunk)
 // (per-workgroup bias-gradient partials: up to thousands of rows); grid (ceil(C / 64), chunks), thread = (row lane 0..3, channel)
 __global__ __launch_bounds__(256) void c8_colsum_stage1_kernel(const float *__restrict__ part, float *__restrict__ part2, int C, int rows,
                                                                int rows_per_chunk) {
@@ -814,14 +839,6 @@ __global__ __launch_bounds__(256) void c8_colsum_stage1_kernel(const float *__re
   red[rl][threadIdx.x & 63] = s;
   __syncthreads();
   if (rl == 0 && c < C) part2[(long)chunk * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
-
-__global__ __launch_bounds__(256) void c8_colsum_kernel(const float *__restrict__ part, float *__restrict__ out, int C, int splits) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int i = 0; i < splits; ++i) s += part[(long)i * C + c];
-  out[c] = s;
 }
 
 }  // namespace lsps
