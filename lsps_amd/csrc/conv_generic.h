@@ -577,44 +577,76 @@ __global__ __launch_bounds__(256) void pw1_dgrad_act_kernel(const float *__restr
     s[c] = sw[c] = 0.f;
     wv[c] = c0 + c < C ? w[c0 + c] : 0.f;
   }
-  for (int q = q0 + tid; q < q1; q += 256) {
-    const f32x4 g = gp[q];
-    sd += (g[0] + g[1]) + (g[2] + g[3]);
-    if (X3OUT) {
-      // one channel group (8 channels x this lane's 4 pixels) at a time: 8 loads in flight, then 12 stores of 16 bytes; the 16
-      // channels of the slice at once need 233 registers (one wave per SIMD: 0.53 ms against the f32 form's 0.30)
-      const long cgs = C >> 3, HW = (long)HW4 * 4, ls = cgs * HW * 8;
+  if (X3OUT) {
+    // Thread = pixels 4 qb + j * 256 + tid (j < 4) of the block's current 256 quads [qb, qb + 256): every load (4 bytes per lane) and
+    // every 16-byte limb store is DENSE over the lanes.  (With thread = one quad — 16-byte loads, but stores 64 bytes apart between
+    // lanes, four instructions to fill a line — the kernel moved 3.8 TB/s.)  One channel group at a time: 32 loads in flight, then
+    // 12 stores; all 16 channels of the slice at once need 233 registers.
+    const long cgs = C >> 3, HW = (long)HW4 * 4, ls = cgs * HW * 8;
+    const float *ys = y + ((long)n * C + c0) * HW, *gs = dy + (long)n * HW;
+    const long pend = (long)q1 * 4;
+    auto pass = [&](long pb, auto full_tag) {                   // pb: this lane's first pixel
+      constexpr bool FULL = decltype(full_tag)::value;         // all 1024 pixels of the pass exist: no guards, constant offsets
+      constexpr int NJ = FULL ? 4 : 1;                         // (the ragged last pass: one pixel per call, guarded)
+      float g[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        g[j] = (FULL || pb + j * 256 < pend) ? gs[pb + j * 256] : 0.f;
+        sd += g[j];
+      }
 #pragma unroll
       for (int grp = 0; grp < PW1_CS / 8; ++grp) {
-        f32x4 yv[8], oo[8];
+        float yv[8][NJ], oo[8][NJ];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) yv[k] = yp[(long)(grp * 8 + k) * HW4 + q];
+        for (int k = 0; k < 8; ++k) {
+          const float *yk = ys + (long)(grp * 8 + k) * HW + pb;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) yv[k][j] = (FULL || pb + j * 256 < pend) ? yk[j * 256] : 0.f;
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int c = grp * 8 + k;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = wv[c] * g[e];
-            oo[k][e] = yv[k][e] > 0.f ? v : v * slope;
+          for (int j = 0; j < NJ; ++j) {
+            const float v = wv[c] * g[j];
+            oo[k][j] = yv[k][j] > 0.f ? v : v * slope;
           }
-          s[c] += (oo[k][0] + oo[k][1]) + (oo[k][2] + oo[k][3]);
-          sw[c] += (yv[k][0] * g[0] + yv[k][1] * g[1]) + (yv[k][2] * g[2] + yv[k][3] * g[3]);
+          if constexpr (FULL) {
+            s[c] += (oo[k][0] + oo[k][1]) + (oo[k][NJ - 2] + oo[k][NJ - 1]);
+            sw[c] += (yv[k][0] * g[0] + yv[k][1] * g[1]) + (yv[k][NJ - 2] * g[NJ - 2] + yv[k][NJ - 1] * g[NJ - 1]);
+          } else {
+            s[c] += oo[k][0];
+            sw[c] += yv[k][0] * g[0];
+          }
         }
-        unsigned short *base = reinterpret_cast<unsigned short *>(dx) + (((long)n * 3 * cgs + ((c0 >> 3) + grp)) * HW + (long)q * 4) * 8;
+        unsigned short *base = reinterpret_cast<unsigned short *>(dx) + (((long)n * 3 * cgs + ((c0 >> 3) + grp)) * HW + pb) * 8;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v8[8];
+        for (int j = 0; j < NJ; ++j) {
+          if (FULL || pb + j * 256 < pend) {
+            float v8[8];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v8[k] = oo[k][e];
-          bf16x8 h, m, l;
-          split3(v8, h, m, l);
-          *reinterpret_cast<bf16x8 *>(base + e * 8) = h;
-          *reinterpret_cast<bf16x8 *>(base + ls + e * 8) = m;
-          *reinterpret_cast<bf16x8 *>(base + 2 * ls + e * 8) = l;
+            for (int k = 0; k < 8; ++k) v8[k] = oo[k][j];
+            bf16x8 h, m, l;
+            split3(v8, h, m, l);
+            *reinterpret_cast<bf16x8 *>(base + j * 2048) = h;
+            *reinterpret_cast<bf16x8 *>(base + ls + j * 2048) = m;
+            *reinterpret_cast<bf16x8 *>(base + 2 * ls + j * 2048) = l;
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);          // the next group's 32 loads stay behind this group's stores
       }
-      continue;
+    };
+    for (int qb = q0; qb < q1; qb += 256) {
+      if (qb + 256 <= q1) {                                     // uniform
+        pass((long)qb * 4 + tid, std::true_type());
+      } else {
+        for (int j = 0; j < 4; ++j) pass((long)qb * 4 + j * 256 + tid, std::false_type());
+      }
     }
+  }
+  for (int q = q0 + tid; !X3OUT && q < q1; q += 256) {
+    const f32x4 g = gp[q];
+    sd += (g[0] + g[1]) + (g[2] + g[3]);
     f32x4 yv[PW1_CS];
 #pragma unroll
     for (int c = 0; c < PW1_CS; ++c)                   // all loads of the slice in flight before the first store
