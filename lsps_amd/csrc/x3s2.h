@@ -606,9 +606,32 @@ __global__ __launch_bounds__(512, 1) void x3s2_tr_kernel(X3S2TParams p) {
     float sdb[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) sdb[e] = 0.f;
+    // MASKED: the mask operand (hi limb of the saved output: unit (n, limb 0, group, row 2p + a, column 2q + b), this lane's 8 bytes) of
+    // channel group rq + 1 is requested before group rq is processed: one workgroup per CU, nothing else covers an epilogue load
+    // (-3 ... -6 % per masked launch; all 32 pieces up front: 152 bytes of scratch)
+    u64 amk[4][2][2][2];                                          // [rq][a][j][b]
+    auto mask_fetch = [&](auto rq_tag) {
+      constexpr int rq = decltype(rq_tag)::value;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const long u0 = ((long)yn[j] * 3 * (p.M >> 3) + ((mt_c * 64 + wm * 32 + 8 * rq) >> 3)) * HWl + ypix[j] + (long)a * p.W;
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            amk[rq][a][j][b] = ypix[j] < 0 ? 0ull : reinterpret_cast<const u64 *>(p.ActY)[((u0 + b) << 1) + half];
+        }
+    };
+    if (MASKED) mask_fetch(std::integral_constant<int, 0>());
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       const int m8 = mt_c * 64 + wm * 32 + 8 * rq;                // channel group's first channel
+      if (MASKED) {
+        if (rq == 0) mask_fetch(std::integral_constant<int, 1>());
+        if (rq == 1) mask_fetch(std::integral_constant<int, 2>());
+        if (rq == 2) mask_fetch(std::integral_constant<int, 3>());
+        __builtin_amdgcn_sched_barrier(0);                        // ... and stays in front of group rq's stores
+      }
       f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) b4 = *reinterpret_cast<const f32x4 *>(p.bias + m8 + 4 * half);
 #pragma unroll
@@ -617,16 +640,9 @@ __global__ __launch_bounds__(512, 1) void x3s2_tr_kernel(X3S2TParams p) {
         for (int j = 0; j < 2; ++j) {
           if (ypix[j] < 0) continue;
           float v[2][4];                                          // [b][e]
-          u64 am[2] = {0ull, 0ull};
-          if (MASKED) {
-            // hi limb of the saved output: unit (n, limb 0, group, row 2p + a, column 2q + b), this lane's 8 bytes
-            const long u0 = ((long)yn[j] * 3 * (p.M >> 3) + (m8 >> 3)) * HWl + ypix[j] + (long)a * p.W;
-#pragma unroll
-            for (int b = 0; b < 2; ++b) am[b] = reinterpret_cast<const u64 *>(p.ActY)[((u0 + b) << 1) + half];
-          }
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
-            const bf16x4 mk = __builtin_bit_cast(bf16x4, am[b]);
+            const bf16x4 mk = __builtin_bit_cast(bf16x4, MASKED ? amk[rq][a][j][b] : 0ull);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float x = acc[a * 2 + b][j][rq * 4 + e] + b4[e];
