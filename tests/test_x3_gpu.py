@@ -172,13 +172,15 @@ def test_stem_writes_limbs(stride):
     assert _rel(y, ref) < TOL
 
 
-def test_output_head_dgrad_emits_limbs():
+@pytest.mark.parametrize("H", [64, 20, 128])
+def test_output_head_dgrad_emits_limbs(H):
     """lsps_pw1_dgrad_act_x3: the 1x1 head's input gradient with the LeakyReLU backward of the layer in front, written as limbs —
-    bit for bit the f32 entry's result, split."""
+    bit for bit the f32 entry's result, split.  (H = 20: 50 pixel quads per block, the kernel's ragged pass; 64 / 128: full
+    1024-pixel passes only.)"""
     _need_gpu()
     _lib, L, ops, dev, st = _env()
     torch.manual_seed(13)
-    N, C, H = 3, 64, 64
+    N, C = 3, 64
     dpre, w, y = torch.randn(N, 1, H, H, device=dev), torch.randn(C, device=dev), torch.randn(N, C, H, H, device=dev)
     ws, wsb = _lib.workspace(L.lsps_pw1_dgrad_act_workspace_bytes(N, C), dev)
     dx, db0, dw0 = torch.empty(N, C, H, H, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
