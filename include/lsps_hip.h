@@ -85,6 +85,25 @@ int         lsps_get_math_mode(void);
 int         lsps_set_winograd(int mode);
 int         lsps_get_winograd(void);
 
+/* Dispatch / experiment switches of the library, set by the host in ONE call (round 6: no `getenv` is left in the library;
+ * lsps_amd/options.py owns the LSPS_* environment, pushes this block when the library is loaded and whenever its options
+ * object changes, hashes it into the hipGraph signature and prints it in the bench line).  A field value of -1 means
+ * "keep the library's default" (the value in brackets).  `struct_size` = sizeof(LspsOptions) of the caller (ABI check).
+ * Not a per-call argument: the same process-wide scope as lsps_set_math_mode / lsps_set_winograd.              */
+typedef struct LspsOptions {
+  int struct_size;
+  int wino4_split;     /* [1] reduction-split F(4x4,3x3) launches for few-image passes without a backward (igemm.hip)   */
+  int fs2_cc;          /* [4] channel chunk (4 | 8) of the exact-f32 3x3 / stride-2 forward kernel                        */
+  int wino4w;          /* [1] F(4x4,3x3) weight gradient (0: F(2x2) / direct)                                             */
+  int wino4w_waves;    /* [8] waves per workgroup (4 | 8) of the F(4x4,3x3) weight-gradient kernel                        */
+  int chwn_group;      /* [1] batch-innermost trunk dgrad with positions grouped by tap count                             */
+  int c8w_queue;       /* [1] workgroups per CU the C8 weight-gradient grids aim at                                       */
+  int c8_stem_bf16;    /* [1] bf16-MFMA forms of the one-input-channel stems in bf16 mode                                 */
+  int x3_plan;         /* [1] per-launch plan (walk order, reduction ranges) of the three-limb stride-2 kernels; 0: plain */
+} LspsOptions;
+int         lsps_set_options(const LspsOptions *opt);
+int         lsps_get_options(LspsOptions *out);      /* the values in force (defaults resolved); out->struct_size is set */
+
 /* ---- Conv2d: replaces nn.Conv2d forward + autograd's convolution_backward -----------------
  * call sites: common_net.py:250 (LeakyReLUConv2d), :162-163 (LeakyINSResBlock.conv3x3),
  *             lsps_nets.py:123-124 (Post / D heads).

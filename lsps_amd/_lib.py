@@ -9,7 +9,14 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('LSPS_HIP_LIB', os.path.join(_HERE, 'liblsps_hip.so'))   # override: kernel A/B experiments
+LIB_PATH = os.path.join(_HERE, 'liblsps_hip.so')        # options.hip_lib (LSPS_HIP_LIB) overrides it: kernel A/B experiments
+
+
+class LspsOptions(ctypes.Structure):
+    """include/lsps_hip.h: struct LspsOptions (the library's dispatch switches; -1 = the library's default)."""
+    _fields_ = [('struct_size', c_int), ('wino4_split', c_int), ('fs2_cc', c_int), ('wino4w', c_int), ('wino4w_waves', c_int),
+                ('chwn_group', c_int), ('c8w_queue', c_int), ('c8_stem_bf16', c_int), ('x3_plan', c_int)]
+
 
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2, 3
 LOSS_L1, LOSS_L2, LOSS_SQ, LOSS_KLSD = 0, 1, 2, 3
@@ -24,6 +31,8 @@ _SIGNATURES = {
     'lsps_set_math_mode': (c_int, [c_int]),
     'lsps_set_winograd': (c_int, [c_int]),
     'lsps_get_winograd': (c_int, []),
+    'lsps_set_options': (c_int, [ctypes.POINTER(LspsOptions)]),
+    'lsps_get_options': (c_int, [ctypes.POINTER(LspsOptions)]),
     'lsps_get_math_mode': (c_int, []),
     'lsps_pack_cache_begin': (c_int, [_P, c_size_t]),
     'lsps_pack_cache_end': (c_int, []),
@@ -144,15 +153,38 @@ def lib():
         # torch must load ITS libamdhip64 first: liblsps_hip.so then binds to the same HIP runtime
         # (two runtimes in one process => "no ROCm-capable device" on the second one).
         import torch  # noqa: F401
-        if not os.path.exists(LIB_PATH):
+        from . import options
+        path = options.get().hip_lib or LIB_PATH
+        if not os.path.exists(path):
             raise LspsHipError("liblsps_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`"
-                               % LIB_PATH)
-        h = ctypes.CDLL(LIB_PATH)
+                               % path)
+        h = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(h, name)           # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
         _lib = h
+        # the library reads no environment variable: its switches come from the options object, at load and on every change
+        push_options(options.get())
+        rc = h.lsps_set_winograd(int(options.get().wino))
+        if rc != 0:
+            raise LspsHipError("LSPS_WINO=%r: %s" % (options.get().wino, h.lsps_last_error().decode()))
     return _lib
+
+
+def push_options(opt):
+    """lsps_set_options with the library's share of `opt` (lsps_amd/options.py: Options.native())."""
+    blk = LspsOptions(struct_size=ctypes.sizeof(LspsOptions), **opt.native())
+    rc = _lib.lsps_set_options(ctypes.byref(blk))
+    if rc != 0:
+        msg = _lib.lsps_last_error()
+        raise LspsHipError("lsps_set_options failed (rc=%d): %s" % (rc, msg.decode() if msg else ''))
+
+
+def native_options():
+    """What the library reports as in force (lsps_get_options): {field: int}."""
+    blk = LspsOptions()
+    check(lib().lsps_get_options(ctypes.byref(blk)), 'lsps_get_options')
+    return dict((f, int(getattr(blk, f))) for f, _ in LspsOptions._fields_ if f != 'struct_size')
 
 
 def check(rc, what):

@@ -11,12 +11,7 @@
 namespace lsps {
 
 static int c8_wgrad_queue() {                     // workgroups per CU the weight-gradient kernels' grids aim at (experiments)
-  static int q = 0;
-  if (!q) {
-    const char *e = getenv("LSPS_C8W_QUEUE");
-    q = e && atoi(e) > 0 ? atoi(e) : 1;             // one round of workgroups: half the partial sums of 2, measured faster (profiles/r3d)
-  }
-  return q;
+  return opts().c8w_queue;                          // default 1: one round of workgroups: half the partial sums of 2, measured faster (profiles/r3d)
 }
 
 static bool c8_geom_ok(int N, int C, int H, int W, int K) {
@@ -352,11 +347,7 @@ static int c8s2_run_wgrad(const void *small, const void *big, float *dw, int N, 
 #define C8SW_BLOCKS 512
 
 bool c8_stem_bf16_ok(int N, int H, int W, int K, int R, int S, int stride, int pad) {
-  static int on = -1;
-  if (on < 0) {
-    const char *e = getenv("LSPS_C8_STEM_BF16");
-    on = !(e && e[0] == '0');
-  }
+  const int on = opts().c8_stem_bf16;
   if (!on || N <= 0 || K != 64 || R > 7 || S > 7 || R < 1 || S < 1 || (stride != 1 && stride != 2) || pad < 0) return false;
   const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
   if (P <= 0 || (Q != 32 && Q != 64 && Q != 128) || (P % (128 / Q)) != 0) return false;

@@ -516,11 +516,7 @@ static int chwn_run_gemm(const float *A, const float *B, const float *bias, floa
   p.mode = mode;
   p.act = act;
   p.slope = slope;
-  static int group_env = -1;
-  if (group_env < 0) {
-    const char *e = getenv("LSPS_CHWN_GROUP");
-    group_env = (e && e[0] == '0') ? 0 : 1;
-  }
+  const int group_env = opts().chwn_group;
   // dgrad: positions grouped by tap count (see chwn_group_positions); maps of at least 4 x 4 positions (NB % 4 == 0)
   // (measured, tools/bench_chwn.py, profiles/r4s_chwn_grouped_dgrad.txt: 8x8 ... 32x32 input maps gain 8 - 15 % at N = 128 and 768;
   // on the 4x4 map — 9 groups — the lower occupancy costs more than the balance gives: per-position workgroups stay)

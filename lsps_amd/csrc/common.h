@@ -9,6 +9,9 @@ namespace lsps {
 
 void set_error(const char *fmt, ...);
 
+// the switches in force (lsps_set_options; defaults resolved, never -1).  Defined in igemm.hip.
+const LspsOptions &opts();
+
 #define LSPS_CHECK_ARG(cond, ...)            \
   do {                                       \
     if (!(cond)) {                           \

@@ -331,14 +331,25 @@ static bool f3x3_ok(int Cin, int H, int W, int R, int S, int st_, int pad) {
 // Winograd F(2x2,3x3) path of run_f3x3 (f32 mode): conv_wino.h.  Mode (lsps_set_winograd, initial value from LSPS_WINO):
 // 0 = never (direct kernel), 1 = grids that fill the chip (default), 2 = every eligible shape.
 // 3 / 4 = like 1 / 2 but F(2x2,3x3) only (the F(4x4,3x3) kernel of conv_wino4.h is not used).
-static int g_wino_mode = -1;
-static int wino_mode() {
-  if (g_wino_mode < 0) {
-    const char *e = getenv("LSPS_WINO");
-    g_wino_mode = (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : 1;
-  }
-  return g_wino_mode;
+#define FS2_DEFAULT_CC 4        // channel chunk of the exact-f32 3x3 / stride-2 forward kernel
+#define W4W_DEFAULT_WAVES 8     // waves per workgroup of the F(4x4,3x3) weight-gradient kernel
+static LspsOptions default_options() {
+  LspsOptions d;
+  d.struct_size = (int)sizeof(LspsOptions);
+  d.wino4_split = 1;
+  d.fs2_cc = FS2_DEFAULT_CC;
+  d.wino4w = 1;
+  d.wino4w_waves = W4W_DEFAULT_WAVES;
+  d.chwn_group = 1;
+  d.c8w_queue = 1;
+  d.c8_stem_bf16 = 1;
+  d.x3_plan = 1;
+  return d;
 }
+static LspsOptions g_opts = default_options();
+const LspsOptions &opts() { return g_opts; }
+static int g_wino_mode = 1;
+static int wino_mode() { return g_wino_mode; }
 // One workgroup per CU (512 threads, 226 VGPRs) and no reduction split: a single workgroup takes ~75 us for 256 input
 // channels, so below ~96 workgroups the direct kernel with its 2-row tiles and channel split is faster (measured on
 // 256 -> 256 @ 32x32, tools/sweep_wino.py: N = 4: 0.063 vs 0.079 ms, N = 6: 0.089 vs 0.078, N = 16: 0.158 vs 0.081)
@@ -364,11 +375,7 @@ static bool wino4_ok(int N, int Cin, int H, int M) {
 static int wino4_split(int N, int Cin, int H, int M) {
   const int mode = wino_mode();
   if ((mode != 1 && mode != 2) || g_math_mode != 0 || H != 32 || (M % 32) != 0 || (Cin % 64) != 0) return 0;
-  static int off = -1;
-  if (off < 0) {
-    const char *e = getenv("LSPS_WINO4_SPLIT");
-    off = (e && e[0] == '0') ? 1 : 0;
-  }
+  const int off = !opts().wino4_split;
   const long wgs = (long)N * (M / 32);
   if (off || wgs >= 128) return 0;
   int ks = (int)(256 / wgs);
@@ -685,7 +692,6 @@ static int run_f3x3(const float *in, const float *W, const float *bias, float *o
   return 0;
 }
 
-#define FS2_DEFAULT_CC 4
 static bool f3x3s2_ok(int Cb, int Hb, int Wb, int Cs, int Hs, int Ws, int R, int S, int st_, int pad) {
   return R == 3 && S == 3 && st_ == 2 && pad == 1 && Hb == 2 * Hs && Wb == 2 * Ws && (Ws % 32) == 0 && (Hs % 4) == 0 &&
          (Cb % F3_CC) == 0 && Cs >= 128 &&
@@ -757,11 +763,7 @@ static int run_f3x3s2(const float *in, const float *W, const float *bias, float 
   FS2Params p;
   memset(&p, 0, sizeof(p));
   const int2 *gtab_unused;
-  static int cc = 0;                       // LSPS_FS2_CC=4|8: channel-chunk variant of the f32 kernel (A/B comparisons)
-  if (!cc) {
-    const char *e = getenv("LSPS_FS2_CC");
-    cc = (e && e[0] == '8') ? 8 : ((e && e[0] == '4') ? 4 : FS2_DEFAULT_CC);
-  }
+  const int cc = opts().fs2_cc;            // 4 | 8: channel-chunk variant of the f32 kernel (A/B comparisons)
   const int ccu = g_math_mode == 1 ? 8 : cc;
   int rc = launch_pack(W, ws, M, Mp, RED, RED, l, sm, sc, 4 * Hs * Ws, 2 * Ws, st, &p.Wp, &gtab_unused, &p.zero, ccu);
   if (rc) return rc;
@@ -1190,7 +1192,6 @@ static int run_wino_w(const float *dy, const float *x, float *dW, int N, int C, 
 // possible (one split per XCD group).  LSPS_WINO4W=0 keeps the F(2x2,3x3) kernel (A/B comparisons).
 // 8 waves (KH = 1: two waves per SIMD, 9 accumulator tiles each) measured 6 - 7 % faster than 4 (KH = 2) in the step at every
 // batch size from 32 to 256 per domain (round 2, profiles/r2t_wino4w_waves.txt)
-#define W4W_DEFAULT_WAVES 8
 static int wino4_w_splits(int M, int C, int ntr) {
   int s = 256 / ((M / 64) * (C / 32));
   if (s > ntr) s = ntr;
@@ -1201,11 +1202,7 @@ static size_t wino4_w_ws_bytes(int N, int M, int C, int H) {
   return (size_t)wino4_w_splits(M, C, N * H / 4) * 36 * M * C * sizeof(float);
 }
 static bool wino4_w_ok(int N, int C, int H, int M) {
-  static int enabled = -1;
-  if (enabled < 0) {
-    const char *e = getenv("LSPS_WINO4W");
-    enabled = !(e && e[0] == '0');
-  }
+  const int enabled = opts().wino4w;
   const int mode = wino_mode();
   if (!enabled || mode == 0 || mode >= 3 || g_math_mode != 0 || (H % 4) != 0 || (C % 32) != 0 || (M % 64) != 0) return false;
   return mode == 2 || (long)N * (H / 4) >= 64;
@@ -1229,11 +1226,7 @@ static int run_wino4_w(const float *dy, const float *x, float *dW, int N, int C,
   p.ntr = N * H / 4;
   const int splits = wino4_w_splits(M, C, p.ntr);
   p.per_split = ceil_div(p.ntr, splits);
-  static int waves = 0;
-  if (!waves) {                            // LSPS_WINO4W_WAVES=4|8: workgroup shape of the kernel (A/B comparisons)
-    const char *e = getenv("LSPS_WINO4W_WAVES");
-    waves = (e && e[0] == '8') ? 8 : ((e && e[0] == '4') ? 4 : W4W_DEFAULT_WAVES);
-  }
+  const int waves = opts().wino4w_waves;   // 4 | 8: workgroup shape of the kernel (A/B comparisons)
   int rc = wino4_launch_wgrad(p, splits, dW, waves, st);
   if (rc) return rc;
   note_kernel("wino4_w3x3_kernel");
@@ -1603,6 +1596,32 @@ int lsps_set_winograd(int mode) {
 }
 
 int lsps_get_winograd(void) { return lsps::wino_mode(); }
+
+int lsps_set_options(const LspsOptions *o) {
+  LSPS_CHECK_ARG(o && o->struct_size == (int)sizeof(LspsOptions), "set_options: struct_size %d != %d (header / library mismatch)",
+                 o ? o->struct_size : -1, (int)sizeof(LspsOptions));
+  LSPS_CHECK_ARG(o->fs2_cc == -1 || o->fs2_cc == 4 || o->fs2_cc == 8, "set_options: fs2_cc must be 4 or 8");
+  LSPS_CHECK_ARG(o->wino4w_waves == -1 || o->wino4w_waves == 4 || o->wino4w_waves == 8, "set_options: wino4w_waves must be 4 or 8");
+  LSPS_CHECK_ARG(o->c8w_queue == -1 || (o->c8w_queue >= 1 && o->c8w_queue <= 8), "set_options: c8w_queue must be 1 .. 8");
+  LspsOptions d = lsps::default_options();
+  auto pick = [](int v, int dflt, bool flag) { return v == -1 ? dflt : (flag ? (v != 0) : v); };
+  d.wino4_split = pick(o->wino4_split, d.wino4_split, true);
+  d.fs2_cc = pick(o->fs2_cc, d.fs2_cc, false);
+  d.wino4w = pick(o->wino4w, d.wino4w, true);
+  d.wino4w_waves = pick(o->wino4w_waves, d.wino4w_waves, false);
+  d.chwn_group = pick(o->chwn_group, d.chwn_group, true);
+  d.c8w_queue = pick(o->c8w_queue, d.c8w_queue, false);
+  d.c8_stem_bf16 = pick(o->c8_stem_bf16, d.c8_stem_bf16, true);
+  d.x3_plan = pick(o->x3_plan, d.x3_plan, false);
+  lsps::g_opts = d;
+  return 0;
+}
+
+int lsps_get_options(LspsOptions *out) {
+  LSPS_CHECK_ARG(out, "get_options: null");
+  *out = lsps::opts();
+  return 0;
+}
 
 int lsps_pack_cache_begin(void *arena, size_t bytes) {
   LSPS_CHECK_ARG(arena && bytes >= ((size_t)1 << 20) && (((uintptr_t)arena) & 255) == 0, "pack_cache_begin: need a 256-byte aligned arena of >= 1 MiB");

@@ -122,14 +122,7 @@ struct X3Plan {
   int ks, kper, linear, grid;
 };
 
-static int x3_plan_mode() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char *e = getenv("LSPS_X3_PLAN");
-    mode = e ? atoi(e) : 1;
-  }
-  return mode;
-}
+static int x3_plan_mode() { return opts().x3_plan; }
 
 static int x3_device_cus();
 

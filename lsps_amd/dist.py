@@ -325,36 +325,58 @@ def agree_all(flag, device=None):
     return bool(int(t.item()))
 
 
-_oob_round = [0]
+_oob_attempts = {}
 
 
-def agree_all_oob(flag, timeout_s=60.0):
+def agree_all_oob(flag, timeout_s=60.0, tag='capture'):
     """True only if `flag` is true on EVERY rank, agreed through the process group's rendezvous STORE (TCPStore counters): no
     collective of the backend is issued, so nothing is added to RCCL's stream or its watchdog's work list.  This is what the
     capture decision of a data-parallel step needs: the ranks must take the same branch — a rank that stays eager
     while the others capture would, one call later, issue collectives the replaying ranks do not — and the agreement itself
-    must not be an eager RCCL collective (it would have to be drained again).  Every rank calls this the same number of times
-    in the same order (one call per capture attempt), which makes the per-process round counter a common key.  Identity in a
-    single process; a store error or time-out answers False on this rank AND poisons the round for the others."""
+    must not be an eager RCCL collective (it would have to be drained again).
+
+    The verdict has ONE writer: every rank adds its vote, then the first rank that either sees all `n` votes or
+    runs out of time publishes 'yes' / 'no' with `compare_set` on an empty verdict key, and EVERY rank — the publisher
+    included — returns what that key holds.  A rank that arrives in the gap between another rank's last poll and its
+    time-out therefore reads the same 'no' the timed-out rank wrote, instead of counting `n` votes for itself; and a verdict
+    once written is never revised.  The key is derived from `tag` (the caller's graph signature) and a per-tag attempt
+    counter, not from one process-wide call counter: ranks call this once per capture attempt OF THAT SIGNATURE in the same
+    order, so one diverged or failed agreement cannot shift the keys of every later one.  Identity in a single process; a
+    store error answers False on this rank (and, where the store still works, publishes 'no' for the others)."""
     import time
+    import hashlib
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return bool(flag)
-    _oob_round[0] += 1
-    key = 'lsps_agree_%d' % _oob_round[0]
+    tag_key = hashlib.sha1(repr(tag).encode()).hexdigest()[:16]
+    attempt = _oob_attempts[tag_key] = _oob_attempts.get(tag_key, 0) + 1
+    key = 'lsps_agree_%s_%d' % (tag_key, attempt)
     n = dist.get_world_size()
+    store = None
     try:
         from torch.distributed.distributed_c10d import _get_default_store
         store = _get_default_store()
         store.add(key + '_ok', 1 if flag else 0)
         store.add(key + '_n', 1)
         t0 = time.time()
-        while store.add(key + '_n', 0) < n:
-            if time.time() - t0 > timeout_s:
-                store.add(key + '_ok', -n)           # poison: whoever reads later sees < n
-                return False
-            time.sleep(0.002)
-        return store.add(key + '_ok', 0) == n
+        while True:
+            verdict = store.compare_set(key + '_verdict', '', '')       # read without writing ('' while nobody decided)
+            if verdict:
+                return verdict == b'yes'
+            if store.add(key + '_n', 0) >= n:
+                mine = 'yes' if store.add(key + '_ok', 0) == n else 'no'
+            elif time.time() - t0 > timeout_s:
+                mine = 'no'
+            else:
+                time.sleep(0.002)
+                continue
+            # single writer: only an EMPTY verdict is replaced; the answer is whatever the key holds afterwards
+            return store.compare_set(key + '_verdict', '', mine) == b'yes'
     except Exception:                              # noqa: BLE001  (no store: nothing can be agreed => never capture)
+        try:
+            if store is not None:
+                store.compare_set(key + '_verdict', '', 'no')
+        except Exception:                          # noqa: BLE001
+            pass
         return False
 
 
@@ -370,6 +392,33 @@ def all_reduce_mean_scalars(values, device):
     t = torch.tensor(values, dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return (t / world()).tolist()
+
+
+def global_first(tensors, k=4):
+    """The first `k` samples of the GLOBAL batch of every tensor in `tensors` (each this rank's contiguous shard along dim 0,
+    equal shard sizes), identical on every rank — what `images[0:4]` means in the single-process reference
+    (/root/reference/src/trainers/lsps_trainer.py:238) when the batch is sharded.  Shard >= k samples: they all live on rank 0,
+    ONE broadcast of the concatenated slices (same trailing shape) or one per tensor.  Shard < k (e.g. global 16 over 8 ranks):
+    the first ceil(k / shard) ranks hold them — one all-gather of the whole (small) shards, cut to k.  Identity when inactive."""
+    if not active():
+        return [t[0:k] for t in tensors]
+    n = tensors[0].size(0)
+    if n >= k:
+        same = all(t.shape[1:] == tensors[0].shape[1:] and t.dtype == tensors[0].dtype for t in tensors)
+        if same:
+            first = torch.cat([t[0:k] for t in tensors], 0)
+            dist.broadcast(first, 0)
+            return list(first.split(k, 0))
+        out = [t[0:k].contiguous() for t in tensors]
+        for t in out:
+            dist.broadcast(t, 0)
+        return out
+    out = []
+    for t in tensors:
+        parts = [torch.empty_like(t) for _ in range(world())]
+        dist.all_gather(parts, t.contiguous())
+        out.append(torch.cat(parts, 0)[0:k])
+    return out
 
 
 def shard_batch(t, dim=0):

@@ -209,9 +209,15 @@ def _fuse_enabled():
     return options.get().fuse_act
 
 
-def _fusable(prev):
+def x3_fuse_enabled():
+    """ONE predicate for both sides of a fused LeakyReLU backward on C8 / X3 tensors (the X3 stem paired with its
+    consumer on `fuse_act` alone while the consumer's backward also asked for `c8_fuse_act`)."""
     o = options.get()
-    return prev is not None and prev.slope >= 0 and o.c8_fuse_act and o.fuse_act
+    return o.c8_fuse_act and o.fuse_act
+
+
+def _fusable(prev):
+    return prev is not None and prev.slope >= 0 and x3_fuse_enabled()
 
 
 def _act_backward(L, dy, y, act, slope, want_db, channels, ws, wsb, st):
@@ -1018,7 +1024,7 @@ def _x3_grad_operand(L, dy, y, slope, own, want_db, channels, out_f32, st):
 
 def x3_stem_ok(x, w, stride, pad):
     """7x7 one-input-channel stem writing its activation straight as X3 (f32 math mode; the consumer must be an X3 layer)."""
-    if get_math_mode() != 'f32' or not options.get().x3 or not options.get().fuse_act or x.dim() != 4 or x.dtype != torch.float32:
+    if get_math_mode() != 'f32' or not options.get().x3 or not x3_fuse_enabled() or x.dim() != 4 or x.dtype != torch.float32:
         return False
     N, C, H, W = x.shape
     K, C2, R, S = w.shape

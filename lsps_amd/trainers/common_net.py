@@ -119,7 +119,7 @@ def run_layers(layers, x, noise=None):
     def x3_next(i, y_shape):
         """Does layer i + 1 take the X3 output (shape as f32 NCHW: `y_shape`) of layer i?  Then layer i writes X3 and the pair
         shares an ActHolder (layer i + 1's dgrad applies layer i's LeakyReLU backward)."""
-        if i + 1 >= len(layers) or not ops.options.get().fuse_act:
+        if i + 1 >= len(layers) or not ops.x3_fuse_enabled():
             return False
         n = layers[i + 1]
         probe = torch.empty(y_shape, dtype=torch.float32, device='meta')

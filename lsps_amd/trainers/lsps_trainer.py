@@ -14,6 +14,7 @@ unchanged.  Differences, none of which changes a result:
   * keyword-only `noise=` arguments inject the random draws for parity tests.
 """
 import os
+import pickle as _pickle
 
 import numpy as np
 import torch
@@ -149,6 +150,7 @@ class _GraphedUpdate(object):
 class LSPSTrainer(nn.Module):
     def __init__(self, hyperparameters):
         super(LSPSTrainer, self).__init__()
+        ops.options.warn_if_env_changed()     # LSPS_* set after `import lsps_amd` are NOT in force until options.reload_env()
         lr = hyperparameters['lr']
         self.dis = _net(hyperparameters['dis'])
         self.gen = _net(hyperparameters['gen'])
@@ -280,8 +282,10 @@ class LSPSTrainer(nn.Module):
         # math switches of the library, the process options as a whole (lsps_amd/options.py: a frozen, hashable object — a
         # switch added there is part of the signature by construction) and the arenas' addresses
         sig = (name, _flatten_tensors((args, kwargs), tensors), self.gen.training, self.dis.training, self.vae.training,
-               self.map.training, ops.get_winograd(), ops.get_math_mode(), ops.options.get(),
-               tuple(int(o.arena.flat_p.data_ptr()) for o in (self.dis_opt, self.gen_opt, self.vae_opt) if o.arena is not None))
+               self.map.training, ops.get_winograd(), ops.get_math_mode(), ops.options.get())
+        oob_tag = sig                            # the rank-independent part: key of the ranks' capture agreement (no addresses)
+        sig = sig + (tuple(int(o.arena.flat_p.data_ptr()) for o in (self.dis_opt, self.gen_opt, self.vae_opt)
+                           if o.arena is not None),)
         if name == 'post_update':
             # a post_update captured while the generator's panels are frozen holds no pack launches for them (they were cache
             # hits): it is only valid while that cache is — same generator epoch — and such graphs of older epochs can never be
@@ -316,7 +320,7 @@ class LSPSTrainer(nn.Module):
             # everywhere (a rank that stayed eager alone would issue, one call later, an agreement collective the replaying
             # ranks do not: ADVICE r4), and the agreement must not itself be RCCL work that needs draining: it goes through
             # the rendezvous store (dist.agree_all_oob).
-            if not lsps_dist.agree_all_oob(lsps_dist.drain_watchdog()):
+            if not lsps_dist.agree_all_oob(lsps_dist.drain_watchdog(), tag=oob_tag):
                 return eager(self, *args, **kwargs)
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
@@ -531,18 +535,10 @@ class LSPSTrainer(nn.Module):
         elif mode == 1:
             terms_reg.append(regression(self.dis.regress_b, images_b, labels_b, noise.get('vae_b')))
         else:
-            first_a, first_b = images_a[0:4], images_b[0:4]                       # :238 — only the first 4 samples
-            if lsps_dist.active():
-                # exact global-batch parity: every rank evaluates the SAME (global first-4) feature term
-                na = first_a.size(0)                                              # < 4 when the per-rank batch is
-                if first_a.shape[1:] == first_b.shape[1:]:
-                    first = torch.cat((first_a, first_b), 0)                      # ONE broadcast of the 2 x na images
-                    torch.distributed.broadcast(first, 0)
-                    first_a, first_b = first[:na], first[na:]
-                else:                                                             # input_dim_a != input_dim_b
-                    first_a, first_b = first_a.contiguous(), first_b.contiguous()
-                    torch.distributed.broadcast(first_a, 0)
-                    torch.distributed.broadcast(first_b, 0)
+            # :238 — only the first 4 samples OF THE GLOBAL BATCH: under data parallelism every rank evaluates the SAME feature
+            # term (exact global-batch parity), wherever those samples live (dist.global_first: rank 0 alone when the shard
+            # holds >= 4, the first ranks' shards otherwise)
+            first_a, first_b = lsps_dist.global_first((images_a, images_b), 4)
             if ops.options.get().est_merge:
                 # Round 5: ONE pass of the discriminator over [regression samples | the 16 feature samples] (SharedDis.regress_feats).
                 # The generator pass on the first 4 + 4 samples has no consumer but that pass, so nothing is left to overlap it
@@ -656,27 +652,42 @@ class LSPSTrainer(nn.Module):
     def _load(path):
         return torch.load(path, map_location='cpu')
 
+    # what a rank may fail with when ITS copy of the snapshot is missing or unreadable (no shared filesystem, a file another
+    # rank is still writing): torch.load on a truncated zip raises RuntimeError('PytorchStreamReader failed ...'), a cut
+    # pickle UnpicklingError / EOFError.  Anything else is a configuration error (state-dict key or shape mismatch).
+    _ABSENT = (IndexError, FileNotFoundError, OSError, EOFError, _pickle.UnpicklingError)
+
+    @classmethod
+    def _snapshot_absent(cls, ex):
+        if isinstance(ex, cls._ABSENT):
+            return True
+        return isinstance(ex, RuntimeError) and ('PytorchStreamReader' in str(ex) or 'zip archive' in str(ex)
+                                                 or 'unexpected EOF' in str(ex))
+
     def resume(self, snapshot_prefix, idx=-1, load_opt=False, est=False):
         """Under data parallelism the outcome is rank 0's: a rank that does not see the snapshot (no shared filesystem, a
-        half-written file) still enters the same broadcasts as the others and ends up with rank 0's weights and count."""
+        half-written file) still enters the same collectives as the others and ends up with rank 0's weights and count.
+        EVERY rank records whatever its local load raised and then enters the same two agreements (a rank that
+        raises alone leaves the others blocked in a broadcast until the launcher kills them):
+        1. rank 0's outcome — if rank 0 failed, all ranks raise together;
+        2. whether any OTHER rank failed with a configuration error (not a missing / unreadable file) — then all ranks
+           raise together too; a rank whose copy was merely absent adopts rank 0's weights in `sync_replicas()`."""
         err = None
         try:
             iterations = self._resume_local(snapshot_prefix, idx, load_opt, est)
-        except (IndexError, FileNotFoundError, OSError, EOFError) as ex:
-            # the snapshot is not there / not readable on THIS rank.  Single process / rank 0: the reference's behaviour
-            # (helpers.get_model_list raises on an empty directory); another rank must not leave rank 0 alone in the
-            # broadcasts below just because ITS disk holds nothing.  Anything else (a state-dict key or shape mismatch, a
-            # corrupt pickle) is a configuration error and is raised on the rank that saw it (ADVICE r4).
+        except Exception as ex:                     # noqa: BLE001  (kept and re-raised below, on every rank together)
             if lsps_dist.world() == 1:
-                raise
+                raise                               # single process: the reference's behaviour (helpers.get_model_list)
             err, iterations = ex, 0
         if lsps_dist.world() > 1:
-            # rank 0's outcome decides, and every rank learns it BEFORE the weight broadcasts: if rank 0 failed, all raise
-            # together instead of blocking in sync_replicas() until the launcher kills them
             ok0, iterations = lsps_dist.agree_from_rank0((err is None, iterations))
             if not ok0:
                 raise err if (err is not None and lsps_dist.rank() == 0) else RuntimeError(
                     "resume(): rank 0 could not load the snapshot '%s'" % snapshot_prefix)
+            config_error = err is not None and not self._snapshot_absent(err)
+            if not lsps_dist.agree_all(not config_error):
+                raise err if config_error else RuntimeError(
+                    "resume(): another rank could not apply the snapshot '%s' (state-dict mismatch)" % snapshot_prefix)
         self.sync_replicas()
         return iterations
 

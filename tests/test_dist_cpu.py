@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size 2 over gloo.  The product's data-parallel machinery
+"""N>1 path on CPU: world_size 2 and 8 over gloo.  The product's data-parallel machinery
 (lsps_amd.optim.FlatArena + lsps_amd.dist.GradReducer) is backend-agnostic; here it is driven with the
 CPU oracle as the compute (tests may use the oracle) and checked against a single-process run on the
 global batch: averaged shard gradients == global-batch gradients (InstanceNorm has no batch statistics,
@@ -22,6 +22,27 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+WORLDS = (2, 8)       # 8 = BASELINE config 4's world size: the same code paths at the real rank count
+
+
+def _spawn(target, world, args, n_results, timeout=300):
+    """Runs `target(rank, world, port, *args, out)` in `world` spawned processes; returns `n_results` queue items."""
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (out,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = [out.get(timeout=timeout) for _ in range(n_results)]
+    finally:
+        for p in procs:
+            p.join(timeout=90)
+    for p in procs:
+        assert p.exitcode == 0, [q.exitcode for q in procs]
+    return got
 
 
 def _dis_grads(hp, sds, batch, noise, arena_cls=None, reducer_cls=None, bucket_bytes=1 << 16):
@@ -57,13 +78,13 @@ def _worker(rank, world, port, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     from lsps_amd import dist as ldist
     from lsps_amd.optim import FlatArena
     try:
         hp = cases.hp_for('tiny')
         sds = cases.make_weights(hp, lsps_ref)
-        N = 4
+        N = max(4, world)                                   # world 8: one sample per domain and rank
         b = cases.make_inputs(N)
         lat = cases.latent_shape(hp, 2 * N)
         nz = cases.noise(lat, 99)
@@ -84,21 +105,13 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_data_parallel_gradients_match_global_batch():
-    ctx = mp.get_context('spawn')
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = out.get(timeout=300)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+@pytest.mark.parametrize('world', WORLDS)
+def test_data_parallel_gradients_match_global_batch(world):
+    res, = _spawn(_worker, world, (), 1)
     assert res['err'] < 1e-4, res
     assert res['nbuckets'] >= 3                       # several buckets at this bucket size
     assert sum(res['early']) >= res['nbuckets'] - 2   # buckets were launched DURING backward (overlap path)
-    assert res['vals'] == [0.5, 2.0]
+    assert res['vals'] == [(world - 1) / 2.0, 2.0]    # mean over ranks of (rank, 2)
     assert not all(res['touched'])                    # Post head untouched -> skipped by Adam, not all-reduced
 
 
@@ -137,7 +150,7 @@ def _product_step_worker(rank, world, port, out):
     from lsps_amd import options
     options.reload_env()                    # the switches are read once per process, at import (lsps_amd/options.py)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     try:
         from lsps_amd import dist as ldist
         from lsps_amd.optim import FlatArena
@@ -198,17 +211,9 @@ def _product_step_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_product_step_learns_expected_gradients_and_overlaps_all_updates():
-    ctx = mp.get_context('spawn')
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_product_step_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = out.get(timeout=300)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+@pytest.mark.parametrize('world', WORLDS)
+def test_product_step_learns_expected_gradients_and_overlaps_all_updates(world):
+    res, = _spawn(_product_step_worker, world, (), 1)
     assert res['same'], "rank 0's weights were not broadcast"
     assert res['steps'] == [3], res['steps']                       # Adam step counts follow rank 0 too
     rep = res['report']
@@ -218,8 +223,8 @@ def test_product_step_learns_expected_gradients_and_overlaps_all_updates():
         assert n0 == n1 >= 3, (sig, n0, n1)
         assert e0 == 0, "first step of a signature: nothing known yet, everything goes at finish()"
         assert e1 >= n1 - 1, (sig, e1, n1)                         # learned: buckets go out DURING backward
-        assert scal == 0.5                                          # scalars: mean over ranks of (0, 1)
-        assert rep[(sig, 'err')] < 1e-5
+        assert scal == (world - 1) / 2.0                            # scalars: mean over ranks of rank
+        assert rep[(sig, 'err')] < 1e-5 * world
     assert rep[('gen', 0)][0] == 0 and rep[('gen', 1)][0] >= rep[('gen', 1)][1] - 1, rep
 
 
@@ -390,13 +395,46 @@ def _resume_worker(rank, world, port, root, out):
         if rank == 0:                                           # only rank 0 holds a snapshot (no shared filesystem)
             torch.save(tr._dense_state(tr.gen), os.path.join(mine, 'pre_gen_%08d.pkl' % 7000))
             torch.save(tr._dense_state(tr.dis), os.path.join(mine, 'pre_dis_%08d.pkl' % 7000))
+        elif rank == 1:
+            # a HALF-WRITTEN file on this rank: torch.load raises RuntimeError (zip reader) / UnpicklingError, not OSError —
+            # the rank must still enter the agreements and adopt rank 0's weights
+            whole = os.path.join(mine, 'whole.pkl')
+            torch.save(tr._dense_state(tr.gen), whole)
+            blob = open(whole, 'rb').read()
+            os.remove(whole)
+            for name in ('pre_gen_%08d.pkl' % 7000, 'pre_dis_%08d.pkl' % 7000):
+                with open(os.path.join(mine, name), 'wb') as f:
+                    f.write(blob[:len(blob) // 3])
         dist.barrier()
         assert tr.gpu is None                                   # resume BEFORE cuda(), as the reference's driver calls it
         it = tr.resume(os.path.join(mine, 'pre'), idx=-1, load_opt=True)
+        w = torch.cat([p.detach().reshape(-1).double() for p in tr.gen.parameters()]).sum().reshape(1)
+        lo, hi = w.clone(), w.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same = bool(torch.equal(lo, hi))
         flags = (ldist.agree_all(True), ldist.agree_all(rank == 0), ldist.drain_watchdog())
         # the out-of-band agreement of the capture decision (rendezvous store, no collective of the backend: ADVICE r4)
         oob = (ldist.agree_all_oob(True), ldist.agree_all_oob(rank == 0), ldist.agree_all_oob(rank == 1), ldist.agree_all_oob(True))
-        out.put((rank, it, flags, oob))
+        # a rank that arrives after another rank's time-out must read THAT rank's verdict, and the next agreement of
+        # another signature must still rendezvous (per-tag attempt counters, single-writer verdict)
+        import time
+        if rank == world - 1:
+            time.sleep(1.5)
+        late = ldist.agree_all_oob(True, timeout_s=0.4, tag=('late',))
+        dist.barrier()
+        after = (ldist.agree_all_oob(True, tag=('late',)), ldist.agree_all_oob(True, tag=('other', 3)))
+        # a CONFIGURATION error on a rank other than 0 (a state dict of another architecture): every rank raises, none hangs
+        if rank == 1:
+            torch.save({'encode_A.0.model.0.weight': torch.zeros(3, 3)}, os.path.join(mine, 'pre_gen_%08d.pkl' % 7000))
+            torch.save(tr._dense_state(tr.dis), os.path.join(mine, 'pre_dis_%08d.pkl' % 7000))
+        dist.barrier()
+        try:
+            tr.resume(os.path.join(mine, 'pre'), idx=-1)
+            raised = None
+        except RuntimeError as e:
+            raised = type(e).__name__ + ':' + str(e)[:60]
+        out.put((rank, it, flags, oob, same, late, after, raised))
     except Exception as e:                                       # the parent would otherwise wait for its timeout
         import traceback
         out.put((rank, 'error', repr(e) + traceback.format_exc()))
@@ -405,28 +443,68 @@ def _resume_worker(rank, world, port, root, out):
         dist.destroy_process_group()
 
 
-def test_resume_before_cuda_agrees_on_rank0s_iteration_count(tmp_path):
-    ctx = mp.get_context('spawn')
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_resume_worker, args=(r, 2, port, str(tmp_path), out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = sorted(out.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert [g[1] for g in got] == [7000, 7000], got             # rank 1 found nothing locally and still continues at 7000
+@pytest.mark.parametrize('world', WORLDS)
+def test_resume_before_cuda_agrees_on_rank0s_iteration_count(tmp_path, world):
+    got = sorted(_spawn(_resume_worker, world, (str(tmp_path),), world, timeout=180))
+    assert all(g[1] != 'error' for g in got), got
+    assert [g[1] for g in got] == [7000] * world, got           # ranks without a (readable) snapshot still continue at 7000
     assert all(g[2] == (True, False, True) for g in got), got   # agree_all = AND over ranks; gloo has no watchdog to drain
     assert all(g[3] == (True, False, False, True) for g in got), got   # the same answer on every rank, round after round
+    # (g[4]: the weights themselves are broadcast by cuda() -> sync_replicas(); before cuda() resume() only agrees on the count)
+    assert len(set(g[5] for g in got)) == 1, got                # the late arrival and the timed-out ranks agree ...
+    assert got[0][5] is False                                   # ... on the verdict of the rank that timed out
+    assert all(g[6] == (True, True) for g in got), got          # and later agreements still rendezvous
+    assert all(g[7] is not None for g in got), got              # the configuration error is raised on EVERY rank
 
 
-def test_estimate_first4_broadcast_slices_by_the_real_count():
-    """post_update's data-parallel broadcast of the first images must not assume 4 per rank."""
+def _global_first_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        from lsps_amd import dist as ldist
+        res = {}
+        # (global batch, what the case is): the first 4 on rank 0 only / spread over the first ranks / fewer than 4 in total
+        for name, gb in (('rank0_only', 8 * world), ('exactly_4_per_rank', 4 * world), ('spread', 2 * world),
+                         ('one_per_rank', world)):
+            a = torch.arange(gb * 6, dtype=torch.float32).reshape(gb, 1, 2, 3)
+            b = -torch.arange(gb * 6, dtype=torch.float32).reshape(gb, 1, 2, 3)
+            fa, fb = ldist.global_first((ldist.shard_batch(a), ldist.shard_batch(b)), 4)
+            k = min(4, gb)
+            res[name] = bool(torch.equal(fa, a[:k]) and torch.equal(fb, b[:k]))
+        # different trailing shapes (input_dim_a != input_dim_b): one collective per tensor
+        a = torch.arange(8. * world).reshape(8 * world, 1)
+        c = torch.arange(16. * world).reshape(8 * world, 2)
+        fa, fc = ldist.global_first((ldist.shard_batch(a), ldist.shard_batch(c)), 4)
+        res['mixed_shapes'] = bool(torch.equal(fa, a[:4]) and torch.equal(fc, c[:4]))
+        out.put((rank, res))
+    except Exception as e:
+        import traceback
+        out.put((rank, 'error: ' + repr(e) + traceback.format_exc()))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', WORLDS)
+def test_estimate_first4_are_the_global_first4_wherever_they_live(world):
+    """post_update(mode >= 2) runs the generator on `images[0:4]` of the GLOBAL batch (reference lsps_trainer.py:238).  Sharded:
+    rank 0 holds them when the shard has >= 4 samples (config 4: 128 per rank); with 16 samples over 8 ranks they are spread
+    over ranks 0 and 1 — every rank must still see the same four."""
+    got = _spawn(_global_first_worker, world, (), world, timeout=120)
+    for rank, res in got:
+        assert isinstance(res, dict) and all(res.values()), (rank, res)
     import inspect
     import lsps_amd.trainers.lsps_trainer as lt
-    src = inspect.getsource(lt.LSPSTrainer.post_update)
-    assert 'first[:na], first[na:]' in src and 'first[0:4], first[4:8]' not in src
+    assert 'global_first((images_a, images_b), 4)' in inspect.getsource(lt.LSPSTrainer.post_update)
+
+
+def test_global_first_single_process_is_a_plain_slice():
+    from lsps_amd import dist as ldist
+    a = torch.arange(12.).reshape(6, 2)
+    fa, = ldist.global_first((a,), 4)
+    assert torch.equal(fa, a[:4])
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -475,7 +553,9 @@ def _multi_pass_worker(rank, world, port, out):
         (sum((p @ x).sum() for p in ps[:4]) + sum((p @ x).pow(2).sum() for p in ps[2:])).backward()
         ref = torch.cat([p.grad.reshape(-1) for p in ps])
         dist.all_reduce(ref)
-        out.put((rank, [dict(r, g=bool(torch.equal(r['g'], ref))) for r in res]))
+        # two ranks: a + b is one rounding whatever the chunking; eight: the ring's summation order depends on the buffer cut
+        same = torch.equal if world == 2 else (lambda a, b: torch.allclose(a, b, rtol=1e-5, atol=1e-4))
+        out.put((rank, [dict(r, g=bool(same(r['g'], ref))) for r in res]))
     except Exception as e:
         import traceback
         out.put((rank, 'error', repr(e) + traceback.format_exc()))
@@ -484,17 +564,9 @@ def _multi_pass_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_reducer_counts_accumulations_of_a_multi_pass_step():
-    ctx = mp.get_context('spawn')
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_multi_pass_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = sorted(out.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+@pytest.mark.parametrize('world', WORLDS)
+def test_reducer_counts_accumulations_of_a_multi_pass_step(world):
+    got = sorted(_spawn(_multi_pass_worker, world, (), world, timeout=180))
     for rank, res in got:
         assert res != 'error', got
         first, second, third = res

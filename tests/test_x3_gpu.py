@@ -242,8 +242,10 @@ def test_layer_chains_match_the_f32_kernels(what, monkeypatch):
         m.to(dev)
     res = []
     probe = None
-    for gmac in ('1e9', '0'):                                   # exact-f32 kernels, then the three-limb family
-        monkeypatch.setattr(ops.options, '_current', ops.options.from_env({'LSPS_X3_MIN_GMAC': gmac}))
+    # exact-f32 kernels, then the three-limb family; then the family with LSPS_C8_FUSE_ACT=0 (the X3 stem used to pair
+    # with its consumer on `fuse_act` alone and its backward raised when the consumer took the unfused branch)
+    for gmac, fuse in (('1e9', '1'), ('0', '1'), ('0', '0')):
+        monkeypatch.setattr(ops.options, '_current', ops.options.from_env({'LSPS_X3_MIN_GMAC': gmac, 'LSPS_C8_FUSE_ACT': fuse}))
         for m in layers:
             for p in m.parameters():
                 p.grad = None
@@ -256,13 +258,14 @@ def test_layer_chains_match_the_f32_kernels(what, monkeypatch):
         names = ops.kernel_log_end()
         assert any(k.startswith('x3s2_') for k in names) == (gmac == '0'), names
         res.append([out.detach().clone(), xx.grad.clone()] + [p.grad.clone() for m in layers for p in m.parameters()])
-    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5 * float(res[0][0].abs().max())
-    for i, (a, b) in enumerate(zip(res[1][1:], res[0][1:])):
-        d, am = (a - b).abs().double().flatten(), float(b.abs().max())
-        q = float(torch.quantile(d[:: max(1, d.numel() // 1000000)], 0.5))
-        assert q <= 2e-5 * am + 1e-12, (a.shape, q, am)
-        # ONE flipped mask at 128 x 128 changes ~0.3 % of the input gradient's elements by ~3 % each = 1.6e-3 of its L2 norm
-        # (measured: 1.4e-3 with one flip); the parameter gradients sum over every pixel of only 3 samples here and see it at ~1e-3
-        # (measured 1.15e-3 on the first transposed conv's weight).  A wrong tap, mask or scale would show at 0.1 - 1.
-        l2 = 5e-3 if i == 0 else 3e-3
-        assert float(d.norm()) <= l2 * float(b.double().norm()) + 1e-12, (a.shape, float(d.norm()), float(b.double().norm()))
+    for k in (1, 2):
+        assert float((res[0][0] - res[k][0]).abs().max()) <= 2e-5 * float(res[0][0].abs().max())
+        for i, (a, b) in enumerate(zip(res[k][1:], res[0][1:])):
+            d, am = (a - b).abs().double().flatten(), float(b.abs().max())
+            q = float(torch.quantile(d[:: max(1, d.numel() // 1000000)], 0.5))
+            assert q <= 2e-5 * am + 1e-12, (a.shape, q, am)
+            # ONE flipped mask at 128 x 128 changes ~0.3 % of the input gradient's elements by ~3 % each = 1.6e-3 of its L2 norm
+            # (measured: 1.4e-3 with one flip); the parameter gradients sum over every pixel of only 3 samples here and see it at ~1e-3
+            # (measured 1.15e-3 on the first transposed conv's weight).  A wrong tap, mask or scale would show at 0.1 - 1.
+            l2 = 5e-3 if i == 0 else 3e-3
+            assert float(d.norm()) <= l2 * float(b.double().norm()) + 1e-12, (a.shape, float(d.norm()), float(b.double().norm()))
