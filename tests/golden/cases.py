@@ -517,6 +517,103 @@ def run_n16_cases(A, shapes_mod, n=16):
     return R
 
 
+def run_trajectory(A, config, shapes_mod, n=4, n_pre=30, n_est=30, held_out=16, cadence=5, graphs=False, perturb=0.0):
+    """a TRAINING TRAJECTORY, not two iterations.  The reference's loop (/root/reference/src/depth_train.py:140-166):
+    `n_pre` pretrain iterations (`dis_update` -> `gen_update`, both schedulers stepped every `cadence` iterations: the driver's
+    1000, scaled) and then `n_est` estimate iterations (`post_update(mode 3)`, the discriminator's scheduler every `cadence`: the
+    driver's 100) on the SAME trainer, three different seeded batches in rotation, every random draw injected.  The schedulers
+    are fast-forwarded to step 197 first (as after 197 000 iterations), so that MultiStepLR's first milestone (200: lr x 0.5,
+    lsps_trainer.py:32-34) falls INSIDE the trajectory and the halved rate reaches Adam on both sides.  Then the A12 read-out
+    (depth_train.py:200-253) of the trained regressor on `held_out` unseen samples.  Returns every loss / accuracy scalar per
+    iteration, the learning rates seen, and the read-out.  `perturb`: relative noise on the initial weights (calibration of
+    how fast two f32 trajectories drift apart by themselves)."""
+    import warnings
+    hp = hp_for(config)
+    sds = make_weights(hp, shapes_mod)
+    if perturb:
+        rs = np.random.RandomState(77)
+        sds = dict((net, OrderedDict((k, (v * (1.0 + perturb * rs.standard_normal(v.shape))).astype(v.dtype)) for k, v in sd.items()))
+                   for net, sd in sds.items())
+    tr = A.make_trainer(hp, sds)
+    A.set_train(tr, True)
+    if graphs:
+        tr.use_graphs(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')                 # "lr_scheduler.step() before optimizer.step()"
+        for _ in range(197):
+            tr.dis_sch.step()
+            tr.gen_sch.step()
+    R = OrderedDict()
+    zd = hp['vae']['z_dim']
+    lat2, lat1, lat8 = latent_shape(hp, 2 * n), latent_shape(hp, n), latent_shape(hp, 2 * min(4, n))
+    batches = []
+    for s in range(3):
+        xa, la, ca = synth.make_batch(n, 5000 + 2 * s)
+        xb, lb, cb = synth.make_batch(n, 5001 + 2 * s)
+        batches.append(dict(xa=xa, la=la, ca=ca, xb=xb, lb=lb, cb=cb))
+    lrs = []
+    for it in range(n_pre):
+        if (it + 1) % cadence == 0:                     # depth_train.py:154-156
+            tr.dis_sch.step()
+            tr.gen_sch.step()
+        b = batches[it % 3]
+        A.dis_update(tr, b, hp, noise(lat2, 11000 + it))
+        A.gen_update(tr, b, hp, (noise(lat2, 12000 + it), noise(lat1, 13000 + it), noise(lat1, 14000 + it)))
+        R['traj.pre.it%03d' % it] = A.scalars(tr)
+        lrs.append((float(tr.dis_opt.param_groups[0]['lr']), float(tr.gen_opt.param_groups[0]['lr'])))
+    for it in range(n_est):
+        if (it + 1) % cadence == 0:                     # depth_train.py:163-164
+            tr.dis_sch.step()
+        b = batches[it % 3]
+        A.post_update(tr, b, 3, hp, noise(lat8, 15000 + it), noise((n, zd), 16000 + it, 0.05), noise((n, zd), 17000 + it, 0.05))
+        R['traj.est.it%03d' % it] = dict((k, v) for k, v in A.scalars(tr).items() if k.startswith('dis_'))
+        lrs.append((float(tr.dis_opt.param_groups[0]['lr']), float(tr.gen_opt.param_groups[0]['lr'])))
+    # A12 on held-out samples with the TRAINED regressor
+    xb, lb, cb = synth.make_batch(held_out, 6001)
+    getattr(tr.dis, 'eval', lambda: None)()        # the product's is an nn.Module; the oracle's net has no mode
+    torch = A.torch
+    with torch.no_grad():
+        _, post, _ = tr.dis.regress_b(A.T(xb))
+        pose = A.N(tr.vae.decode(post)).reshape(held_out, -1)
+    cube = np.array([300.0, 300.0, 300.0], np.float32)
+    idx = np.array([0, 3, 6, 9, 12, 15, 18, 21, 24, 25, 27, 30, 31, 32])
+    gt = lb.reshape(held_out, -1, 3)[:, idx] * (cube[0] / 2.) + cb.reshape(held_out, 1, 3)
+    pr = pose.reshape(held_out, -1, 3)[:, idx] * (cube[0] / 2.) + cb.reshape(held_out, 1, 3)
+    err = np.sqrt(np.square(gt - pr).sum(axis=2))
+    return dict(scalars=R, lrs=lrs, pose=pose, err=err, worst_joint=np.argmax(err, axis=1),
+                mean_err=float(np.nanmean(np.nanmean(err, axis=1))), frames_within_40=int((np.nanmax(err, axis=1) <= 40).sum()),
+                dis=A.params(tr, 'dis'))
+
+
+def compare_trajectories(got, ref, rtol=1e-3, growth=10.0):
+    """Every scalar of iteration `it` (counted over both phases) within rtol * (1 + it / growth) of the reference's, relative to
+    max(|reference|, the scalar's largest magnitude over the trajectory * 1e-2) — accuracies and vanishing losses are not held to a
+    relative bound of their own tiny value.  Returns (failures, worst ratio of error to allowance, where)."""
+    keys = list(ref['scalars'])
+    assert list(got['scalars']) == keys
+    scale = {}
+    for k in keys:
+        for name, v in ref['scalars'][k].items():
+            scale[name] = max(scale.get(name, 0.0), abs(float(v)))
+    bad, worst, where = [], 0.0, None
+    for it, k in enumerate(keys):
+        allow = rtol * (1.0 + it / growth)
+        for name, v in ref['scalars'][k].items():
+            g = float(got['scalars'][k][name])
+            if name.endswith('_acc'):
+                # a count of >= 0.5 decisions over a handful of outputs of an untrained discriminator (they sit AT 0.5: dis_ad_loss
+                # = 4 ln 2): one decision may legitimately fall the other way; more than one of the 2n would be a real difference
+                r = abs(g - float(v)) / 0.26
+            else:
+                den = max(abs(float(v)), 1e-2 * scale[name], 1e-12)
+                r = abs(g - float(v)) / den / allow
+            if r > worst:
+                worst, where = r, (k, name, g, float(v))
+            if r > 1.0 or not np.isfinite(g):
+                bad.append((k, name, g, float(v)))
+    return bad, worst, where
+
+
 def run_expand_cases(A, shapes_mod):
     """Round 4 (golden_expand.npz): `SharedDis` with the optional `n_expand_layer` key (lsps_nets.py:93,116-118): ONE stride-1
     3x3 LeakyReLUConv2d in front of the stride-2 trunk, tiny width (front 4 -> 8 channels, expand 8 -> 16 on 32 x 32, trunk

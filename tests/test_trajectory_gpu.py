@@ -1,0 +1,61 @@
+"""the HIP trainer against the CPU oracle over a TRAINING TRAJECTORY — the reference's loop
+(/root/reference/src/depth_train.py:140-166: `dis_update` -> `gen_update` for n iterations with both MultiStepLR schedulers on the
+driver's cadence, then `post_update(mode 3)` with the discriminator's) — instead of the two iterations every golden case stops at,
+followed by the joint read-out (A12) of the TRAINED regressor on held-out samples.  Every random draw is injected on both sides.
+Bound (north_star: 1e-3 rel fp32): every loss scalar of iteration `it` within 1e-3 * (1 + it / 10) of the oracle's; the read-out's
+joints within 1e-3 with the identical worst joint per frame."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import lsps_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _adapter():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import lsps_amd.trainers as prod
+    return cases.NativeAdapter(prod, 'cuda')
+
+
+def _check(got, ref, what):
+    assert got['lrs'] == ref['lrs'], "learning rates seen by the optimizers differ"
+    bad, worst, where = cases.compare_trajectories(got, ref, rtol=1e-3, growth=10.0)
+    print(what, "worst error / allowance %.3f at %s" % (worst, where,))
+    assert not bad, "%s: %d scalars outside 1e-3 (1 + it/10); first: %s" % (what, len(bad), bad[:6])
+    assert np.abs(got['pose'] - ref['pose']).max() <= 1e-3 * np.abs(ref['pose']).max(), what
+    assert (got['worst_joint'] == ref['worst_joint']).all(), what
+    assert got['frames_within_40'] == ref['frames_within_40'], what
+    assert abs(got['mean_err'] - ref['mean_err']) <= 1e-3 * ref['mean_err'], what
+
+
+def test_tiny_width_trajectory_eager_and_graphed_against_the_oracle():
+    """Tiny width, 4 samples per domain, 30 pretrain + 30 estimate3 iterations; the HIP trainer once eager and once with
+    `use_graphs(True)` (the scheduler's new rate must reach the replayed Adam step: the milestone falls at pretrain iteration 14)."""
+    A = _adapter()
+    torch.set_num_threads(8)
+    O = cases.NativeAdapter(lsps_ref, 'cpu', trainer_kwargs=dict(literal=False))
+    ref = cases.run_trajectory(O, 'tiny', lsps_ref)
+    assert len(set(ref['lrs'])) >= 2, "the milestone did not fall inside the trajectory"
+    eager = cases.run_trajectory(A, 'tiny', lsps_ref)
+    _check(eager, ref, 'eager')
+    graphed = cases.run_trajectory(A, 'tiny', lsps_ref, graphs=True)
+    _check(graphed, ref, 'graphed')
+    # and the two product runs with each other (same kernels, replayed): tighter
+    bad, worst, where = cases.compare_trajectories(graphed, eager, rtol=1e-4, growth=10.0)
+    assert not bad, (worst, where)
+
+
+def test_full_width_trajectory_against_the_oracle():
+    """Full width (exps/nnyu.yaml nets), 4 samples per domain, 5 + 5 iterations, scheduler cadence 2 (milestone inside)."""
+    A = _adapter()
+    torch.set_num_threads(max(1, (__import__('os').cpu_count() or 2) // 2))
+    O = cases.NativeAdapter(lsps_ref, 'cpu', trainer_kwargs=dict(literal=False))
+    kw = dict(n=4, n_pre=5, n_est=5, held_out=16, cadence=2)
+    ref = cases.run_trajectory(O, 'full', lsps_ref, **kw)
+    assert len(set(ref['lrs'])) >= 2
+    got = cases.run_trajectory(A, 'full', lsps_ref, **kw)
+    _check(got, ref, 'full width')

@@ -62,9 +62,13 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void probe(float *out, int 
         for (int j = 0; j < NV; ++j) valu(x, a, b, j);
       }
     } else {
-      auto T = [&]() {
+      auto T = [&]() {                      // chunks of 65 (a full unroll of 390+ ops is refused and x[] would go to scratch)
+        static_assert(MODE == 0 || NV % 65 == 0, "phase modes: NV in multiples of 65");
+#pragma unroll 1
+        for (int c = 0; c < NV / 65; ++c) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) valu(x, a, b, j);
+          for (int j = 0; j < 65; ++j) valu(x, a, b, j);
+        }
       };
       auto M = [&]() {
 #pragma unroll
@@ -117,42 +121,21 @@ void run(const char *what) {
 }
 
 int main() {
-  // (1) bare MFMA rate, independent and dependent accumulators
-  run<256, 0, 0, 0, 8, 8>("bare");
-  run<256, 0, 0, 0, 8, 2>("bare");
-  run<256, 0, 0, 0, 8, 1>("bare, one accumulator");
-  run<256, 1, 0, 0, 8, 8>("bare");
-  run<256, 1, 0, 0, 8, 2>("bare");
-  run<256, 1, 0, 0, 8, 1>("bare, one accumulator");
+  // (1) bare MFMA rate
   run<512, 0, 0, 0, 8, 8>("bare");
-  run<512, 1, 0, 0, 8, 8>("bare");
-  // (2) fine interleave
-  run<256, 0, 0, 4, 8, 8>("fine");
-  run<256, 0, 0, 8, 8, 8>("fine");
-  run<256, 0, 0, 12, 8, 8>("fine");
-  run<256, 0, 0, 16, 8, 8>("fine");
-  run<512, 0, 0, 4, 8, 8>("fine");
-  run<512, 0, 0, 8, 8, 8>("fine");
-  run<512, 0, 0, 12, 8, 8>("fine");
   run<512, 0, 0, 14, 8, 8>("fine");
-  run<512, 0, 0, 16, 8, 8>("fine");
-  run<512, 0, 0, 14, 8, 2>("fine");
-  run<512, 1, 0, 4, 8, 8>("fine");
-  run<512, 1, 0, 7, 8, 8>("fine");
-  run<512, 1, 0, 8, 8, 8>("fine");
-  run<512, 1, 0, 7, 8, 2>("fine");
-  run<256, 1, 0, 7, 8, 8>("fine");
-  // (3) phases: 390 VALU then 54 K=8 MFMAs (one 8-channel step of a (position block, tile half) wave), 780 / 54 K=16
-  run<512, 1, 1, 390, 54, 2>("phases free");
-  run<512, 1, 2, 390, 54, 2>("phases lockstep");
-  run<512, 1, 3, 390, 54, 2>("phases ping-pong");
+  run<512, 0, 0, 7, 8, 8>("fine");
+  // (3) phases, K=16: 780 VALU + 54 MFMAs = one 16-channel step of a (position block, tile half) wave that transforms all 8 of its
+  // lane's channels; 390 + 54 = the transform shared by two k blocks (each wave half the channels, V through LDS)
   run<512, 0, 1, 780, 54, 2>("phases free");
   run<512, 0, 2, 780, 54, 2>("phases lockstep");
   run<512, 0, 3, 780, 54, 2>("phases ping-pong");
-  run<256, 1, 1, 390, 54, 2>("phases, one wave");
-  // half the VALU (a transform shared by two k blocks)
-  run<512, 1, 1, 195, 54, 2>("phases free, half VALU");
+  run<256, 0, 1, 780, 54, 2>("phases, one wave");
   run<512, 0, 1, 390, 54, 2>("phases free, half VALU");
+  run<512, 0, 2, 390, 54, 2>("phases lockstep, half VALU");
   run<512, 0, 3, 390, 54, 2>("ping-pong, half VALU");
+  run<256, 0, 1, 390, 54, 2>("one wave, half VALU");
+  run<512, 0, 1, 195, 54, 2>("phases free, quarter VALU");
+  run<512, 0, 3, 195, 54, 2>("ping-pong, quarter VALU");
   return 0;
 }
