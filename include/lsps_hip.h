@@ -100,6 +100,7 @@ typedef struct LspsOptions {
   int c8w_queue;       /* [1] workgroups per CU the C8 weight-gradient grids aim at                                       */
   int c8_stem_bf16;    /* [1] bf16-MFMA forms of the one-input-channel stems in bf16 mode                                 */
   int x3_plan;         /* [1] per-launch plan (walk order, reduction ranges) of the three-limb stride-2 kernels; 0: plain */
+  int x3_ring;         /* [0] three-limb forward kernel with a 3-deep image ring and counted waits (round 6 experiment)    */
 } LspsOptions;
 int         lsps_set_options(const LspsOptions *opt);
 int         lsps_get_options(LspsOptions *out);      /* the values in force (defaults resolved); out->struct_size is set */

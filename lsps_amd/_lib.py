@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'liblsps_hip.so')        # options.hip_lib (LSPS_
 class LspsOptions(ctypes.Structure):
     """include/lsps_hip.h: struct LspsOptions (the library's dispatch switches; -1 = the library's default)."""
     _fields_ = [('struct_size', c_int), ('wino4_split', c_int), ('fs2_cc', c_int), ('wino4w', c_int), ('wino4w_waves', c_int),
-                ('chwn_group', c_int), ('c8w_queue', c_int), ('c8_stem_bf16', c_int), ('x3_plan', c_int)]
+                ('chwn_group', c_int), ('c8w_queue', c_int), ('c8_stem_bf16', c_int), ('x3_plan', c_int), ('x3_ring', c_int)]
 
 
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2, 3

@@ -344,6 +344,7 @@ static LspsOptions default_options() {
   d.c8w_queue = 1;
   d.c8_stem_bf16 = 1;
   d.x3_plan = 1;
+  d.x3_ring = 0;
   return d;
 }
 static LspsOptions g_opts = default_options();
@@ -1613,6 +1614,7 @@ int lsps_set_options(const LspsOptions *o) {
   d.c8w_queue = pick(o->c8w_queue, d.c8w_queue, false);
   d.c8_stem_bf16 = pick(o->c8_stem_bf16, d.c8_stem_bf16, true);
   d.x3_plan = pick(o->x3_plan, d.x3_plan, false);
+  d.x3_ring = pick(o->x3_ring, d.x3_ring, true);
   lsps::g_opts = d;
   return 0;
 }

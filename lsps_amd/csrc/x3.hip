@@ -295,10 +295,17 @@ static int x3s2_run_fwd(const void *big, const float *w, long sm, long sc, const
     }
   }
   const dim3 grid(plan.grid);
+  // round 6: 3-deep image ring + counted waits (x3s2.h: RING); its 9 image pieces per limb hold every geometry but the 2x2 maps
+  const bool ring = opts().x3_ring && 2 * p.TI * p.TR * (2 * p.Q + 1) <= X3R_BP * 64;
 #define X3F_LAUNCH(O3, MK)                                                                                                  \
   do {                                                                                                                      \
-    if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_fwd_kernel<O3, MK>), X3F_LDS_BYTES, "x3s2_fwd")) return rc;  \
-    hipLaunchKernelGGL((x3s2_fwd_kernel<O3, MK>), grid, dim3(512), X3F_LDS_BYTES, st, p);                                   \
+    if (ring) {                                                                                                             \
+      if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_fwd_kernel<O3, MK, true>), X3R_LDS_BYTES, "x3s2_fwd_ring")) return rc; \
+      hipLaunchKernelGGL((x3s2_fwd_kernel<O3, MK, true>), grid, dim3(512), X3R_LDS_BYTES, st, p);                          \
+    } else {                                                                                                                \
+      if (int rc = lds_optin(reinterpret_cast<const void *>(x3s2_fwd_kernel<O3, MK>), X3F_LDS_BYTES, "x3s2_fwd")) return rc; \
+      hipLaunchKernelGGL((x3s2_fwd_kernel<O3, MK>), grid, dim3(512), X3F_LDS_BYTES, st, p);                                 \
+    }                                                                                                                       \
   } while (0)
   if (yl) {
     if (act_y) X3F_LAUNCH(true, true); else X3F_LAUNCH(true, false);

@@ -158,9 +158,17 @@ struct X3S2Params {
 #define X3F_ASTAGE (X3F_APIECES * 1024)                    // bytes of packed weights per stage
 #define X3F_STAGE ((X3F_BPIECES + X3F_APIECES) * 1024)     // 64512
 #define X3F_LDS_BYTES (2 * X3F_STAGE)                      // 129024
+// RING variant (round 6): the image pieces of a stage are requested TWO stages ahead into a ring of three image
+// buffers, the (L2-resident) weight pieces one stage ahead into two weight buffers; the stage-end wait is a counted vmcnt that leaves
+// the newest image requests in flight instead of draining to zero.  9 pieces per limb (<= 576 units: every layer but the 2x2 maps).
+#define X3R_BP 9
+#define X3R_BPIECES (3 * X3R_BP)
+#define X3R_IMG (X3R_BPIECES * 1024)                       // 27648
+#define X3R_LDS_BYTES (3 * X3R_IMG + 2 * X3F_ASTAGE)       // 156672
 
-template <bool OUT3, bool MASKED>
+template <bool OUT3, bool MASKED, bool RING = false>
 __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
+  constexpr int BP = RING ? X3R_BP : X3F_BP, BPIECES = 3 * BP;
   extern __shared__ __attribute__((aligned(16))) unsigned char x3_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,10 +190,10 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
   unsigned pcol[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int j = wave + 8 * i, pc = j % X3F_BP;
+    const int j = wave + 8 * i, pc = j % BP;
     const int u = pc * 64 + lane;
     pimg[i] = -1; prow[i] = 0; pcol[i] = 0;
-    if (j < X3F_BPIECES && u < bunits) {
+    if (j < BPIECES && u < bunits) {
       const int kh = u >= plane ? 1 : 0, rem = u - kh * plane;
       const int img = rem / blk, rem2 = rem - img * blk;
       const int ri = rem2 / CB, ci = rem2 - ri * CB;
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
                                             0x00020000);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int limb = min((wave + 8 * i) / X3F_BP, 2);
+      const int limb = min((wave + 8 * i) / BP, 2);
       // offset of the r = 1 row (2 (p0 + ri)); r = 0 / 2: -+ one row at issue time; row -1 (r = 0, first output row) is padding
       voffb[i] = (pimg[i] >= 0 && pimg[i] < nimg)
                      ? (unsigned)((pimg[i] * 3 + limb) * img_bytes + 2 * (p0 + prow[i]) * W16) + pcol[i] : X3_OOB;
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int piece = wave + 8 * i;
-      if (piece < X3F_BPIECES) {
+      if (piece < BPIECES) {
         unsigned v = voffb[i];
         if (r == 0) v = (p0 + prow[i] == 0) ? X3_OOB : v - (unsigned)W16;
         if (r == 2) v = v + (unsigned)W16;
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
     for (int i = 0; i < 5; ++i) {
       const int piece = wave + 8 * i;
       if (piece < X3F_APIECES)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (x3_lds_ptr)(base + (X3F_BPIECES + piece) * 1024), 16, voffa[i],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (x3_lds_ptr)(base + (BPIECES + piece) * 1024), 16, voffa[i],
                                                  (ch * 3 + r) * X3F_ASTAGE, 0, 0);
     }
   };
@@ -263,8 +271,222 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
   const int yil = t_px / tpi, yrem = t_px - yil * tpi;
   const int ypl = yrem / Q, yql = yrem - ypl * Q;
   const unsigned bbase = (unsigned)((half * plane + yil * blk + ypl * CB + yql) * 16);
-  const unsigned a_base = (unsigned)(X3F_BPIECES * 1024 + (half * 128 + wm * 64 + l31) * 16);
+  const unsigned a_base = (unsigned)(BPIECES * 1024 + (half * 128 + wm * 64 + l31) * 16);
 
+  auto epilogue = [&](f32x16 (&acc)[2], int mt_c, int ptile_c, bool yvalid, long ypix, long yunit, float *red_) {
+  // epilogue: acc[i][r] = channel mt*128 + wm*64 + i*32 + (r&3) + 8 (r>>2) + 4 half of this lane's pixel
+  float sdb[32];
+#pragma unroll
+  for (int e = 0; e < 32; ++e) sdb[e] = 0.f;
+  u64 am[2][4];                                                  // MASKED: the mask operand's pieces, all fetched before the first store
+  if (MASKED) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int m4 = mt_c * 128 + wm * 64 + i * 32 + 8 * rq + 4 * half;
+        am[i][rq] = yvalid ? reinterpret_cast<const u64 *>(p.ActY)[((yunit + (long)(m4 >> 3) * PQ) << 1) + half] : 0ull;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int m4 = mt_c * 128 + wm * 64 + i * 32 + 8 * rq + 4 * half;
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) b4 = *reinterpret_cast<const f32x4 *>(p.bias + m4);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = acc[i][rq * 4 + e] + b4[e];
+        x = fmaxf(x, x * p.lrelu);
+        if (MASKED) {
+          const bf16x4 mk = __builtin_bit_cast(bf16x4, am[i][rq]);
+          x = c8_sel_nonpos((float)mk[e], x * p.act_slope, x);
+          if (yvalid) sdb[i * 16 + rq * 4 + e] += x;
+        }
+        v[e] = x;
+      }
+      if (!yvalid) continue;
+      if (!OUT3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p.Y[ypix + (long)(m4 + e) * PQ] = v[e];
+      } else {
+        bf16x4 h, mi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          h[e] = (__bf16)v[e];
+          const float r1 = v[e] - (float)h[e];
+          mi[e] = (__bf16)r1;
+          lo[e] = (__bf16)(r1 - (float)mi[e]);
+        }
+        const long o = ((yunit + (long)(m4 >> 3) * PQ) << 1) + half;      // 8-byte pieces
+        u64 *Y = reinterpret_cast<u64 *>(p.YL);
+        const long ls = (long)(p.M >> 3) * PQ * 2;                         // limb plane of one image in 8-byte pieces
+        Y[o] = __builtin_bit_cast(u64, h);
+        Y[o + ls] = __builtin_bit_cast(u64, mi);
+        Y[o + 2 * ls] = __builtin_bit_cast(u64, lo);
+      }
+    }
+  if (MASKED) {
+    // per-channel sums over the workgroup's pixels: butterfly over the 32 pixel lanes of a half, then over the 4 pixel waves
+    c8_reduce_scatter32<16>(sdb, l31);                           // lane (half, l31): slot l31 = i*16 + r of its half
+    float *red = red_;                                           // [wave 8][half 2][32] in a dead buffer
+    red[(wave * 2 + half) * 32 + l31] = sdb[0];
+    __syncthreads();
+    if (tid < 128) {                                             // (wm, half, slot)
+      const int w_m = tid >> 6, hf = (tid >> 5) & 1, qs = tid & 31;
+      float t = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) t += red[((w4 * 2 + w_m) * 2 + hf) * 32 + qs];
+      const int m = mt_c * 128 + w_m * 64 + (qs >> 4) * 32 + (qs & 3) + 8 * ((qs >> 2) & 3) + 4 * hf;
+      p.dbpart[(long)ptile_c * p.M + m] = t;
+    }
+    __syncthreads();                                             // before the next tile's DMA lands on `red`
+  }
+  };
+
+  if constexpr (RING) {
+    // ---- round 6: three image buffers (requested two stages ahead) + two weight buffers (one stage ahead), counted waits ----
+    struct Stage { int lin, mtk, ptile, ch, ke, r, valid; };          // a stage = (tile, 16-channel chunk, tap row); wave-uniform
+    auto open_tile = [&](Stage &it, int lin_) {
+      it.lin = lin_;
+      it.valid = decode(lin_, it.mtk, it.ptile) ? 1 : 0;
+      it.ch = (it.mtk / MT) * p.kper;
+      it.ke = min(nch, it.ch + p.kper);
+      it.r = 0;
+    };
+    auto advance = [&](Stage &it) {                                   // next stage; true when it entered another tile
+      if (!it.valid) return false;
+      if (++it.r < 3) return false;
+      it.r = 0;
+      if (++it.ch < it.ke) return false;
+      open_tile(it, it.lin + G);
+      return it.valid != 0;
+    };
+    __amdgpu_buffer_rsrc_t xrs_i, wrs_w;
+    unsigned voff_i[4];
+    int p0_i = 0;
+    auto setup_img = [&](const Stage &it) {
+      int n0_;
+      if (TI == 1) {
+        n0_ = it.ptile / p.tiles_per_img;
+        p0_i = (it.ptile - n0_ * p.tiles_per_img) * TR;
+      } else {
+        n0_ = it.ptile * TI;
+        p0_i = 0;
+      }
+      const int nimg_ = min(TI, p.N - n0_);
+      xrs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.X) + (long)n0_ * 3 * (img_bytes >> 1), 0, nimg_ * 3 * img_bytes,
+                                                0x00020000);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int limb = min((wave + 8 * i) / BP, 2);
+        voff_i[i] = (pimg[i] >= 0 && pimg[i] < nimg_)
+                        ? (unsigned)((pimg[i] * 3 + limb) * img_bytes + 2 * (p0_i + prow[i]) * W16) + pcol[i] : X3_OOB;
+      }
+    };
+    auto setup_w = [&](const Stage &it) {
+      wrs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.Wq) + (long)(it.mtk % MT) * nch * 3 * (X3F_ASTAGE >> 1), 0,
+                                                nch * 3 * X3F_ASTAGE, 0x00020000);
+    };
+    auto issue_img = [&](const Stage &it, int slot) {
+      unsigned char *base = x3_lds + slot * X3R_IMG;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int piece = wave + 8 * i;
+        if (piece < BPIECES) {
+          unsigned v = voff_i[i];
+          if (it.r == 0) v = (p0_i + prow[i] == 0) ? X3_OOB : v - (unsigned)W16;
+          if (it.r == 2) v = v + (unsigned)W16;
+          if (voff_i[i] == X3_OOB) v = X3_OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs_i, (x3_lds_ptr)(base + piece * 1024), 16, v, it.ch * 2 * HW16, 0, 0);
+        }
+      }
+    };
+    auto issue_w = [&](const Stage &it, int slot) {
+      unsigned char *base = x3_lds + 3 * X3R_IMG + slot * X3F_ASTAGE;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int piece = wave + 8 * i;
+        if (piece < X3F_APIECES)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs_w, (x3_lds_ptr)(base + piece * 1024), 16, voffa[i], (it.ch * 3 + it.r) * X3F_ASTAGE, 0, 0);
+      }
+    };
+    // the stage-end wait: everything but this wave's newest image requests (pieces wave + 8 i < 27: four for waves 0 - 2, three else)
+    auto wait_stage = [&](int img_in_flight) {
+      if (!img_in_flight)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (wave < BPIECES - 24)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    const unsigned a_off = (unsigned)((half * 128 + wm * 64 + l31) * 16);
+
+    Stage ci, wi, ii;
+    open_tile(ci, blockIdx.x);
+    if (!ci.valid) return;
+    wi = ci;
+    ii = ci;
+    setup_img(ii);
+    setup_w(wi);
+    issue_img(ii, 0);
+    issue_w(wi, 0);
+    if (advance(ii)) setup_img(ii);
+    if (ii.valid) issue_img(ii, 1);                                   // stage 1's image
+    if (advance(wi)) setup_w(wi);
+    wait_stage(ii.valid);
+    int t3 = 0, t2 = 0;
+    while (true) {
+      const int mt_c = ci.mtk % MT, ksp_c = ci.mtk / MT, ptile_c = ci.ptile;
+      int n0_c, p0_c;
+      if (TI == 1) {
+        n0_c = ptile_c / p.tiles_per_img;
+        p0_c = (ptile_c - n0_c * p.tiles_per_img) * TR;
+      } else {
+        n0_c = ptile_c * TI;
+        p0_c = 0;
+      }
+      const bool yvalid = yil < min(TI, p.N - n0_c);
+      const long ypix = (long)ksp_c * p.ysplit + (long)(n0_c + yil) * p.M * PQ + (long)(p0_c + ypl) * Q + yql;
+      const long yunit = (long)(n0_c + yil) * 3 * (p.M >> 3) * PQ + (long)(p0_c + ypl) * Q + yql;
+      f32x16 acc[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      const int nst = (ci.ke - ci.ch) * 3;
+      for (int st = 0; st < nst; ++st) {
+        if (wi.valid) issue_w(wi, t2 ^ 1);                            // weights of stage t + 1
+        if (advance(ii)) setup_img(ii);
+        if (ii.valid) issue_img(ii, t3 == 0 ? 2 : t3 - 1);            // image of stage t + 2 -> slot (t + 2) % 3
+        const unsigned char *SI = x3_lds + t3 * X3R_IMG, *SA = x3_lds + 3 * X3R_IMG + t2 * X3F_ASTAGE;
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) {
+          const int coff = (sx == 0 ? 0 : (sx == 1 ? Q + 1 : 1)) * 16;
+          bf16x8 af[2][3], bf[3];
+#pragma unroll
+          for (int l = 0; l < 3; ++l) {
+            bf[l] = *reinterpret_cast<const bf16x8 *>(SI + l * (BP * 1024) + bbase + coff);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i][l] = *reinterpret_cast<const bf16x8 *>(SA + a_off + ((l * 3 + sx) * 256 + i * 32) * 16);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i] = mfma_split6(af[i][0], af[i][1], af[i][2], bf[0], bf[1], bf[2], acc[i]);
+        }
+        wait_stage(ii.valid);
+        if (advance(wi)) setup_w(wi);
+        t3 = t3 == 2 ? 0 : t3 + 1;
+        t2 ^= 1;
+      }
+      // scratch of the MASKED column sums: the image buffer the last stage consumed (its next request goes out in the next stage)
+      epilogue(acc, mt_c, ptile_c, yvalid, ypix, yunit, reinterpret_cast<float *>(x3_lds + (t3 == 0 ? 2 : t3 - 1) * X3R_IMG));
+      open_tile(ci, ci.lin + G);
+      if (!ci.valid) return;
+    }
+  }
   int lin = blockIdx.x, buf = 0;
   {
     int m_, t_;
@@ -307,7 +529,7 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
           bf16x8 af[2][3], bf[3];
 #pragma unroll
           for (int l = 0; l < 3; ++l) {
-            bf[l] = *reinterpret_cast<const bf16x8 *>(S + l * (X3F_BP * 1024) + bbase + coff);
+            bf[l] = *reinterpret_cast<const bf16x8 *>(S + l * (BP * 1024) + bbase + coff);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
               af[i][l] = *reinterpret_cast<const bf16x8 *>(S + a_base + ((l * 3 + s) * 256 + i * 32) * 16);
@@ -321,76 +543,7 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
       }
     }
 
-    // epilogue: acc[i][r] = channel mt*128 + wm*64 + i*32 + (r&3) + 8 (r>>2) + 4 half of this lane's pixel
-    float sdb[32];
-#pragma unroll
-    for (int e = 0; e < 32; ++e) sdb[e] = 0.f;
-    u64 am[2][4];                                                  // MASKED: the mask operand's pieces, all fetched before the first store
-    if (MASKED) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const int m4 = mt_c * 128 + wm * 64 + i * 32 + 8 * rq + 4 * half;
-          am[i][rq] = yvalid ? reinterpret_cast<const u64 *>(p.ActY)[((yunit + (long)(m4 >> 3) * PQ) << 1) + half] : 0ull;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int m4 = mt_c * 128 + wm * 64 + i * 32 + 8 * rq + 4 * half;
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) b4 = *reinterpret_cast<const f32x4 *>(p.bias + m4);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x = acc[i][rq * 4 + e] + b4[e];
-          x = fmaxf(x, x * p.lrelu);
-          if (MASKED) {
-            const bf16x4 mk = __builtin_bit_cast(bf16x4, am[i][rq]);
-            x = c8_sel_nonpos((float)mk[e], x * p.act_slope, x);
-            if (yvalid) sdb[i * 16 + rq * 4 + e] += x;
-          }
-          v[e] = x;
-        }
-        if (!yvalid) continue;
-        if (!OUT3) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) p.Y[ypix + (long)(m4 + e) * PQ] = v[e];
-        } else {
-          bf16x4 h, mi, lo;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            h[e] = (__bf16)v[e];
-            const float r1 = v[e] - (float)h[e];
-            mi[e] = (__bf16)r1;
-            lo[e] = (__bf16)(r1 - (float)mi[e]);
-          }
-          const long o = ((yunit + (long)(m4 >> 3) * PQ) << 1) + half;      // 8-byte pieces
-          u64 *Y = reinterpret_cast<u64 *>(p.YL);
-          const long ls = (long)(p.M >> 3) * PQ * 2;                         // limb plane of one image in 8-byte pieces
-          Y[o] = __builtin_bit_cast(u64, h);
-          Y[o + ls] = __builtin_bit_cast(u64, mi);
-          Y[o + 2 * ls] = __builtin_bit_cast(u64, lo);
-        }
-      }
-    if (MASKED) {
-      // per-channel sums over the workgroup's pixels: butterfly over the 32 pixel lanes of a half, then over the 4 pixel waves
-      c8_reduce_scatter32<16>(sdb, l31);                           // lane (half, l31): slot l31 = i*16 + r of its half
-      float *red = reinterpret_cast<float *>(x3_lds + (buf ^ 1) * X3F_STAGE);   // [wave 8][half 2][32] in the dead buffer
-      red[(wave * 2 + half) * 32 + l31] = sdb[0];
-      __syncthreads();
-      if (tid < 128) {                                             // (wm, half, slot)
-        const int w_m = tid >> 6, hf = (tid >> 5) & 1, qs = tid & 31;
-        float t = 0.f;
-#pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4) t += red[((w4 * 2 + w_m) * 2 + hf) * 32 + qs];
-        const int m = mt_c * 128 + w_m * 64 + (qs >> 4) * 32 + (qs & 3) + 8 * ((qs >> 2) & 3) + 4 * hf;
-        p.dbpart[(long)ptile_c * p.M + m] = t;
-      }
-      __syncthreads();                                             // before the next tile's DMA lands on `red`
-    }
+    epilogue(acc, mt_c, ptile_c, yvalid, ypix, yunit, reinterpret_cast<float *>(x3_lds + (buf ^ 1) * X3F_STAGE));
     if (!more) return;
     lin += G;
   }

@@ -21,7 +21,7 @@ import os
 DEFAULT_BUCKET_BYTES = 16 << 20
 
 # fields handed to the library by lsps_set_options (include/lsps_hip.h: struct LspsOptions, same order after struct_size)
-NATIVE_FIELDS = ('wino4_split', 'fs2_cc', 'wino4w', 'wino4w_waves', 'chwn_group', 'c8w_queue', 'c8_stem_bf16', 'x3_plan')
+NATIVE_FIELDS = ('wino4_split', 'fs2_cc', 'wino4w', 'wino4w_waves', 'chwn_group', 'c8w_queue', 'c8_stem_bf16', 'x3_plan', 'x3_ring')
 
 
 @dataclasses.dataclass(frozen=True)
@@ -55,6 +55,7 @@ class Options:
     c8w_queue: int = 1                 # LSPS_C8W_QUEUE: workgroups per CU of the C8 weight-gradient grids
     c8_stem_bf16: bool = True          # LSPS_C8_STEM_BF16=0: f32 stems in bf16 mode
     x3_plan: int = 1                   # LSPS_X3_PLAN=0: three-limb kernels launched without a plan
+    x3_ring: bool = False              # LSPS_X3_RING=1: three-limb forward kernel with the 3-deep image ring (round 6 experiment)
     hip_lib: str = ''                  # LSPS_HIP_LIB: another build of the library (kernel A/B experiments); '' = in-tree
 
     def as_dict(self):
@@ -83,7 +84,7 @@ def from_env(env=None):
         bucket_bytes=int(e.get('LSPS_BUCKET_BYTES', DEFAULT_BUCKET_BYTES)),
         wino=int(e.get('LSPS_WINO', '1')), wino4_split=off('LSPS_WINO4_SPLIT'), fs2_cc=int(e.get('LSPS_FS2_CC', '4')),
         wino4w=off('LSPS_WINO4W'), wino4w_waves=int(e.get('LSPS_WINO4W_WAVES', '8')), chwn_group=off('LSPS_CHWN_GROUP'),
-        c8w_queue=int(e.get('LSPS_C8W_QUEUE', '1')), c8_stem_bf16=off('LSPS_C8_STEM_BF16'), x3_plan=int(e.get('LSPS_X3_PLAN', '1')),
+        c8w_queue=int(e.get('LSPS_C8W_QUEUE', '1')), c8_stem_bf16=off('LSPS_C8_STEM_BF16'), x3_plan=int(e.get('LSPS_X3_PLAN', '1')), x3_ring=on('LSPS_X3_RING'),
         hip_lib=e.get('LSPS_HIP_LIB', ''))
 
 

@@ -24,10 +24,10 @@ def test_from_env_parses_every_switch_and_is_hashable():
     assert e.chwn_min_n == 16 and e.est_order == 'chain' and e.x3_min_gmac == 7.5 and e.force_dp and e.bucket_bytes == 65536
     assert e.side_prio == -1 and e.share_encoder and e.wino == 3
     # the library's own switches are ordinary fields now (round 6: no getenv in csrc); native() is the lsps_set_options block
-    assert d.native() == dict(wino4_split=1, fs2_cc=4, wino4w=1, wino4w_waves=8, chwn_group=1, c8w_queue=1, c8_stem_bf16=1, x3_plan=1)
+    assert d.native() == dict(wino4_split=1, fs2_cc=4, wino4w=1, wino4w_waves=8, chwn_group=1, c8w_queue=1, c8_stem_bf16=1, x3_plan=1, x3_ring=0)
     n = options.from_env({'LSPS_WINO4_SPLIT': '0', 'LSPS_FS2_CC': '8', 'LSPS_WINO4W': '0', 'LSPS_WINO4W_WAVES': '4', 'LSPS_CHWN_GROUP': '0',
-                          'LSPS_C8W_QUEUE': '2', 'LSPS_C8_STEM_BF16': '0', 'LSPS_X3_PLAN': '0', 'LSPS_HIP_LIB': '/x/y.so'})
-    assert n.native() == dict(wino4_split=0, fs2_cc=8, wino4w=0, wino4w_waves=4, chwn_group=0, c8w_queue=2, c8_stem_bf16=0, x3_plan=0)
+                          'LSPS_C8W_QUEUE': '2', 'LSPS_C8_STEM_BF16': '0', 'LSPS_X3_PLAN': '0', 'LSPS_X3_RING': '1', 'LSPS_HIP_LIB': '/x/y.so'})
+    assert n.native() == dict(wino4_split=0, fs2_cc=8, wino4w=0, wino4w_waves=4, chwn_group=0, c8w_queue=2, c8_stem_bf16=0, x3_plan=0, x3_ring=1)
     assert n.hip_lib == '/x/y.so' and hash(n) != hash(d)
     assert hash(d) != hash(e) and d != e and d == options.from_env({})           # usable inside a hipGraph signature
     json.dumps(e.as_dict())                                                       # goes into bench.py's JSON line
