@@ -166,6 +166,8 @@ struct X3S2Params {
 #define X3R_IMG (X3R_BPIECES * 1024)                       // 27648
 #define X3R_LDS_BYTES (3 * X3R_IMG + 2 * X3F_ASTAGE)       // 156672
 
+struct X3Stage { int lin, mtk, ptile, ch, ke, r, valid; };
+
 template <bool OUT3, bool MASKED, bool RING = false>
 __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
   constexpr int BP = RING ? X3R_BP : X3F_BP, BPIECES = 3 * BP;
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(512, 1) void x3s2_fwd_kernel(X3S2Params p) {
 
   if constexpr (RING) {
     // ---- round 6: three image buffers (requested two stages ahead) + two weight buffers (one stage ahead), counted waits ----
-    struct Stage { int lin, mtk, ptile, ch, ke, r, valid; };          // a stage = (tile, 16-channel chunk, tap row); wave-uniform
+    typedef X3Stage Stage;                                            // a stage = (tile, 16-channel chunk, tap row); wave-uniform
     auto open_tile = [&](Stage &it, int lin_) {
       it.lin = lin_;
       it.valid = decode(lin_, it.mtk, it.ptile) ? 1 : 0;

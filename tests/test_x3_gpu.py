@@ -97,6 +97,36 @@ def test_conv_forward_dgrad_wgrad(N, C, H, K):
     assert _rel(dw, dw_ref) < TOL
 
 
+@pytest.mark.parametrize("N,C,H,K", [(3, 128, 64, 256), (5, 64, 128, 128), (19, 512, 8, 1024)])
+def test_forward_ring_variant_is_bitwise_the_double_buffered_kernel(N, C, H, K):
+    """Round 6 experiment kept behind `options.x3_ring` (image pieces requested two stages ahead into a ring of
+    three buffers, counted stage-end waits; measured 7 - 17 % SLOWER, profiles/r6f_x3_ring_ab.txt, so it is off): the same MFMAs
+    in the same order, so every output bit must equal the default kernel's — f32 and X3 output, persistent multi-tile walk."""
+    _need_gpu()
+    _lib, L, ops, dev, st = _env()
+    torch.manual_seed(N)
+    P = H // 2
+    x = torch.randn(N, C, H, H, device=dev)
+    w = torch.randn(K, C, 3, 3, device=dev) * 0.05
+    b = torch.randn(K, device=dev)
+    xl = ops.x3_split(x)
+    ws, wsb = _lib.workspace(L.lsps_x3_conv3x3s2_workspace_bytes(N, C, H, H, K), dev)
+    outs = []
+    for ring in (False, True):
+        with ops.options.override(x3_ring=ring):
+            assert _lib.native_options()['x3_ring'] == int(ring)
+            y = torch.empty(N, K, P, P, device=dev)
+            yl = torch.empty(N, 3, K // 8, P, P, 8, dtype=BF, device=dev)
+            ops.kernel_log_begin()
+            _lib.check(L.lsps_x3_conv3x3s2_fwd(_lib.ptr(xl, BF), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), None, N, C, H, H, K, 0.01, ws, wsb, st), 'f')
+            _lib.check(L.lsps_x3_conv3x3s2_fwd(_lib.ptr(xl, BF), _lib.ptr(w), _lib.ptr(b), None, _lib.ptr(yl, BF), N, C, H, H, K, 0.01, ws, wsb, st), 'f3')
+            ops.kernel_log_end()
+            outs.append((y, yl))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = F.leaky_relu(F.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), stride=2, padding=1), 0.01)
+    assert _rel(outs[1][0], ref) < TOL
+
+
 @pytest.mark.parametrize("N,Ci,H,Co", [(3, 256, 32, 128), (2, 128, 64, 64), (5, 256, 8, 128)])
 def test_transposed_conv_forward_dgrad_wgrad(N, Ci, H, Co):
     _need_gpu()
