@@ -509,14 +509,25 @@ def main():
         roofline = None
         traffic = None
         traffic_file = None
-        tfiles = ('r4_traffic.json', 'r2t_traffic.json') if args.dtype == 'f32' else ('r4_traffic_bf16.json', 'r3l_traffic_bf16.json')
-        for tf in tfiles:               # PMC traffic is collected offline (rocprofv3 --pmc cannot run inside the timed bench)
+        # PMC traffic is collected offline (rocprofv3 --pmc cannot run inside the timed bench): tools/jobs/round_end_validation.sh writes
+        # profiles/r6_traffic*.json with the hash of the kernel sources it was taken on; a file from OTHER sources is refused (its
+        # numbers are still quoted, marked stale, so that the line says what exists) - VERDICT r5 item 7(i)
+        from lsps_amd import _lib as _lsps_lib
+        src_sha = _lsps_lib.csrc_sha16()
+        tfiles = ('r6_traffic.json', 'r4_traffic.json') if args.dtype == 'f32' else ('r6_traffic_bf16.json', 'r4_traffic_bf16.json')
+        traffic_stale = None
+        for tf in tfiles:
             try:
                 with open(os.path.join(REPO, 'profiles', tf)) as f:
-                    tj = json.load(f).get(dom_name)
+                    tall = json.load(f)
+                tj = tall.get(dom_name)
                 if tj:   # scaled from the profiled launch shape to this run's average launch by algorithmic work
-                    traffic = tj['hbm_bytes_per_launch'] * dom['gflop_per_launch'] / tj['gflop_per_launch']
-                    traffic_file = tf
+                    scaled = tj['hbm_bytes_per_launch'] * dom['gflop_per_launch'] / tj['gflop_per_launch']
+                    if tall.get('_csrc_sha16') == src_sha:
+                        traffic, traffic_file = scaled, tf
+                    else:
+                        traffic_stale = {'file': 'profiles/' + tf, 'bytes_per_launch': scaled, 'taken_on_csrc_sha16': tall.get('_csrc_sha16'),
+                                         'this_build_csrc_sha16': src_sha}
                     break
             except (OSError, ValueError, TypeError, KeyError):
                 traffic = None
@@ -532,8 +543,11 @@ def main():
                         # 1/2.25 (F2) resp. 1/4 (F4) of the algorithmic multiplies `achieved` counts
                         'frac': dom['tflops'] / (wino_x if wino else 1.0) / peak,
                         'algorithmic_frac': dom['tflops'] / peak, 'traffic': traffic,
-                        'traffic_note': 'HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE KB, calibrated), '
-                                        'profiles/%s; scaled to this run\'s mean launch size' % (traffic_file or tfiles[0]),
+                        'traffic_note': ('HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE KB, calibrated), '
+                                         'profiles/%s, taken on THESE kernel sources (csrc sha %s); scaled to this run\'s mean launch size'
+                                         % (traffic_file, src_sha)) if traffic_file else
+                                        'null: no PMC file for this build\'s kernel sources (csrc sha %s); see traffic_stale' % src_sha,
+                        'traffic_stale': traffic_stale,
                         'launches': dom['launches'], 'avg_launch_ms': dom['avg_ms'],
                         'algorithmic_gflop_per_launch': dom['gflop_per_launch'],
                         'share_of_step_time': dom['total_ms'] / (1e3 * elapsed),
@@ -588,8 +602,18 @@ def main():
                 try:
                     with open(os.path.join(REPO, 'profiles', 'r5i_pmc_x3.json')) as f:
                         blk['pmc'] = json.load(f)
+                    blk['pmc']['build'] = ('round-5 build; the default kernels of csrc/x3s2.h are unchanged in round 6 (the forward kernel\'s '
+                                           'epilogue became a lambda, a RING variant was added and measured slower: profiles/r6f_x3_ring_ab.txt)')
                 except (OSError, ValueError):
                     blk['pmc'] = None
+                try:   # how the family's accuracy compares with the exact-f32 kernels it replaced, per layer
+                    with open(os.path.join(REPO, 'profiles', 'r6_x3_accuracy.json')) as f:
+                        acc = json.load(f)
+                    blk['accuracy_vs_exact_f32_kernels'] = {'summary': acc['summary'], 'forward_ratio_per_layer':
+                                                            dict((e['layer'], e['ratio']) for e in acc['forward']), 'source': acc['source']}
+                    blk['note'] += ('; accuracy: NOT uniformly the exact-f32 kernels\' - ' + acc['summary'])
+                except (OSError, ValueError, KeyError):
+                    pass
                 roofline['three_limb_stride2_family'] = blk
         out = {
             'metric': 'depth_train steps/sec (128x128x1, bs=%d)' % args.batch, 'value': world * args.steps / elapsed,

@@ -171,6 +171,21 @@ def lib():
     return _lib
 
 
+def csrc_sha16():
+    """sha256[:16] over the library's sources (csrc/*.hip, *.h, Makefile, include/lsps_hip.h): names the BUILD a measurement file
+    (profiles/r*_traffic*.json) belongs to; bench.py refuses PMC numbers taken on other sources."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, 'csrc', '*.hip')) + glob.glob(os.path.join(_HERE, 'csrc', '*.h')))
+    files += [os.path.join(_HERE, 'csrc', 'Makefile'), os.path.join(os.path.dirname(_HERE), 'include', 'lsps_hip.h')]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def push_options(opt):
     """lsps_set_options with the library's share of `opt` (lsps_amd/options.py: Options.native())."""
     blk = LspsOptions(struct_size=ctypes.sizeof(LspsOptions), **opt.native())

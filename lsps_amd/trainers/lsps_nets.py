@@ -144,12 +144,21 @@ class SharedDis(_Net):
         layers = list(self.model_S)
         if ops.is_c8(f) or ops.get_math_mode() == 'bf16':
             return ops.from_c8(run_layers(layers, f))
-        c0 = layers[0].model[0] if layers and isinstance(layers[0], LeakyReLUConv2d) else None
-        if c0 is not None and ops.x3_conv_s2_ok(f, c0.weight, c0.stride, c0.padding):
-            # three-limb operands on the bf16 matrix pipe (csrc/x3s2.h): the layers chain in the X3 layout (run_layers), the
-            # last one hands out f32 NCHW; no transposes, the LeakyReLU backward passes ride in the dgrad epilogues
+        N, C, H, W = ops._x3_shape(f) or f.shape             # f32 NCHW here (the fronts hand an X3 tensor only to a layer of their own chain)
+        # three-limb operands on the bf16 matrix pipe (csrc/x3s2.h): the layers chain in the X3 layout (run_layers), the last one
+        # hands out f32 NCHW; no transposes, the LeakyReLU backward passes ride in the dgrad epilogues.  EVERY trunk layer must
+        # qualify (geometry and options.x3_min_gmac at its own map size): a chain that loses its tail to the plain NCHW kernels
+        # pays a join / split per hand-over and never reaches the batch-innermost kernels below
+        x3_all, c, h, w = bool(layers), C, H, W
+        for l in layers:
+            conv = l.model[0] if isinstance(l, LeakyReLUConv2d) else None
+            x3_all = x3_all and conv is not None and ops.x3_conv_s2_ok(torch.empty((N, c, h, w), dtype=torch.float32, device='meta'),
+                                                                       conv.weight, conv.stride, conv.padding)
+            if not x3_all:
+                break
+            c, h, w = conv.weight.shape[0], h // 2, w // 2
+        if x3_all:
             return ops.from_c8(run_layers(layers, f))
-        N, C, H, W = f.shape
         # below ~96 samples the 128-wide batch tile of the GEMM is mostly padding (dis.feats on 16 samples: slower than NCHW)
         opt = ops.options.get()
         ok = len(layers) > 0 and N >= opt.chwn_min_n and opt.chwn

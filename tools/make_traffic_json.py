@@ -6,8 +6,11 @@ Counters as MI355X_MICROARCH.md prescribes: separate passes for FETCH_SIZE and W
 3 x 1 GiB arrays in the same passes (2 GiB really read, 1 GiB really written): bytes = KB x 1024 x (known / counted)."""
 import collections
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def parse(path):
@@ -47,7 +50,9 @@ def main():
     ctr = parse(path)
     ax = find(ctr, r'axpy_kernel')
     cal = {'fetch': 2097152.0 / ax['FETCH_SIZE'], 'write': 1048576.0 / ax['WRITE_SIZE']}
-    out = {'_what': 'HBM traffic per launch from rocprofv3 PMC on the round-4 build: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes '
+    from lsps_amd import _lib
+    out = {'_csrc_sha16': _lib.csrc_sha16(),      # the sources these counters were taken on (bench.py checks it)
+           '_what': 'HBM traffic per launch from rocprofv3 PMC on the build named by _csrc_sha16: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes '
                     '(tools/pmc_pass.sh over tools/%s), built by tools/make_traffic_json.py from %s'
                     % ('pmc_traffic.py' if kind == 'f32' else 'pmc_c8.py', path),
            '_calibration': 'lsps_axpy on 3 x 1 GiB arrays in the same passes: FETCH_SIZE %d KB counted for 2 GiB read (x %.3f), '
