@@ -105,6 +105,33 @@ def test_n16_full_width_default_dispatch_against_the_oracle(monkeypatch):
     assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
 
 
+def test_n32_full_width_literal_default_dispatch_against_the_oracle():
+    """VERDICT r5 "what's weak" 2: the N = 16 test above moves two thresholds so that every kernel family appears, i.e. it is A
+    mixed dispatch, not the bench's.  Here NOTHING is overridden: full width, 32 samples per domain, `dis_update` + `gen_update` +
+    `post_update(3)` once against the CPU oracle run in the test (~1.5 min on the GPU box's host).  At this batch the default
+    dispatch is the bs = 128 bench's: F(4x4,3x3) forward / dgrad / wgrad for the residual convs, the three-limb kernels for EVERY
+    stride-2 layer of both nets (>= 10^9 multiply-adds per launch), no batch-innermost trunk, no exact-f32 stride-2 kernel."""
+    A = _adapter()
+    from lsps_amd import ops
+    import os
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    assert ops.options.get() == ops.options.from_env({}) and ops.get_winograd() == 'auto'      # the literal defaults
+    O = cases.NativeAdapter(lsps_ref, 'cpu')
+    gold = cases.flatten(cases.run_n16_cases(O, lsps_ref, n=32))
+    ops.kernel_log_begin()
+    try:
+        R = cases.run_n16_cases(A, lsps_ref, n=32)
+    finally:
+        names = set(ops.kernel_log_end())
+    for k in ('wino4_f3x3_kernel', 'wino4_w3x3_kernel', 'x3s2_fwd_kernel', 'x3s2_tr_kernel', 'x3s2_wgrad_kernel'):
+        assert k in names, (k, sorted(names))
+    assert not [k for k in names if k.startswith('chwn_') or (k.startswith('igemm_') and '3x3s2' in k)], sorted(names)
+    report = {}
+    bad, worst = cases.compare(R, gold, RTOL, grad_rtol=2e-2, report=report)
+    print("worst rel err", worst, report)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
+
+
 def test_extra_cases_match_reference_golden(golden):
     """`post_update(mode=1)` (lsps_trainer.py:231-234) and a full-width pretrain iteration at a batch where the DEFAULT
     dispatch ('auto') of the residual convs is the Winograd path — the dispatch the bench runs, at trainer level."""
