@@ -45,6 +45,7 @@ class Options:
     force_dp: bool = False             # LSPS_FORCE_DP=1: gradient exchange also in a 1-rank group
     dp_graphs: bool = True             # LSPS_DP_GRAPHS=0: data-parallel steps never captured
     bucket_bytes: int = DEFAULT_BUCKET_BYTES   # LSPS_BUCKET_BYTES
+    lazy_scalars: bool = True          # LSPS_LAZY_SCALARS=0: every update method ends with a synchronous device -> host copy of its scalars
     # ---- inside the library (csrc), through lsps_set_options ----
     wino: int = 1                      # LSPS_WINO: initial Winograd mode 0..4 (lsps_set_winograd; ops.set_winograd changes it later)
     wino4_split: bool = True           # LSPS_WINO4_SPLIT=0: no reduction-split F(4x4,3x3) launches
@@ -81,7 +82,7 @@ def from_env(env=None):
         frozen_packs=not on('LSPS_NO_FROZEN_PACKS'), est_split_backward=off('LSPS_EST_SPLIT_BACKWARD'),
         est_order=e.get('LSPS_EST_ORDER', 'feat_first'), est_merge=off('LSPS_EST_MERGE'), share_encoder=on('LSPS_SHARE_ENCODER'), fuse_act=off('LSPS_FUSE_ACT'), c8_fuse_act=off('LSPS_C8_FUSE_ACT'),
         c8=off('LSPS_C8'), c8s2=off('LSPS_C8S2'), x3=off('LSPS_X3'), x3_min_gmac=float(e.get('LSPS_X3_MIN_GMAC', '1.0')), force_dp=on('LSPS_FORCE_DP'), dp_graphs=off('LSPS_DP_GRAPHS'),
-        bucket_bytes=int(e.get('LSPS_BUCKET_BYTES', DEFAULT_BUCKET_BYTES)),
+        bucket_bytes=int(e.get('LSPS_BUCKET_BYTES', DEFAULT_BUCKET_BYTES)), lazy_scalars=off('LSPS_LAZY_SCALARS'),
         wino=int(e.get('LSPS_WINO', '1')), wino4_split=off('LSPS_WINO4_SPLIT'), fs2_cc=int(e.get('LSPS_FS2_CC', '4')),
         wino4w=off('LSPS_WINO4W'), wino4w_waves=int(e.get('LSPS_WINO4W_WAVES', '8')), chwn_group=off('LSPS_CHWN_GROUP'),
         c8w_queue=int(e.get('LSPS_C8W_QUEUE', '1')), c8_stem_bf16=off('LSPS_C8_STEM_BF16'), x3_plan=int(e.get('LSPS_X3_PLAN', '1')), x3_ring=on('LSPS_X3_RING'),

@@ -105,3 +105,43 @@ def test_pretrain_with_gpu_augmentation(tmp_path):
     assert not torch.equal(aug[0], plain[0]) and not torch.equal(aug[1], plain[1])
     tr, hist = depth_train.run(P(['--config', cfgp, '--mode', 'pretrain', '--batch_size', '4', '--iterations', '4', '--augment']))
     assert len(hist) == 2 and all(np.isfinite(v) for v in hist[-1].values())
+
+
+def test_loss_scalars_materialise_on_read_and_equal_the_synchronous_publication():
+    """Round 6: the update methods publish their scalars with ONE asynchronous device -> pinned-host copy and the attributes become
+    numpy values when they are READ (no host synchronisation at the end of a step).  Same values as the synchronous path
+    (`lazy_scalars = False`), the same reflection the reference's `write_loss` performs (common.py:73-80: `dir()` + `getattr`):
+    names appear once an update method has published them and not before; values survive more steps than the ring is deep."""
+    import copy
+    import cases
+    from oracle import lsps_ref
+    import lsps_amd.trainers as prod
+    from lsps_amd.depth_train import write_loss
+    A = cases.NativeAdapter(prod, 'cuda')
+    hp = cases.hp_for('tiny')
+    sds = cases.make_weights(hp, lsps_ref)
+    b = cases.make_inputs(2)
+    lat2, lat1 = cases.latent_shape(hp, 4), cases.latent_shape(hp, 2)
+    out = []
+    for lazy in (True, False):
+        tr = A.make_trainer(hp, sds)
+        tr.lazy_scalars = lazy
+        A.set_train(tr, True)
+        assert not [k for k in dir(tr) if 'loss' in k and not k.startswith('_') and not callable(getattr(tr, k))]
+        assert not hasattr(tr, 'dis_loss')
+        A.dis_update(tr, b, hp, cases.noise(lat2, 1))
+        if lazy:
+            assert isinstance(tr.__dict__['dis_loss'], tuple)              # in flight: nothing has waited for it
+        assert 'dis_loss' in dir(tr) and 'gen_total_loss' not in dir(tr) and not hasattr(tr, 'dis_reg_loss')
+        first = float(tr.dis_loss)
+        assert isinstance(tr.dis_loss, np.ndarray) and tr.dis_loss.dtype == np.float32 and tr.dis_loss.shape == ()
+        A.gen_update(tr, b, hp, (cases.noise(lat2, 2), cases.noise(lat1, 3), cases.noise(lat1, 4)))
+        rec = write_loss(0, 1, tr, 0.0)
+        assert set(rec) >= {'dis_loss', 'dis_ad_loss', 'dis_true_acc', 'gen_total_loss', 'gen_ll_loss'} and 'dis_reg_loss' not in rec
+        keep = copy.deepcopy(rec)
+        for it in range(10):                                                # deeper than the ring of pinned buffers (8)
+            A.dis_update(tr, b, hp, cases.noise(lat2, 10 + it))
+        assert float(tr.gen_total_loss) == keep['gen_total_loss']          # published 10 steps ago by another method, never re-read
+        out.append((first, keep, A.scalars(tr)))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert out[0][2].keys() == out[1][2].keys() and all(out[0][2][k] == out[1][2][k] for k in out[0][2])

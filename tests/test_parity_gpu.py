@@ -110,7 +110,7 @@ def test_n32_full_width_literal_default_dispatch_against_the_oracle():
     mixed dispatch, not the bench's.  Here NOTHING is overridden: full width, 32 samples per domain, `dis_update` + `gen_update` +
     `post_update(3)` once against the CPU oracle run in the test (~1.5 min on the GPU box's host).  At this batch the default
     dispatch is the bs = 128 bench's: F(4x4,3x3) forward / dgrad / wgrad for the residual convs, the three-limb kernels for EVERY
-    stride-2 layer of both nets (>= 10^9 multiply-adds per launch), no batch-innermost trunk, no exact-f32 stride-2 kernel."""
+    stride-2 layer of both nets (>= 10^9 multiply-adds per launch), no batch-innermost trunk."""
     A = _adapter()
     from lsps_amd import ops
     import os
@@ -125,7 +125,10 @@ def test_n32_full_width_literal_default_dispatch_against_the_oracle():
         names = set(ops.kernel_log_end())
     for k in ('wino4_f3x3_kernel', 'wino4_w3x3_kernel', 'x3s2_fwd_kernel', 'x3s2_tr_kernel', 'x3s2_wgrad_kernel'):
         assert k in names, (k, sorted(names))
-    assert not [k for k in names if k.startswith('chwn_') or (k.startswith('igemm_') and '3x3s2' in k)], sorted(names)
+    # no batch-innermost trunk at this batch.  (Exact-f32 stride-2 kernels DO appear, as in the bs = 128 estimate3 step: the merged
+    # discriminator pass of post_update runs front B on the 4 + 4 generated samples only, 0.6 x 10^9 multiply-adds, below the family's
+    # work threshold; the pretrain iteration has no such launch.)
+    assert not [k for k in names if k.startswith('chwn_')], sorted(names)
     report = {}
     bad, worst = cases.compare(R, gold, RTOL, grad_rtol=2e-2, report=report)
     print("worst rel err", worst, report)
