@@ -447,9 +447,19 @@ class LSPSTrainer(nn.Module):
         for i, k in enumerate(names):
             self.__dict__[k] = (slot, i)
 
+    def __getstate__(self):
+        # copy.deepcopy / pickle: scalars still in flight become plain numpy values; the pinned ring (events cannot be copied) stays behind
+        for k in _SCALAR_NAMES:
+            if isinstance(self.__dict__.get(k), tuple):
+                getattr(self, k)
+        d = self.__dict__.copy()
+        d.pop('_scalar_ring', None)
+        d.pop('_scalar_next', None)
+        return d
+
     def __dir__(self):
         # the reference's write_loss reflects over dir(trainer) (common.py:73-80): scalars no update method has published yet do not exist
-        return [k for k in super(LSPSTrainer, self).__dir__() if k not in _SCALAR_NAMES or k in self.__dict__]
+        return sorted(set(k for k in super(LSPSTrainer, self).__dir__() if k not in _SCALAR_NAMES or k in self.__dict__))
 
     # ------------------------------------------------------------------ loss helpers (:42-60)
     def _compute_ll_loss(self, a, b):

@@ -90,3 +90,31 @@ def test_dropin_in_front_of_the_reference_src_dir():
     ''') % {'repo': REPO}
     out = _run(['/root/reference/src', os.path.join(REPO, 'dropin')], extra)
     assert 'ORDER-OK' in out
+
+
+def test_loss_scalars_reflect_like_the_references_attributes():
+    """Round 6: `dis_loss` & co. are class-level properties (published asynchronously on the GPU, materialised on read).  For a caller
+    they must behave like the reference's plain attributes (lsps_trainer.py:73,132-140,198-199,214-217,260-261; common.py:73-80 reflects
+    with dir() + getattr): absent until an update method published them, numpy values afterwards, assignable, deletable, deep-copyable."""
+    import copy
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, 'tests', 'golden'))
+    import cases
+    import lsps_amd.trainers as prod
+    from lsps_amd.depth_train import write_loss
+    tr = prod.LSPSTrainer(cases.hp_for('tiny'))
+    assert not hasattr(tr, 'dis_loss') and 'dis_loss' not in dir(tr) and 'dis_loss' not in vars(tr)
+    assert write_loss(0, 1, tr, 0.0).keys() == {'iteration', 'sec_per_display'}
+    tr.dis_loss = np.asarray(1.5, dtype=np.float32)                    # what _finish_step's synchronous path does
+    tr.gen_total_loss = np.asarray(2.5, dtype=np.float32)
+    assert 'dis_loss' in dir(tr) and 'dis_loss' in vars(tr) and float(tr.dis_loss) == 1.5
+    rec = write_loss(0, 1, tr, 0.0)
+    assert rec['dis_loss'] == 1.5 and rec['gen_total_loss'] == 2.5 and 'dis_reg_loss' not in rec
+    clone = copy.deepcopy(tr)
+    assert float(clone.dis_loss) == 1.5 and not hasattr(clone, 'vae_total_loss')
+    del tr.dis_loss
+    assert not hasattr(tr, 'dis_loss') and float(clone.dis_loss) == 1.5
+    # no other non-callable public attribute may contain 'loss' / 'acc' (SURVEY 8(b)): the reflective logger would print it
+    extra = [a for a in dir(tr) if ('loss' in a or 'acc' in a) and not a.startswith('_') and not callable(getattr(tr, a))]
+    assert extra == ['gen_total_loss'], extra
