@@ -256,6 +256,76 @@ def test_two_rank_hip_trainer_matches_reference_golden_and_overlaps(golden):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# round 6: estimate3 at world sizes where the GLOBAL first four samples do not live on rank 0 alone.  The golden
+# case has 8 samples per domain: 4 ranks hold 2 each (the first four are spread over ranks 0 and 1), 8 ranks hold 1 each (ranks 0 - 3).
+# `dist.global_first` must hand every rank the same four; the result is the reference's own global-batch run.
+# ---------------------------------------------------------------------------------------------------------------
+def _estimate_golden_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    os.environ['LSPS_BUCKET_BYTES'] = str(1 << 16)
+    from lsps_amd import options
+    options.reload_env()
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import lsps_amd.trainers as prod
+        from collections import OrderedDict
+        hp = cases.hp_for('tiny')
+        A = cases.NativeAdapter(prod, 'cuda')
+        sds = cases.make_weights(hp, lsps_ref)
+        R = OrderedDict()
+        post_n, zd = 8, hp['vae']['z_dim']
+        per = post_n // world
+        sl = slice(rank * per, (rank + 1) * per)
+        bp = cases.make_inputs(post_n)
+        shard = {k: v[sl] for k, v in bp.items()}
+        latp = cases.latent_shape(hp, 8)
+        for mode in (3, 4):
+            tr = A.make_trainer(hp, sds)
+            A.set_train(tr, True)
+            for it in range(2):
+                A.post_update(tr, shard, mode, hp, cases.noise(latp, 5000 + it), cases.noise((post_n, zd), 6000 + it, 0.05)[sl],
+                              cases.noise((post_n, zd), 7000 + it, 0.05)[sl])
+                R['estimate%d.it%d.scalars' % (mode, it)] = A.scalars(tr)
+                R['estimate%d.it%d.dis.params' % (mode, it)] = A.params(tr, 'dis')
+        torch.cuda.synchronize()
+        if rank == 0:
+            out.put(R)
+    except Exception as e:                                       # the parent would otherwise wait for its timeout
+        import traceback
+        if rank == 0:
+            out.put('error: ' + repr(e) + traceback.format_exc())
+        raise
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_estimate_modes_at_world_4_and_8_match_the_references_global_batch_golden(world, golden):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_estimate_golden_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    R = out.get(timeout=900)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert not isinstance(R, str), R
+    g = {k: v for k, v in golden('tiny').items() if k.split('/')[0] in R}
+    assert len(g) > 80, len(g)
+    bad, worst = cases.compare(R, g, 1e-3, grad_rtol=2e-2)
+    print("world", world, "worst rel err", worst)
+    assert not bad, "worst=%g first failures: %s" % (worst, bad[:8])
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # round 3: data-parallel steps replayed from hipGraphs (the bucket all-reduces are captured RCCL launches) and the
 # estimate modes' side stream under data parallelism.  One rank on RCCL (LSPS_FORCE_DP=1): RCCL refuses two ranks on one
 # device, so this pins the capture / replay machinery and its bookkeeping, not a transfer.

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-iteration deviation of the HIP trainer's loss scalars from the CPU oracle's over a training trajectory
-(tests/golden/cases.py: run_trajectory; tests/test_trajectory_gpu.py holds the bound).  Usage: python tools/trajectory_report.py [tiny|full]"""
+(tests/golden/cases.py: run_trajectory; tests/test_trajectory_gpu.py holds the bound).  Usage: python tools/trajectory_report.py [tiny|full] [f32|bf16]"""
 import os
 import sys
 
@@ -13,6 +13,7 @@ from oracle import lsps_ref   # noqa: E402
 import lsps_amd.trainers as prod   # noqa: E402
 
 config = sys.argv[1] if len(sys.argv) > 1 else 'tiny'
+mode = sys.argv[2] if len(sys.argv) > 2 else 'f32'          # 'bf16': the HIP trainer in the bf16 math mode (BASELINE config 5's arithmetic)
 kw = dict() if config == 'tiny' else dict(n=4, n_pre=5, n_est=5, held_out=16, cadence=2)
 torch.set_num_threads(8)
 O = cases.NativeAdapter(lsps_ref, 'cpu', trainer_kwargs=dict(literal=False))
@@ -20,7 +21,13 @@ A = cases.NativeAdapter(prod, 'cuda')
 ref = cases.run_trajectory(O, config, lsps_ref, **kw)
 pert = [cases.run_trajectory(O, config, lsps_ref, perturb=p, **kw) for p in (1e-5, 3e-5)]
 env = cases.trajectory_envelope(ref, pert)
-got = cases.run_trajectory(A, config, lsps_ref, **kw)
+from lsps_amd import ops   # noqa: E402
+ops.set_math_mode(mode)
+try:
+    got = cases.run_trajectory(A, config, lsps_ref, **kw)
+finally:
+    ops.set_math_mode('f32')
+print('HIP trainer math mode:', mode)
 names = sorted(set(n for it in ref['scalars'].values() for n in it))
 print('%-16s' % 'iteration' + ''.join('%15s' % n[-14:] for n in names))
 for it, k in enumerate(ref['scalars']):
