@@ -212,7 +212,9 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
   // prologue: first loads go out before the LDS zero fill
   load_rows(0);
   load_u(0);
+#ifndef W4_ABL_NOZERO          // (ablations: timing only, results wrong)
   for (int u = tid; u < 2 * W4_BUF / 4; u += 512) reinterpret_cast<f32x4 *>(w4_lds)[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
   for (int q = 0; q < 9; ++q)
 #pragma unroll
@@ -505,6 +507,10 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
     __syncthreads();                             // phase-2 regions are read
     float *red = w4_lds;                         // [pass 2][wt 2][wp 4][half 2][i 4]
     float mean[4], rs[4];
+#ifdef W4_ABL_NOSTATS
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { mean[i] = 0.f; rs[i] = 1.f; }
+#else
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       float s[4];
@@ -536,6 +542,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
           rs[i] = rsqrtf(tot * (1.f / 1024.f) + p.eps);
       }
     }
+#endif
     if (l31 == 0 && wt == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) p.rstd[(long)n * p.M + kbase + i] = rs[i];
@@ -553,6 +560,9 @@ __global__ __launch_bounds__(512, 1) void wino4_f3x3_kernel(Wino4Params p) {
           o[x] = v;
         }
         if (p.norm == 2) o += res[i][yy];
+#ifdef W4_ABL_NOSTORE
+        if (o[0] == 123.456f)
+#endif
         *reinterpret_cast<f32x4 *>(ym + yy * 32) = o;
       }
     }
